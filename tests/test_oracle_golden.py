@@ -1,0 +1,192 @@
+"""Pin the oracle (oracle/mtm_oracle.py) to golden vectors captured from the real reference
+(tests/golden/make_golden.py).  CPU only.  Bit-exactness is expected on the tiny config (same
+torch build, same op order); full-size configs use a 1e-5-relative bar because the reference's
+native TransformerEncoderLayer fast path fuses ops differently from the restatement."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from m3pc_amd import synth
+from oracle import mtm_oracle as O
+
+GD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(GD, name), allow_pickle=False)
+
+
+def _close(a, b, rtol, atol, what=""):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    err = np.abs(a - b)
+    lim = atol + rtol * np.abs(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert (err <= lim).all(), f"{what}: max err {err.max():.3e}, max ref {np.abs(b).max():.3e}"
+
+
+# ------------------------------------------------------------------------------------- masks
+@pytest.mark.parametrize("T,idx", [(8, 4), (16, 0), (32, 16), (8, 0), (8, 7)])
+def test_masks_kat(T, idx):
+    g = _load("g4_masks.npz")
+    for nm, fn in (("rcbc", O.rcbc_mask), ("fd", O.fd_mask), ("pi", O.pi_mask), ("fid", O.fid_mask),
+                   ("gid", O.gid_mask)):
+        m = fn(T, idx)
+        got = np.stack([m[k] for k in O.KEYS]).astype(np.uint8)
+        assert np.array_equal(got, g[f"{nm}_T{T}_i{idx}"]), (nm, T, idx)
+
+
+# ------------------------------------------------------------------------------------- G1 tiny
+@pytest.fixture(scope="module")
+def tiny():
+    dims = synth.Dims(11, 3, 8, n_embd=64, n_head=2)
+    return dict(dims=dims, sd=synth.make_state_dict(dims, 0),
+                stats=O.make_stats(synth.make_tokenizer_stats(dims, 0)),
+                critic=synth.make_critic(dims, 0), g=_load("g1_tiny.npz"))
+
+
+@pytest.mark.parametrize("mode,temp", [("rtg", 0.01), ("critic", 1.0), ("noise", 1.0)])
+@pytest.mark.parametrize("pl", [0, 3, 100, 998])
+def test_g1_plan_step(tiny, mode, temp, pl):
+    g, dims = tiny["g"], tiny["dims"]
+    N, H = 16, 4
+    cfg = O.PlanCfg(8, H, N, 0.99, temp, 0.6, n_head=2)
+    win, h = O.assemble_window(cfg, synth.make_history(dims, 0), pl, 3.0)
+    pre = f"{mode}_pl{pl}_"
+    assert h == int(g[pre + "horizon"])
+    for k in win:
+        assert win[k].dtype == (torch.float64 if k == "returns" else torch.float32)
+        assert np.array_equal(win[k].numpy(), g[pre + "win_" + k]), k
+    gen = torch.Generator().manual_seed(123 if mode == "noise" else 77)
+    eps = torch.randn((N, h, 3), generator=gen) if mode == "noise" else torch.from_numpy(g["eps"])
+    taps = {}
+    r = O.guiding(tiny["sd"], tiny["stats"], cfg, win, h, 0.6, eps, mode, critic=tiny["critic"], generator=gen,
+                  taps=taps)
+    tol = dict(rtol=1e-6, atol=1e-6)
+    _close(r["loc"], g[pre + "loc"], what="loc", **tol)
+    _close(r["std"], g[pre + "std"], what="std", **tol)
+    _close(r["sample_actions"], g[pre + "sample_actions"], what="sample_actions", **tol)
+    er = r["expect_return"] - r["expect_return"].max()
+    _close(er, g[pre + "expect_return"], rtol=1e-5, atol=1e-5, what="expect_return")
+    _close(r["p"], g[pre + "p"], rtol=1e-5, atol=1e-7, what="p")
+    _close(r["eval_action"], g[pre + "eval_action"], rtol=1e-5, atol=1e-6, what="eval_action")
+    assert int(r["sample_idx"]) == int(g[pre + "sample_idx"].reshape(-1)[0])
+    assert int(torch.argmax(r["expect_return"])) == int(np.argmax(g[pre + "expect_return"]))
+    _close(r["sample_action"], g[pre + "sample_action"], what="sample_action", **tol)
+    T = 8
+    for k in ("rewards", "returns") if mode == "rtg" else ("states", "rewards"):
+        _close(taps["dec_" + k], g[pre + "dec_" + k], rtol=1e-5, atol=1e-5, what="dec_" + k)
+    if pl == 100:
+        for nm in ("enc_in", "enc_out", "dec_in", "dec_out"):
+            _close(taps[nm], g[pre + nm + "_pass2"], rtol=1e-5, atol=1e-5, what=nm)
+
+
+@pytest.mark.parametrize("pl", [0, 100])
+def test_g1_noplan(tiny, pl):
+    g, dims = tiny["g"], tiny["dims"]
+    cfg = O.PlanCfg(8, 4, 16, n_head=2)
+    win, h = O.assemble_window(cfg, synth.make_history(dims, 0), pl, 3.0)
+    eps = torch.from_numpy(g[f"noplan_pl{pl}_eps"])
+    sa, ea = O.mtm_sampling(tiny["sd"], tiny["stats"], cfg, win, h, eps)
+    _close(ea, g[f"noplan_pl{pl}_eval_action"], 1e-6, 1e-6, "eval")
+    _close(sa, g[f"noplan_pl{pl}_sample_action"], 1e-6, 1e-6, "sample")
+
+
+def test_g1_explore_rtg(tiny):
+    rtg = O.explore_rtg(tiny["stats"], 0.8)
+    assert np.array_equal(tiny["g"]["explore_returns"], rtg * np.ones((1, 8, 1)))
+
+
+# ------------------------------------------------------------------------------------- G2 full size
+def _full_setup(name):
+    g = _load(f"g2_{name}.npz")
+    S, A, T, H, N = [int(v) for v in g["cfg"]]
+    dims = synth.Dims(S, A, T)
+    sd = synth.make_state_dict(dims, 0)
+    stats = O.make_stats(synth.make_tokenizer_stats(dims, 0))
+    mode = str(g["mode"])
+    cfg = O.PlanCfg(T, H, N, 0.99, float(g["temperature"]), 0.6)
+    win, h = O.assemble_window(cfg, synth.make_history(dims, 0), 500, 3.0)
+    assert h == H
+    return g, dims, sd, stats, mode, cfg, win
+
+
+@pytest.mark.parametrize("name", ["c1", "c2s", "c2"])
+def test_g2_full_step(name):
+    g, dims, sd, stats, mode, cfg, win = _full_setup(name)
+    N, H, T = cfg.action_samples, cfg.horizon, cfg.traj_length
+    eps = synth.make_eps(N, dims, 1)
+    gen = torch.Generator().manual_seed(77)
+    r = O.guiding(sd, stats, cfg, win, H, 0.6, eps, mode, critic=synth.make_critic(dims, 0), generator=gen)
+    _close(r["loc"], g["loc"], 1e-5, 1e-5, "loc")
+    _close(r["std"], g["std"], 1e-5, 1e-6, "std")
+    rows = g["rows"]
+    _close(r["sample_actions"][rows], g["sample_actions_rows"], 1e-5, 1e-5, "sample_actions")
+    er = (r["expect_return"] - r["expect_return"].max()).numpy()
+    # rtg scores are 1000 x predicted returns: 1e-5 relative to the score magnitude (~1e3)
+    scale = float(np.abs(r["expect_return"].numpy()).max())
+    _close(er, g["expect_return_shifted"], rtol=0, atol=2e-5 * scale, what="expect_return")
+    assert r["argmax"] == int(g["argmax"])
+    assert set(torch.topk(r["expect_return"], 8).indices.tolist()) == set(g["top32"][:8].tolist())
+    _close(r["p"], g["p"], rtol=1e-4, atol=1e-8, what="p")
+    _close(r["eval_action"], g["eval_action"], rtol=1e-5, atol=1e-6, what="eval_action")
+    assert int(r["sample_idx"]) == int(g["sample_idx"].reshape(-1)[0])
+
+
+def test_g2_critic_subset():
+    """C3 (walker2d, critic-scored, N=4096): a 256-candidate subset incl. the reference argmax."""
+    g, dims, sd, stats, mode, cfg, win = _full_setup("c3")
+    N, H, T = cfg.action_samples, cfg.horizon, cfg.traj_length
+    eps = synth.make_eps(N, dims, 1)
+    sel = np.unique(np.concatenate([np.arange(0, N, 17)[:240], g["top32"][:16]]))
+    loc, std = O.policy_pass(sd, stats, cfg, win, H)
+    _close(loc, g["loc"], 1e-5, 1e-5, "loc")
+    acts = O.sample_candidates(loc, std, eps[sel], T, H)
+    er = O.plan_candidates(sd, stats, cfg, win, H, acts, "critic", 0.6, synth.make_critic(dims, 0)).numpy()
+    ref = g["expect_return_shifted"][sel]
+    _close(er - er.max(), ref - ref.max(), rtol=0, atol=2e-5, what="expect_return subset")
+    assert sel[int(np.argmax(er))] == int(g["argmax"])
+
+
+def test_g2_c4_block():
+    """C4 (halfcheetah, N=16384, T=64): first 512-candidate block of the sharded config."""
+    g, dims, sd, stats, mode, cfg, win = _full_setup("c4")
+    N, H, T = cfg.action_samples, cfg.horizon, cfg.traj_length
+    b0, b1 = [int(v) for v in g["blocks"][0]]
+    eps = synth.make_eps(N, dims, 1)[b0:b0 + 128]
+    loc, std = O.policy_pass(sd, stats, cfg, win, H)
+    _close(loc, g["loc"], 1e-5, 1e-5, "loc")
+    acts = O.sample_candidates(loc, std, eps, T, H)
+    taps = {}
+    er = O.plan_candidates(sd, stats, cfg, win, H, acts, "rtg", 0.6, taps=taps).numpy()
+    _close(taps["rewards"], g["dec_rewards_blocks"][0][:128], 1e-5, 2e-5, "rewards")
+    _close(taps["boot"] / 1000, g["dec_returns_blocks"][0][:128], 1e-5, 2e-5, "returns")
+    ref = g["expect_return_shifted_blocks"][0][:128]
+    scale = float(np.abs(er).max())
+    _close(er - er[0], ref - ref[0], rtol=0, atol=2e-5 * scale, what="expect_return block")
+
+
+# ------------------------------------------------------------------------------------- G3 zero-shot
+@pytest.mark.parametrize("pl", [0, 2, 37, 997])
+def test_g3_zeroshot(pl):
+    g = _load("g3_zeroshot.npz")
+    dims = synth.Dims(11, 3, 8)
+    sd = synth.make_state_dict(dims, 0)
+    stats = O.make_stats(synth.make_tokenizer_stats(dims, 0))
+    cfg = O.PlanCfg(8, 4, 1)
+    hist = synth.make_history(dims, 0)
+    hist["observations"] = g[f"obs_pl{pl}"]
+    win, h = O.assemble_goal_window(cfg, hist, pl, 2.5)
+    assert h == int(g[f"action_piid_sample_pl{pl}_horizon"])
+    assert np.array_equal(win["states"].numpy(), g[f"action_id_sample_pl{pl}_win_states"])
+    loc, std, inferred = O.goal_piid(sd, stats, cfg, win, h)
+    pre = f"action_piid_sample_pl{pl}_"
+    _close(inferred, g[pre + "state_inference"], 1e-5, 1e-5, "state_inference")
+    _close(loc, g[pre + "loc"], 1e-5, 1e-5, "piid loc")
+    _close(torch.tanh(loc)[0, 8 - h], g[pre + "eval_action"], 1e-5, 1e-5, "piid eval_action")
+    loc2, std2 = O.goal_id(sd, stats, cfg, win, h)
+    pre = f"action_id_sample_pl{pl}_"
+    _close(loc2, g[pre + "loc"], 1e-5, 1e-5, "id loc")
+    _close(std2, g[pre + "std"], 1e-5, 1e-6, "id std")
+    _close(torch.tanh(loc2)[0, 8 - h], g[pre + "eval_action"], 1e-5, 1e-5, "id eval_action")
