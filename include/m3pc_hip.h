@@ -1,0 +1,163 @@
+/*
+ * m3pc_hip.h -- C ABI of libm3pc_hip.so, the MI355X (gfx950) implementation of the m3pc
+ * test-time MPC plan step.
+ *
+ * The reference (wkh923/m3pc) is pure Python/PyTorch and has no native interface; the entry
+ * points below are what a ctypes binding for its hot path binds (INTEGRATION.md shows the
+ * stub).  Each function names the reference code it replaces (paths relative to the
+ * reference root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative M3PC_E* code on failure;
+ *     m3pc_last_error() returns a thread-local message for the last failure.
+ *   - "device" pointers are HIP device pointers owned by the caller (e.g. tensor.data_ptr());
+ *     they must stay alive until the stream has been synchronised.  "host" pointers are
+ *     ordinary process memory and are consumed before the call returns.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).  Calls enqueue work on
+ *     it and return without synchronising unless documented otherwise.
+ *   - one handle per (process, device); a handle is not re-entrant.
+ *   - all tensors are dense row-major fp32 unless stated otherwise.
+ */
+#ifndef M3PC_HIP_H
+#define M3PC_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M3PC_ABI_VERSION 1
+
+#define M3PC_OK 0
+#define M3PC_EINVAL (-1)   /* bad argument / shape mismatch            */
+#define M3PC_ESTATE (-2)   /* weights / tokenizer / critic not loaded  */
+#define M3PC_EHIP (-3)     /* HIP runtime error                        */
+#define M3PC_ENOMEM (-4)   /* workspace too small for the request      */
+
+/* modality order everywhere: the reference's dict insertion order
+ * states, actions, rewards, returns (finetune_omtm/learner.py:348-366; mtm_model.py:625,676) */
+#define M3PC_STATES 0
+#define M3PC_ACTIONS 1
+#define M3PC_REWARDS 2
+#define M3PC_RETURNS 3
+
+/* plan_guidance modes (finetune_omtm/learner.py:389-407) */
+#define M3PC_MODE_RTG 0     /* rtg_guiding            learner.py:271-327 */
+#define M3PC_MODE_CRITIC 1  /* critic_lambda_guiding  learner.py:211-268 */
+#define M3PC_MODE_NOISE 2   /* noise_adding_lambda    learner.py:142-208 */
+
+/* arithmetic of the batched candidate pass */
+#define M3PC_PREC_FP32 0  /* fp32 operands, f32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate */
+#define M3PC_PREC_BF16 1  /* bf16 operands, bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate,
+                             fp32 residual stream / LayerNorm / softmax */
+
+typedef struct m3pc_handle m3pc_handle;
+
+/* static sizes of one planner instance: omtmConfig + data_shapes + traj_length
+ * (mtm_model.py:200-221, 324-344; finetune_omtm/config.yaml:5,29-34) */
+typedef struct m3pc_dims {
+    int state_dim;      /* S */
+    int action_dim;     /* A */
+    int traj_length;    /* T  (cfg.traj_length == model max_len) */
+    int n_embd;         /* d, multiple of 64 */
+    int n_head;
+    int n_enc_layer;
+    int n_dec_layer;
+    int max_candidates; /* largest n_count a plan_step call will use on this device */
+    int max_batch;      /* largest B for m3pc_forward */
+    int critic_hidden;  /* TwinQ hidden width (256), 0 = no critic */
+} m3pc_dims;
+
+/* one entry of a state_dict: fp32, contiguous, torch layout */
+typedef struct m3pc_named_tensor {
+    const char* name;   /* e.g. "encoder.layers.0.self_attn.in_proj_weight" */
+    const float* data;
+    long long numel;
+    int on_device;      /* 0: host pointer, 1: device pointer */
+} m3pc_named_tensor;
+
+typedef struct m3pc_plan_args {
+    int mode;          /* M3PC_MODE_*                                                        */
+    int precision;     /* M3PC_PREC_* for the candidate pass (the policy pass is always fp32) */
+    int horizon;       /* effective h of this step (learner.py:342-345)                      */
+    int n_total;       /* cfg.action_samples: leading dimension of eps                       */
+    int n_begin;       /* first candidate scored by this call (candidate sharding)           */
+    int n_count;       /* number of candidates scored by this call                           */
+    double lmbda;      /* TD(lambda) mixing, python float in the reference (learner.py:313-316) */
+    double discount;   /* gamma (learner.py:307-309)                                         */
+    double rtg;        /* return-to-go written into every returns slot (learner.py:368-385)  */
+} m3pc_plan_args;
+
+const char* m3pc_last_error(void);
+int m3pc_abi_version(void);
+
+/* Learner.__init__'s model construction (learner.py:32-36): allocates handle, weight arena and
+ * workspace on `device`.  Synchronous. */
+int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out);
+int m3pc_destroy(m3pc_handle* h);
+
+/* omtm.load_state_dict (learner.py:33-35): tensors by state_dict name.
+ * Unknown names are ignored; every required name must be present.  Re-callable after each
+ * fine-tuning update (finetune.py:306); invalidates cached mask-pattern tables.  Synchronous. */
+int m3pc_load_weights(m3pc_handle* h, const m3pc_named_tensor* tensors, int n, void* stream);
+
+/* ContinuousTokenizer(mean, std, stats, normalize) (tokenizers/continuous.py:31-62):
+ * host arrays of `dim` floats. */
+int m3pc_set_tokenizer(m3pc_handle* h, int key, const float* mean, const float* std, int dim, int normalize);
+
+/* TwinQ weights (finetune_omtm/model.py:146-171): "q1.net.0.weight" ... "q2.net.4.bias",
+ * plus the observation mean / std attributes (host, state_dim floats each). */
+int m3pc_set_critic(m3pc_handle* h, const m3pc_named_tensor* tensors, int n, const float* obs_mean,
+                    const float* obs_std, void* stream);
+
+/* ContinuousTokenizer.encode / decode (tokenizers/continuous.py:68-94) on device rows:
+ * out = (in - mean) / std   resp.  out = in * std + mean  (identity when normalize == 0).
+ * `in_f64` != 0: the input rows are float64 and are normalised in float64 before the cast
+ * (the reference's behaviour for `returns`, learner.py:371-374). */
+int m3pc_tokenize(m3pc_handle* h, int key, const void* in, int in_f64, float* out, long long rows, void* stream);
+int m3pc_detokenize(m3pc_handle* h, int key, const float* in, float* out, long long rows, void* stream);
+
+/* omtm.forward (mtm_model.py:593-607) for one token per timestep and modality.
+ *   tokens[k]  device (B,T,D_k) tokenised inputs
+ *   masks[k]   host   (T,) 0/1 bytes, shared by the batch (mtm_model.py:572-575)
+ *   out_*      device, may be NULL to skip a head:
+ *              out_states (B,T,S), out_rewards (B,T,1), out_returns (B,T,1)   raw head outputs
+ *              out_mu / out_std (B,T,A)     DiagGaussianActor loc / std (mtm_model.py:313-321)
+ */
+int m3pc_forward(m3pc_handle* h, int batch, const float* const tokens[4], const unsigned char* const masks[4],
+                 float* out_states, float* out_rewards, float* out_returns, float* out_mu, float* out_std,
+                 int precision, void* stream);
+
+/* One MPC plan step up to (not including) the cross-candidate select:
+ * rtg_guiding / critic_lambda_guiding / noise_adding_lambda (learner.py:142-316).
+ *   states/actions/rewards   device (T,S) (T,A) (T,1): the raw (un-normalised) window assembled by
+ *                            action_sample (learner.py:348-366), future rows zero
+ *   eps       device standard normals: (n_total,T,A) for RTG/CRITIC -- the reference draws
+ *             dist.sample((N,)) over every timestep (learner.py:285-287) -- or (n_total,h,A)
+ *             for NOISE (learner.py:157-163)
+ *   loc,std   device out (T,A), optional: the policy pass distribution
+ *   sample_actions  device out (n_count,h,A): candidates [n_begin, n_begin+n_count)
+ *   expect_return   device out (n_count,): TD(lambda) scores BEFORE the max shift
+ *   pred_rewards, pred_boot  device out (n_count,h), optional: decoded predicted rewards and
+ *             the bootstrap term (1000 x predicted return, or min(q1,q2))
+ */
+int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* args, const float* states, const float* actions,
+                   const float* rewards, const float* eps, float* loc, float* std, float* sample_actions,
+                   float* expect_return, float* pred_rewards, float* pred_boot, void* stream);
+
+/* The cross-candidate tail (learner.py:318-323) over all N candidates (after an all-gather when
+ * sharded): p = softmax(temperature * (E - max E)), eval_action = sum p*a0 / sum p, argmax E.
+ *   a0 device (n, A) rows with stride a0_stride floats (sample_actions[:,0,:] => stride h*A)
+ *   p device out (n,), eval_action device out (A,), argmax device out (1,) -- each optional */
+int m3pc_select(m3pc_handle* h, const float* expect_return, const float* a0, long long a0_stride, int n,
+                float temperature, float* p, float* eval_action, int* argmax, void* stream);
+
+/* kernel-level timing of the last plan_step for bench.py / profiling: when enabled the library
+ * brackets the dominant kernel class (the MFMA GEMMs) with hipEvents on `stream`. */
+int m3pc_profile_enable(m3pc_handle* h, int enable);
+/* sums since the last reset: gemm launches, gemm milliseconds, gemm flops (2*M*N*K) */
+int m3pc_profile_read(m3pc_handle* h, long long* launches, double* gemm_ms, double* gemm_flops, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M3PC_HIP_H */

@@ -1,0 +1,252 @@
+"""ctypes binding of libm3pc_hip.so (C ABI: include/m3pc_hip.h).
+
+``import torch`` happens first on purpose: the library's DT_NEEDED ``libamdhip64.so.7`` then resolves to
+the HIP runtime torch already loaded, so device pointers and streams are shared with PyTorch-ROCm.
+The HIP extension is mandatory: if the shared object is missing this module raises -- there is no CPU
+fallback anywhere in ``m3pc_amd``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Sequence
+
+import torch  # noqa: F401  (must precede the CDLL below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libm3pc_hip.so")
+
+STATES, ACTIONS, REWARDS, RETURNS = 0, 1, 2, 3
+KEYS = ("states", "actions", "rewards", "returns")
+MODE_RTG, MODE_CRITIC, MODE_NOISE = 0, 1, 2
+PREC_FP32, PREC_BF16 = 0, 1
+ABI_VERSION = 1
+
+EXPORTS = (
+    "m3pc_last_error", "m3pc_abi_version", "m3pc_create", "m3pc_destroy", "m3pc_load_weights",
+    "m3pc_set_tokenizer", "m3pc_set_critic", "m3pc_tokenize", "m3pc_detokenize", "m3pc_forward",
+    "m3pc_plan_step", "m3pc_select", "m3pc_profile_enable", "m3pc_profile_read",
+)
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "state_dim", "action_dim", "traj_length", "n_embd", "n_head", "n_enc_layer", "n_dec_layer",
+        "max_candidates", "max_batch", "critic_hidden")]
+
+
+class NamedTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_longlong), ("on_device", C.c_int)]
+
+
+class PlanArgs(C.Structure):
+    _fields_ = [("mode", C.c_int), ("precision", C.c_int), ("horizon", C.c_int), ("n_total", C.c_int),
+                ("n_begin", C.c_int), ("n_count", C.c_int), ("lmbda", C.c_double), ("discount", C.c_double),
+                ("rtg", C.c_double)]
+
+
+class M3pcError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the library (no GPU needed) and declare the prototypes."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise M3pcError(f"{p} not found: build it with `python -m m3pc_amd.build` "
+                        "(m3pc_amd has no fallback path without its HIP library)")
+    lib = C.CDLL(p)
+    vp, i, ll, f, d = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
+    lib.m3pc_last_error.restype = C.c_char_p
+    lib.m3pc_last_error.argtypes = []
+    lib.m3pc_abi_version.restype = i
+    protos = {
+        "m3pc_create": [C.POINTER(Dims), i, C.POINTER(vp)],
+        "m3pc_destroy": [vp],
+        "m3pc_load_weights": [vp, C.POINTER(NamedTensor), i, vp],
+        "m3pc_set_tokenizer": [vp, i, C.POINTER(f), C.POINTER(f), i, i],
+        "m3pc_set_critic": [vp, C.POINTER(NamedTensor), i, C.POINTER(f), C.POINTER(f), vp],
+        "m3pc_tokenize": [vp, i, vp, i, vp, ll, vp],
+        "m3pc_detokenize": [vp, i, vp, vp, ll, vp],
+        "m3pc_forward": [vp, i, C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp, vp, i, vp],
+        "m3pc_plan_step": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "m3pc_select": [vp, vp, vp, ll, i, f, vp, vp, vp, vp],
+        "m3pc_profile_enable": [vp, i],
+        "m3pc_profile_read": [vp, C.POINTER(ll), C.POINTER(d), C.POINTER(d), i],
+    }
+    for name, args in protos.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = i
+    if lib.m3pc_abi_version() != ABI_VERSION:
+        raise M3pcError(f"ABI mismatch: library {lib.m3pc_abi_version()} vs binding {ABI_VERSION}")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise M3pcError(f"m3pc error {rc}: {load_library().m3pc_last_error().decode()}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _named(sd: Dict[str, torch.Tensor]):
+    """state_dict -> (NamedTensor array, keep-alive list).  Tensors are made fp32-contiguous."""
+    keep = []
+    arr = (NamedTensor * len(sd))()
+    for j, (k, v) in enumerate(sd.items()):
+        t = v.detach().to(torch.float32).contiguous()
+        nb = k.encode()
+        keep.append((t, nb))
+        arr[j] = NamedTensor(nb, t.data_ptr(), t.numel(), 1 if t.is_cuda else 0)
+    return arr, keep
+
+
+class Handle:
+    """RAII wrapper of one m3pc_handle (one per process and GPU)."""
+
+    def __init__(self, state_dim, action_dim, traj_length, n_embd=512, n_head=4, n_enc_layer=2, n_dec_layer=1,
+                 max_candidates=1024, max_batch=1, critic_hidden=256, device: int = 0):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise M3pcError("no HIP device visible: m3pc_amd runs only on a GPU (there is no CPU path)")
+        self.device = torch.device("cuda", device)
+        self.dims = Dims(state_dim, action_dim, traj_length, n_embd, n_head, n_enc_layer, n_dec_layer,
+                         max_candidates, max_batch, critic_hidden)
+        self._h = C.c_void_p()
+        torch.cuda.init()
+        with torch.cuda.device(self.device):
+            check(self.lib.m3pc_create(C.byref(self.dims), device, C.byref(self._h)))
+        self.T, self.S, self.A = traj_length, state_dim, action_dim
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.m3pc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- setup -------------------------------------------------------------------------------------
+    def load_weights(self, state_dict: Dict[str, torch.Tensor]):
+        arr, keep = _named(state_dict)
+        check(self.lib.m3pc_load_weights(self._h, arr, len(state_dict), _stream(self.device)))
+        del keep
+
+    def set_tokenizer(self, key: int, mean, std, normalize: bool):
+        m = torch.as_tensor(mean, dtype=torch.float32).contiguous().cpu().reshape(-1)
+        s = torch.as_tensor(std, dtype=torch.float32).contiguous().cpu().reshape(-1)
+        fp = C.POINTER(C.c_float)
+        check(self.lib.m3pc_set_tokenizer(self._h, key, C.cast(m.data_ptr(), fp), C.cast(s.data_ptr(), fp),
+                                          m.numel(), int(bool(normalize))))
+
+    def set_critic(self, q_state_dict: Dict[str, torch.Tensor], obs_mean, obs_std):
+        arr, keep = _named(q_state_dict)
+        m = torch.as_tensor(obs_mean, dtype=torch.float32).contiguous().cpu().reshape(-1)
+        s = torch.as_tensor(obs_std, dtype=torch.float32).contiguous().cpu().reshape(-1)
+        fp = C.POINTER(C.c_float)
+        check(self.lib.m3pc_set_critic(self._h, arr, len(q_state_dict), C.cast(m.data_ptr(), fp),
+                                       C.cast(s.data_ptr(), fp), _stream(self.device)))
+        del keep
+
+    # -- tokenizer ---------------------------------------------------------------------------------
+    def tokenize(self, key: int, x: torch.Tensor) -> torch.Tensor:
+        assert x.is_cuda and x.dtype in (torch.float32, torch.float64)
+        x = x.contiguous()
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        rows = x.numel() // x.shape[-1]
+        check(self.lib.m3pc_tokenize(self._h, key, _ptr(x), int(x.dtype == torch.float64), _ptr(out), rows,
+                                     _stream(self.device)))
+        return out
+
+    def detokenize(self, key: int, y: torch.Tensor) -> torch.Tensor:
+        y = y.contiguous()
+        out = torch.empty_like(y)
+        check(self.lib.m3pc_detokenize(self._h, key, _ptr(y), _ptr(out), y.numel() // y.shape[-1],
+                                       _stream(self.device)))
+        return out
+
+    # -- model -------------------------------------------------------------------------------------
+    def forward(self, tokens: Sequence[Optional[torch.Tensor]], masks: Sequence, want=KEYS, precision=PREC_FP32):
+        """tokens[k]: (B,T,D_k) fp32 cuda; masks[k]: (T,) 0/1.  Returns dict of raw head outputs;
+        'actions' -> (mu, std)."""
+        B = next(t.shape[0] for t in tokens if t is not None)
+        toks = [None if t is None else t.to(torch.float32).contiguous() for t in tokens]
+        tp = (C.c_void_p * 4)(*[None if t is None else t.data_ptr() for t in toks])
+        mb = [bytes(bytearray(int(v != 0) for v in m)) for m in masks]
+        mbuf = [C.create_string_buffer(b, len(b)) for b in mb]
+        mp = (C.c_void_p * 4)(*[C.addressof(b) for b in mbuf])
+        dev = self.device
+        feat = (self.S, self.A, 1, 1)
+        out = {}
+        for k, name in enumerate(KEYS):
+            if name in want and k != ACTIONS:
+                out[name] = torch.empty((B, self.T, feat[k]), dtype=torch.float32, device=dev)
+        mu = sd = None
+        if "actions" in want:
+            mu = torch.empty((B, self.T, self.A), dtype=torch.float32, device=dev)
+            sd = torch.empty_like(mu)
+            out["actions"] = (mu, sd)
+        check(self.lib.m3pc_forward(self._h, B, tp, mp, _ptr(out.get("states")), _ptr(out.get("rewards")),
+                                    _ptr(out.get("returns")), _ptr(mu), _ptr(sd), precision, _stream(dev)))
+        return out
+
+    # -- plan step ---------------------------------------------------------------------------------
+    def plan_step(self, mode: int, states, actions, rewards, eps, horizon: int, rtg: float, lmbda: float,
+                  discount: float, n_total: int, n_begin: int = 0, n_count: Optional[int] = None,
+                  precision: int = PREC_FP32, want_debug: bool = False):
+        n_count = n_total - n_begin if n_count is None else n_count
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        loc = torch.empty((self.T, self.A), **f32)
+        std = torch.empty((self.T, self.A), **f32)
+        acts = torch.empty((n_count, horizon, self.A), **f32)
+        er = torch.empty((n_count,), **f32)
+        pr = torch.empty((n_count, horizon), **f32) if want_debug else None
+        pb = torch.empty((n_count, horizon), **f32) if want_debug else None
+        args = PlanArgs(mode, precision, horizon, n_total, n_begin, n_count, lmbda, discount, rtg)
+        ins = [t.to(torch.float32).contiguous() for t in (states, actions, rewards, eps)]
+        check(self.lib.m3pc_plan_step(self._h, C.byref(args), _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), _ptr(ins[3]),
+                                      _ptr(loc), _ptr(std), _ptr(acts), _ptr(er), _ptr(pr), _ptr(pb), _stream(dev)))
+        res = dict(loc=loc, std=std, sample_actions=acts, expect_return=er)
+        if want_debug:
+            res["pred_rewards"], res["pred_boot"] = pr, pb
+        return res
+
+    def select(self, expect_return: torch.Tensor, a0: torch.Tensor, temperature: float):
+        """a0: (N, A) view (may be a strided slice sample_actions[:, 0])."""
+        n = expect_return.numel()
+        assert a0.shape[0] == n and a0.stride(-1) == 1
+        dev = self.device
+        p = torch.empty((n,), dtype=torch.float32, device=dev)
+        ev = torch.empty((self.A,), dtype=torch.float32, device=dev)
+        am = torch.empty((1,), dtype=torch.int32, device=dev)
+        check(self.lib.m3pc_select(self._h, _ptr(expect_return.contiguous()), _ptr(a0), a0.stride(0), n,
+                                   float(temperature), _ptr(p), _ptr(ev), _ptr(am), _stream(dev)))
+        return p, ev, am
+
+    # -- profiling ---------------------------------------------------------------------------------
+    def profile_enable(self, on: bool):
+        check(self.lib.m3pc_profile_enable(self._h, int(on)))
+
+    def profile_read(self, reset: bool = True):
+        n, ms, fl = C.c_longlong(), C.c_double(), C.c_double()
+        check(self.lib.m3pc_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(fl), int(reset)))
+        return n.value, ms.value, fl.value

@@ -1,0 +1,242 @@
+// softmax(Q K^T / sqrt(hd)) V on the matrix cores, whole key range resident in registers.
+//
+// Block = (batch element, head, group of up to 4 query tiles); wave w owns 32 queries.
+// Scores are computed TRANSPOSED, S^T = K Q^T (A = K rows j, B = Q rows i), so that after the MFMA a lane
+// owns one query column i and the key index j runs over its registers (+ the other lane half):
+// the softmax reductions are register-local plus one cross-half exchange, and the normalised P^T
+// accumulator is directly the A operand of O = P V (rows of P^T are the k index of the second product),
+// so P never moves between lanes and never touches LDS.  Output tile O[i][dim] has dim on the lane =>
+// coalesced stores.
+//
+// Sequence lengths here are tiny (L <= 256), so all S^T tiles of a query tile stay in accumulators
+// (16 regs per 32 keys) and no online-softmax rescaling is needed.
+//
+// Arithmetic: operands are staged to LDS as fp32 (bf16 inputs are widened) and multiplied with
+// v_mfma_f32_32x32x2_f32; softmax in fp32.
+#include "kernels.h"
+
+namespace m3pc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__device__ __forceinline__ f32x4 load4(const T* p);
+template <>
+__device__ __forceinline__ f32x4 load4<float>(const float* p) {
+    return *(const f32x4*)p;
+}
+template <>
+__device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
+    const uint2 u = *(const uint2*)p;
+    f32x4 r;
+    r[0] = __builtin_bit_cast(float, u.x << 16);
+    r[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+    r[2] = __builtin_bit_cast(float, u.y << 16);
+    r[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+    return r;
+}
+
+// HDT = hd / 32, NCH = number of 64-key chunks kept in registers
+template <typename T, int HDT, int NCH>
+__global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
+    constexpr int HD = HDT * 32;
+    constexpr int ROWF = HD + 4;  // padded LDS row (floats): 16-byte pad keeps float4 frag reads conflict-free
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nthr = blockDim.x, nw = nthr >> 6;
+    const int b = blockIdx.x, head = blockIdx.y, qg = blockIdx.z;
+    const int q0 = qg * 128;
+    const int Lk = p.L1 + p.L2;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const T* Qb = (const T*)p.Q + b * p.q_bstride + head * HD;
+    const T* K1 = (const T*)p.K1 + b * p.kv1_bstride + head * HD;
+    const T* V1 = (const T*)p.V1 + b * p.kv1_bstride + head * HD;
+    const T* K2 = p.K2 ? (const T*)p.K2 + head * HD : nullptr;
+    const T* V2 = p.V2 ? (const T*)p.V2 + head * HD : nullptr;
+
+    // ---- stage Q (nw*32 rows) and pull this wave's Q fragments into registers
+    for (int c = tid; c < nw * 32 * (HD / 4); c += nthr) {
+        const int r = c / (HD / 4), k4 = c % (HD / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (q0 + r < p.Lq) v = load4<T>(Qb + (long long)(q0 + r) * p.ldq + k4 * 4);
+        *(f32x4*)(lds + r * ROWF + k4 * 4) = v;
+    }
+    __syncthreads();
+    f32x4 qf[HDT * 4];  // quarter s: floats k = 8s+4h .. +3 of query row (wid*32 + l31)
+#pragma unroll
+    for (int s = 0; s < HDT * 4; ++s) qf[s] = *(const f32x4*)(lds + (wid * 32 + l31) * ROWF + 8 * s + 4 * lh);
+    __syncthreads();
+
+    f32x16 sacc[NCH][2];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[c][jt][e] = 0.f;
+
+    // ---- S^T = K Q^T
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int j0 = c * 64;
+        if (j0 < Lk) {
+            for (int x = tid; x < 64 * (HD / 4); x += nthr) {
+                const int r = x / (HD / 4), k4 = x % (HD / 4), j = j0 + r;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (j < p.L1)
+                    v = load4<T>(K1 + (long long)j * p.ldkv1 + k4 * 4);
+                else if (j < Lk)
+                    v = load4<T>(K2 + (long long)(j - p.L1) * p.ldkv2 + k4 * 4);
+                *(f32x4*)(lds + r * ROWF + k4 * 4) = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                if (j0 + jt * 32 < Lk) {
+#pragma unroll
+                    for (int s = 0; s < HDT * 4; ++s) {
+                        const f32x4 kf = *(const f32x4*)(lds + (jt * 32 + l31) * ROWF + 8 * s + 4 * lh);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            sacc[c][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[s][e], sacc[c][jt], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- softmax over j for the lane's query column.  reg e of tile (c,jt) is key
+    //      j = c*64 + jt*32 + (e&3) + 8*(e>>2) + 4*lh
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int j = c * 64 + jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const float v = (j < Lk) ? sacc[c][jt][e] * p.scale : -INFINITY;
+                sacc[c][jt][e] = v;
+                m = fmaxf(m, v);
+            }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float v = expf(sacc[c][jt][e] - m);
+                sacc[c][jt][e] = v;
+                l += v;
+            }
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[c][jt][e] *= inv;
+
+    // ---- O = P V : A = P (from the S^T accumulator: reg e <-> k = key row), B = V[key][dim]
+    f32x16 oacc[HDT];
+#pragma unroll
+    for (int d = 0; d < HDT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int j0 = c * 64;
+        if (j0 < Lk) {
+            for (int x = tid; x < 64 * (HD / 4); x += nthr) {
+                const int r = x / (HD / 4), k4 = x % (HD / 4), j = j0 + r;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (j < p.L1)
+                    v = load4<T>(V1 + (long long)j * p.ldkv1 + k4 * 4);
+                else if (j < Lk)
+                    v = load4<T>(V2 + (long long)(j - p.L1) * p.ldkv2 + k4 * 4);
+                *(f32x4*)(lds + r * ROWF + k4 * 4) = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                if (j0 + jt * 32 < Lk) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int jr = jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        const float pe = sacc[c][jt][e];
+#pragma unroll
+                        for (int d = 0; d < HDT; ++d) {
+                            const float vv = lds[jr * ROWF + d * 32 + l31];
+                            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(pe, vv, oacc[d], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- store: oacc[d][e] = O[i = wid*32 + (e&3)+8*(e>>2)+4*lh][dim = d*32 + l31]
+    T* Ob = (T*)p.O + b * p.o_bstride + head * HD;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = q0 + wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (i < p.Lq) {
+#pragma unroll
+            for (int d = 0; d < HDT; ++d) Ob[(long long)i * p.ldo + d * 32 + l31] = (T)oacc[d][e];
+        }
+    }
+}
+
+template <typename T, int HDT, int NCH>
+static void launch_nch(const AttnP& p, dim3 grid, dim3 block, size_t smem, hipStream_t st) {
+    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_kernel<T, HDT, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_kernel<T, HDT, NCH>), grid, block, smem, st, p);
+}
+
+template <typename T, int HDT>
+static void launch_hd(const AttnP& p, hipStream_t st) {
+    const int Lk = p.L1 + p.L2;
+    const int qgroups = (p.Lq + 127) / 128;
+    const int nw = p.Lq >= 128 ? 4 : (p.Lq + 31) / 32;
+    const int rows = nw * 32 > 64 ? nw * 32 : 64;
+    const size_t smem = (size_t)rows * (HDT * 32 + 4) * sizeof(float);
+    dim3 grid(p.batch, p.n_head, qgroups), block(nw * 64);
+    if (Lk <= 64)
+        launch_nch<T, HDT, 1>(p, grid, block, smem, st);
+    else if (Lk <= 128)
+        launch_nch<T, HDT, 2>(p, grid, block, smem, st);
+    else
+        launch_nch<T, HDT, 4>(p, grid, block, smem, st);
+}
+
+template <typename T>
+static void launch_t(const AttnP& p, hipStream_t st) {
+    switch (p.hd) {
+        case 32: launch_hd<T, 1>(p, st); break;
+        case 64: launch_hd<T, 2>(p, st); break;
+        case 128: launch_hd<T, 4>(p, st); break;
+        default: break;  // validated by the caller
+    }
+}
+
+void launch_attention(const AttnP& p, int dtype, hipStream_t st) {
+    if (p.batch <= 0 || p.Lq <= 0) return;
+    if (dtype == DT_BF16)
+        launch_t<bf16_t>(p, st);
+    else
+        launch_t<float>(p, st);
+}
+
+}  // namespace m3pc

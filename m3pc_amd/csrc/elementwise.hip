@@ -1,0 +1,493 @@
+// HBM-streaming and small reduction kernels of the plan step (gfx950): token embedding, LayerNorm,
+// output heads, candidate sampling, critic, TD(lambda) scoring and the cross-candidate select.
+// All of them are bandwidth- or latency-bound: one wave (64 lanes) per row, 64-lane shuffles for the
+// reductions, rows laid out so that lanes touch consecutive addresses.
+#include "kernels.h"
+
+namespace m3pc {
+
+__device__ __forceinline__ int map_row(const RowMap& m, int r) {
+    if (m.rpg == 0) return r;
+    return (r / m.rpg) * m.gstride + (r % m.rpg) + m.off;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------ embed
+__global__ __launch_bounds__(256) void embed_kernel(EmbedP p) {
+    const long long row = blockIdx.x;  // b * L + j
+    const int b = (int)(row / p.L), j = (int)(row % p.L);
+    const int2 kt = p.tokmap[j];
+    const int key = kt.x, t = kt.y;
+    const int D = p.feat[key];
+    const float* x = p.tok[key] + (long long)b * p.bstride[key] + (long long)t * D;
+    __shared__ float xs[32];
+    if (threadIdx.x < D) {
+        float v = x[threadIdx.x];
+        if (p.normalize[key]) v = (v - p.mean[key][threadIdx.x]) / p.stdv[key][threadIdx.x];
+        xs[threadIdx.x] = v;
+    }
+    __syncthreads();
+    const float* WT = p.WT[key];
+    const float* E = p.E[key] + (long long)t * p.d;
+    float* out = p.X + row * p.d;
+    for (int c = threadIdx.x; c < p.d; c += blockDim.x) {
+        float acc = 0.f;
+        for (int f = 0; f < D; ++f) acc = fmaf(xs[f], WT[f * p.d + c], acc);
+        out[c] = acc + E[c];
+    }
+}
+void launch_embed(const EmbedP& p, hipStream_t st) {
+    const long long rows = (long long)p.batch * p.L;
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)rows), dim3(p.d < 256 ? p.d : 256), 0, st, p);
+}
+
+// ------------------------------------------------------------------------------------------ gather
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherP p) {
+    const long long row = blockIdx.x;
+    const int b = (int)(row / p.rows_per_batch), i = (int)(row % p.rows_per_batch);
+    const int s = p.rowsrc[i];
+    const float* src = s >= 0 ? p.Xe + (long long)b * p.xe_bstride + (long long)s * p.d : p.table + (long long)(-s - 1) * p.d;
+    for (int c = threadIdx.x * 4; c < p.d; c += blockDim.x * 4) {
+        const float4 v = *(const float4*)(src + c);
+        if (p.out) *(float4*)(p.out + row * p.d + c) = v;
+        if (p.outb) {
+            bf16_t* ob = p.outb + row * p.d + c;
+            ob[0] = (bf16_t)v.x;
+            ob[1] = (bf16_t)v.y;
+            ob[2] = (bf16_t)v.z;
+            ob[3] = (bf16_t)v.w;
+        }
+    }
+}
+void launch_gather_rows(const GatherP& p, hipStream_t st) {
+    const long long rows = (long long)p.batch * p.rows_per_batch;
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)rows), dim3(p.d / 4 < 256 ? p.d / 4 : 256), 0, st, p);
+}
+
+// ------------------------------------------------------------------------------------------ layernorm
+// one wave per row, d/64 (<= 16) values per lane kept in registers
+__global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.rows) return;
+    const float* x = p.X + (long long)map_row(p.xmap, r) * p.ldx;
+    const int n = p.d >> 6;
+    float v[16];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < n) {
+            v[i] = x[i * 64 + lane];
+            s += v[i];
+        }
+    const float inv_d = 1.0f / (float)p.d;
+    float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < n) {
+            const float c = v[i] - mean;
+            q += c * c;
+        }
+    float rstd = rsqrtf(wave_sum(q) * inv_d + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < n) v[i] = (v[i] - mean) * rstd * p.g1[i * 64 + lane] + p.b1[i * 64 + lane];
+    if (p.g2) {
+        s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < n) s += v[i];
+        mean = wave_sum(s) * inv_d;
+        q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < n) {
+                const float c = v[i] - mean;
+                q += c * c;
+            }
+        rstd = rsqrtf(wave_sum(q) * inv_d + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < n) v[i] = (v[i] - mean) * rstd * p.g2[i * 64 + lane] + p.b2[i * 64 + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < n) {
+            if (p.Yf) p.Yf[(long long)r * p.d + i * 64 + lane] = v[i];
+            if (p.Yb) p.Yb[(long long)r * p.d + i * 64 + lane] = (bf16_t)v[i];
+        }
+}
+void launch_layernorm(const LnP& p, hipStream_t st) {
+    if (p.rows <= 0) return;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, st, p);
+}
+
+// ------------------------------------------------------------------------------------------ head out
+__global__ __launch_bounds__(256) void head_out_kernel(HeadOutP p) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.rows) return;
+    const float* x = p.X + (long long)r * p.ldx;
+    const int n = p.d >> 6;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < n) v[i] = x[i * 64 + lane];
+    float* y = p.Y + (long long)map_row(p.ymap, r) * p.ldy;
+    for (int f = 0; f < p.D; ++f) {
+        const float* w = p.W + (long long)f * p.d;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < n) s = fmaf(v[i], w[i * 64 + lane], s);
+        s = wave_sum(s) + p.b[f];
+        if (p.mean) s = __fadd_rn(__fmul_rn(s, p.stdv[f]), p.mean[f]);
+        if (lane == 0) y[f] = s;
+    }
+}
+void launch_head_out(const HeadOutP& p, hipStream_t st) {
+    if (p.rows <= 0) return;
+    hipLaunchKernelGGL(head_out_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, st, p);
+}
+
+// ------------------------------------------------------------------------------------------ actor head
+__global__ __launch_bounds__(256) void actor_head_kernel(ActorP p) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.rows) return;
+    const float* x = p.X + (long long)map_row(p.xmap, r) * p.ldx;
+    const int n = p.d >> 6;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < n) v[i] = x[i * 64 + lane];
+    for (int f = 0; f < p.A; ++f) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < n) {
+                s1 = fmaf(v[i], p.Wmu[(long long)f * p.d + i * 64 + lane], s1);
+                s2 = fmaf(v[i], p.Wls[(long long)f * p.d + i * 64 + lane], s2);
+            }
+        s1 = wave_sum(s1) + p.bmu[f];
+        s2 = wave_sum(s2) + p.bls[f];
+        if (lane == 0) {
+            p.mu[(long long)r * p.A + f] = s1;
+            float ls = tanhf(s2);
+            ls = -5.0f + 0.5f * (2.0f - (-5.0f)) * (ls + 1.0f);
+            p.sd[(long long)r * p.A + f] = expf(ls);
+        }
+    }
+}
+void launch_actor_head(const ActorP& p, hipStream_t st) {
+    if (p.rows <= 0) return;
+    hipLaunchKernelGGL(actor_head_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, st, p);
+}
+
+// ------------------------------------------------------------------------------------------ sampling
+__global__ __launch_bounds__(256) void sample_kernel(SampleP p) {
+    const long long tot = (long long)p.n_count * p.T * p.A;
+    for (long long x = blockIdx.x * (long long)blockDim.x + threadIdx.x; x < tot; x += (long long)gridDim.x * blockDim.x) {
+        const int a = (int)(x % p.A);
+        const int t = (int)((x / p.A) % p.T);
+        const long long n = x / ((long long)p.A * p.T);
+        float v;
+        if (t < p.idx) {
+            v = p.hist_actions[t * p.A + a];
+        } else {
+            const int ta = t * p.A + a;
+            if (p.mode == 0) {
+                const float e = p.eps[((p.n_begin + n) * p.T + t) * p.A + a];
+                v = tanhf(__fadd_rn(__fmul_rn(e, p.sd[ta]), p.loc[ta]));
+            } else {
+                const float e = p.eps[((p.n_begin + n) * p.h + (t - p.idx)) * p.A + a];
+                v = __fadd_rn(tanhf(p.loc[ta]), __fmul_rn(e, 0.09f));
+                v = fminf(fmaxf(v, -0.99999f), 0.99999f);
+            }
+            p.sample_actions[(n * p.h + (t - p.idx)) * p.A + a] = v;
+        }
+        p.cand[x] = v;
+    }
+}
+void launch_sample(const SampleP& p, hipStream_t st) {
+    const long long tot = (long long)p.n_count * p.T * p.A;
+    if (tot <= 0) return;
+    const int grid = (int)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048);
+    hipLaunchKernelGGL(sample_kernel, dim3(grid), dim3(256), 0, st, p);
+}
+
+// ------------------------------------------------------------------------------------------ critic
+// 16 rows per 256-thread block; thread c owns hidden unit c of both layers (hidden <= 256).  Inputs and
+// the first hidden layer live in LDS and are read as broadcasts.
+#define CR_ROWS 16
+__global__ __launch_bounds__(256) void critic_kernel(CriticP p) {
+    __shared__ float sa[CR_ROWS][32];
+    __shared__ float h1[CR_ROWS][256];
+    __shared__ float red[CR_ROWS][4];
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * CR_ROWS;
+    const int SA = p.S + p.A, Hd = p.hidden;
+    const bool on = tid < Hd;
+    for (int x = tid; x < CR_ROWS * SA; x += 256) {
+        const int rr = x / SA, f = x % SA, r = r0 + rr;
+        float v = 0.f;
+        if (r < p.rows) v = f < p.S ? (p.states[(long long)r * p.S + f] - p.om[f]) / p.os[f] : p.actions[(long long)r * p.A + (f - p.S)];
+        sa[rr][f] = v;
+    }
+    float qmin = 0.f;
+    for (int net = 0; net < 2; ++net) {
+        __syncthreads();
+        {
+            float acc[CR_ROWS];
+#pragma unroll
+            for (int rr = 0; rr < CR_ROWS; ++rr) acc[rr] = 0.f;
+            if (on) {
+                for (int f = 0; f < SA; ++f) {
+                    const float w = p.W1T[net][f * Hd + tid];
+#pragma unroll
+                    for (int rr = 0; rr < CR_ROWS; ++rr) acc[rr] = fmaf(sa[rr][f], w, acc[rr]);
+                }
+                const float bb = p.b1[net][tid];
+#pragma unroll
+                for (int rr = 0; rr < CR_ROWS; ++rr) h1[rr][tid] = fmaxf(acc[rr] + bb, 0.f);
+            }
+        }
+        __syncthreads();
+        float acc[CR_ROWS];
+#pragma unroll
+        for (int rr = 0; rr < CR_ROWS; ++rr) acc[rr] = 0.f;
+        float bb = 0.f, w3 = 0.f;
+        if (on) {
+            for (int k = 0; k < Hd; ++k) {
+                const float w = p.W2T[net][k * Hd + tid];
+#pragma unroll
+                for (int rr = 0; rr < CR_ROWS; ++rr) acc[rr] = fmaf(h1[rr][k], w, acc[rr]);
+            }
+            bb = p.b2[net][tid];
+            w3 = p.W3[net][tid];
+        }
+#pragma unroll
+        for (int rr = 0; rr < CR_ROWS; ++rr) {
+            float v = on ? fmaxf(acc[rr] + bb, 0.f) * w3 : 0.f;
+            v = wave_sum(v);
+            if ((tid & 63) == 0) red[rr][tid >> 6] = v;
+        }
+        __syncthreads();
+        if (tid < CR_ROWS) {
+            const float q = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3] + p.b3[net][0];
+            qmin = net == 0 ? q : fminf(qmin, q);
+            if (net == 1 && r0 + tid < p.rows) p.q[r0 + tid] = qmin;
+        }
+    }
+}
+void launch_critic(const CriticP& p, hipStream_t st) {
+    if (p.rows <= 0) return;
+    hipLaunchKernelGGL(critic_kernel, dim3((p.rows + CR_ROWS - 1) / CR_ROWS), dim3(256), 0, st, p);
+}
+
+// ------------------------------------------------------------------------------------------ scoring
+// Same operation order as the reference loop (learner.py:300-316): per step t the discounted values are
+// summed left to right, multiplied by (1-lambda) then lambda^t (fp32 each), and accumulated.
+__global__ __launch_bounds__(256) void score_kernel(ScoreP p) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= p.n) return;
+    const float* rw = p.rewards + (long long)n * p.h;
+    const float* bt = p.boot + (long long)n * p.h;
+    const float one_minus = (float)(1.0 - p.lmbda);
+    float er = 0.f;
+    double lam_t = 1.0;  // python float lmbda**t
+    for (int t = 0; t < p.h; ++t) {
+        float disc = p.gamma, s = 0.f;
+        for (int i = 0; i < t; ++i) {
+            s = __fadd_rn(s, __fmul_rn(rw[i], disc));
+            disc = __fmul_rn(disc, p.gamma);
+        }
+        const float b = __fmul_rn(bt[t], p.boot_scale);
+        if (p.boot_out) p.boot_out[(long long)n * p.h + t] = b;
+        s = __fadd_rn(s, __fmul_rn(b, disc));
+        float w;
+        if (t < p.h - 1)
+            w = __fmul_rn(__fmul_rn(s, one_minus), (float)lam_t);
+        else
+            w = __fmul_rn(s, (float)lam_t);
+        er = __fadd_rn(er, w);
+        lam_t *= p.lmbda;
+    }
+    p.expect_return[n] = er;
+}
+void launch_score(const ScoreP& p, hipStream_t st) {
+    if (p.n <= 0) return;
+    hipLaunchKernelGGL(score_kernel, dim3((p.n + 255) / 256), dim3(256), 0, st, p);
+}
+
+// ------------------------------------------------------------------------------------------ select
+// One 1024-thread block: max / argmax, sum exp, p, weighted mean of the first actions.
+__global__ __launch_bounds__(1024) void select_kernel(SelectP p) {
+    __shared__ float smax[16];
+    __shared__ int sarg[16];
+    __shared__ float ssum[16];
+    __shared__ float bc[2];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float m = -INFINITY;
+    int am = 0x7fffffff;
+    for (int i = tid; i < p.n; i += 1024) {
+        const float v = p.er[i];
+        if (v > m || (v == m && i < am)) {
+            m = v;
+            am = i;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o);
+        const int oa = __shfl_xor(am, o);
+        if (om > m || (om == m && oa < am)) {
+            m = om;
+            am = oa;
+        }
+    }
+    if (lane == 0) {
+        smax[wid] = m;
+        sarg[wid] = am;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float mm = smax[0];
+        int aa = sarg[0];
+        for (int w = 1; w < 16; ++w)
+            if (smax[w] > mm || (smax[w] == mm && sarg[w] < aa)) {
+                mm = smax[w];
+                aa = sarg[w];
+            }
+        bc[0] = mm;
+        if (p.argmax) *p.argmax = aa;
+    }
+    __syncthreads();
+    const float mx = bc[0];
+    float s = 0.f;
+    for (int i = tid; i < p.n; i += 1024) s += expf(__fmul_rn(__fsub_rn(p.er[i], mx), p.temperature));
+    s = wave_sum(s);
+    if (lane == 0) ssum[wid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += ssum[w];
+        bc[1] = t;
+    }
+    __syncthreads();
+    const float tot = bc[1];
+    // p and sum p
+    float ps = 0.f;
+    for (int i = tid; i < p.n; i += 1024) {
+        const float pi = expf(__fmul_rn(__fsub_rn(p.er[i], mx), p.temperature)) / tot;
+        if (p.p) p.p[i] = pi;
+        ps += pi;
+    }
+    ps = wave_sum(ps);
+    __syncthreads();
+    if (lane == 0) ssum[wid] = ps;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += ssum[w];
+        bc[1] = t;
+    }
+    __syncthreads();
+    const float psum = bc[1];
+    if (p.eval_action) {
+        for (int a = 0; a < p.A; ++a) {
+            float acc = 0.f;
+            for (int i = tid; i < p.n; i += 1024) {
+                const float pi = expf(__fmul_rn(__fsub_rn(p.er[i], mx), p.temperature)) / tot;
+                acc = fmaf(p.a0[(long long)i * p.a0_stride + a], pi, acc);
+            }
+            acc = wave_sum(acc);
+            __syncthreads();
+            if (lane == 0) ssum[wid] = acc;
+            __syncthreads();
+            if (tid == 0) {
+                float t = 0.f;
+                for (int w = 0; w < 16; ++w) t += ssum[w];
+                p.eval_action[a] = t / psum;
+            }
+        }
+    }
+}
+void launch_select(const SelectP& p, hipStream_t st) {
+    if (p.n <= 0) return;
+    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, st, p);
+}
+
+// ------------------------------------------------------------------------------------------ tokenizer
+__global__ __launch_bounds__(256) void tokenize_kernel(const void* in, int in_f64, float* out, long long n, int D,
+                                                       const float* mean, const float* stdv, int normalize) {
+    for (long long x = blockIdx.x * (long long)blockDim.x + threadIdx.x; x < n; x += (long long)gridDim.x * blockDim.x) {
+        const int f = (int)(x % D);
+        if (in_f64) {
+            double v = ((const double*)in)[x];
+            if (normalize) v = (v - (double)mean[f]) / (double)stdv[f];
+            out[x] = (float)v;
+        } else {
+            float v = ((const float*)in)[x];
+            if (normalize) v = (v - mean[f]) / stdv[f];
+            out[x] = v;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void detokenize_kernel(const float* in, float* out, long long n, int D, const float* mean,
+                                                         const float* stdv, int normalize) {
+    for (long long x = blockIdx.x * (long long)blockDim.x + threadIdx.x; x < n; x += (long long)gridDim.x * blockDim.x) {
+        const int f = (int)(x % D);
+        float v = in[x];
+        if (normalize) v = __fadd_rn(__fmul_rn(v, stdv[f]), mean[f]);
+        out[x] = v;
+    }
+}
+static int grid_for(long long n) {
+    const long long g = (n + 255) / 256;
+    return (int)(g < 2048 ? (g > 0 ? g : 1) : 2048);
+}
+void launch_tokenize(const void* in, int in_f64, float* out, long long rows, int D, const float* mean, const float* stdv,
+                     int normalize, hipStream_t st) {
+    const long long n = rows * D;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(tokenize_kernel, dim3(grid_for(n)), dim3(256), 0, st, in, in_f64, out, n, D, mean, stdv, normalize);
+}
+void launch_detokenize(const float* in, float* out, long long rows, int D, const float* mean, const float* stdv,
+                       int normalize, hipStream_t st) {
+    const long long n = rows * D;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(detokenize_kernel, dim3(grid_for(n)), dim3(256), 0, st, in, out, n, D, mean, stdv, normalize);
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* in, bf16_t* out, long long n) {
+    for (long long x = blockIdx.x * (long long)blockDim.x + threadIdx.x; x < n; x += (long long)gridDim.x * blockDim.x)
+        out[x] = (bf16_t)in[x];
+}
+void launch_f32_to_bf16(const float* in, bf16_t* out, long long n, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, st, in, out, n);
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* out, float value, long long n) {
+    for (long long x = blockIdx.x * (long long)blockDim.x + threadIdx.x; x < n; x += (long long)gridDim.x * blockDim.x) out[x] = value;
+}
+void launch_fill(float* out, float value, long long n, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, st, out, value, n);
+}
+
+}  // namespace m3pc

@@ -1,0 +1,211 @@
+// Internal launcher interface of libm3pc_hip.so (gfx950 only).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace m3pc {
+
+typedef __bf16 bf16_t;
+
+enum DType { DT_F32 = 0, DT_BF16 = 1 };
+
+static inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+
+// Row remap used by GEMM / LayerNorm operands whose logical rows are a strided subset of a
+// larger tensor: physical_row = (r / rpg) * gstride + (r % rpg) + off.   rpg == 0: identity.
+struct RowMap {
+    int rpg;
+    int gstride;
+    int off;
+};
+static inline RowMap rowmap_identity() { return RowMap{0, 0, 0}; }
+
+// C[M,N] = epilogue(A[M,K] * W[N,K]^T)
+//   v = acc + bias[col] + rowtab[(r % rt_mod) * rt_ld + col];  v = gelu(v);  v += res[row_c * ldr + col]
+// A and W share the operand dtype (fp32 -> v_mfma_f32_32x32x2_f32, bf16 -> v_mfma_f32_32x32x16_bf16),
+// accumulation is fp32.  N % 64 == 0, K*sizeof(T) % 128 == 0.
+struct GemmP {
+    const void* A;
+    int lda;
+    RowMap amap;
+    const void* W;
+    int ldw;
+    int M, N, K;
+    const float* bias;
+    const float* rowtab;
+    int rt_mod, rt_ld;
+    int gelu;
+    const float* res;
+    int ldr;
+    float* Cf;     // fp32 output (optional)
+    bf16_t* Cb;    // bf16 output (optional)
+    int ldc;
+    RowMap cmap;   // applies to res, Cf, Cb
+};
+void launch_gemm(const GemmP& p, int dtype, hipStream_t st);
+
+// LayerNorm over the last dim (eps 1e-5), one wave per row; optional second LayerNorm applied to
+// the result (decoder.norm followed by an output head's LayerNorm).  d <= 1024, d % 64 == 0.
+struct LnP {
+    const float* X;
+    int ldx;
+    RowMap xmap;
+    int rows, d;
+    const float* g1;
+    const float* b1;
+    const float* g2;  // optional
+    const float* b2;
+    float* Yf;        // optional fp32 out (contiguous rows, ld = d)
+    bf16_t* Yb;       // optional bf16 out
+};
+void launch_layernorm(const LnP& p, hipStream_t st);
+
+// softmax(Q K^T * scale) V for one (batch, head) per block-column.  Keys/values come from up to two
+// segments: seg 1 is per batch element, seg 2 is shared by the batch (bstride 0 allowed anywhere).
+struct AttnP {
+    const void* Q;
+    long long q_bstride;
+    int ldq;
+    const void* K1;
+    const void* V1;
+    long long kv1_bstride;
+    int ldkv1;
+    int L1;
+    const void* K2;
+    const void* V2;
+    int ldkv2;
+    int L2;
+    void* O;
+    long long o_bstride;
+    int ldo;
+    int batch, n_head, hd, Lq;
+    float scale;
+};
+void launch_attention(const AttnP& p, int dtype, hipStream_t st);
+
+// Encoder token embedding (mtm_model.py:546-557) with the tokenizer affine folded in and the
+// mask-drop gather (mtm_model.py:534-544) applied: X[b, j, :] for the kept tokens only.
+struct EmbedP {
+    const float* tok[4];     // per key: (.., T, D_k) inputs
+    long long bstride[4];    // batch stride in floats (0 = shared by the batch)
+    int normalize[4];        // apply (x - mean) / std
+    const float* mean[4];
+    const float* stdv[4];
+    const float* WT[4];      // (D_k, d) transposed encoder_embed weight
+    const float* E[4];       // (T, d)  bias + per-dim encoding + pos_embed[t]
+    int feat[4];
+    const int2* tokmap;      // (L,) {key, t} of every kept token, encoder order
+    int batch, L, d, T;
+    float* X;                // (batch, L, d)
+};
+void launch_embed(const EmbedP& p, hipStream_t st);
+
+// out[r, :] = src_row(r), where src is an encoder-output row (per batch element) or a shared table row.
+//   rowsrc[i] >= 0: row of Xe[b, rowsrc[i], :];   rowsrc[i] < 0: row (-rowsrc[i]-1) of table
+struct GatherP {
+    const float* Xe;
+    long long xe_bstride;
+    const float* table;
+    const int* rowsrc;  // (rows_per_batch,)
+    int rows_per_batch, batch, d;
+    float* out;         // (batch, rows_per_batch, d), optional
+    bf16_t* outb;       // same rows as bf16, optional
+};
+void launch_gather_rows(const GatherP& p, hipStream_t st);
+
+// y[r, f] = (x[r,:] . W[f,:] + b[f]) * std[f] + mean[f]   for f < D (D <= 32): output heads' last Linear
+// with the de-tokenizer folded in (tokenizers/continuous.py:81-94).
+struct HeadOutP {
+    const float* X;
+    int ldx;
+    int rows, d, D;
+    const float* W;    // (D, d)
+    const float* b;
+    const float* mean; // optional (normalize)
+    const float* stdv;
+    float* Y;
+    RowMap ymap;       // physical output row
+    int ldy;
+};
+void launch_head_out(const HeadOutP& p, hipStream_t st);
+
+// DiagGaussianActor (mtm_model.py:313-321): mu = x.Wmu + bmu ; std = exp(-5 + 3.5*(tanh(x.Wls + bls)+1))
+struct ActorP {
+    const float* X;
+    int ldx;
+    RowMap xmap;
+    int rows, d, A;
+    const float* Wmu;
+    const float* bmu;
+    const float* Wls;
+    const float* bls;
+    float* mu;   // (rows, A)
+    float* sd;   // (rows, A)
+};
+void launch_actor_head(const ActorP& p, hipStream_t st);
+
+// Candidate construction (learner.py:285-288 / 156-168): cand[n, t, :] = hist actions for t < idx,
+// tanh(loc + std * eps) for t >= idx (mode 0) or clamp(tanh(loc) + 0.09 * eps, +-0.99999) (mode 1).
+struct SampleP {
+    const float* hist_actions;  // (T, A)
+    const float* loc;           // (T, A)
+    const float* sd;            // (T, A)
+    const float* eps;           // mode 0: (n_total, T, A); mode 1: (n_total, h, A)
+    int mode, T, A, idx, h, n_begin, n_count;
+    float* cand;                // (n_count, T, A)
+    float* sample_actions;      // (n_count, h, A)
+};
+void launch_sample(const SampleP& p, hipStream_t st);
+
+// TwinQ (finetune_omtm/model.py:146-171): q[r] = min(q1, q2)( (s - om)/os , a )
+struct CriticP {
+    const float* states;  // (rows, S)
+    const float* actions; // (rows, A)   row r = cand * h + t
+    int rows, S, A, hidden;
+    const float* om;
+    const float* os;
+    const float* W1T[2];  // (S+A, hidden) transposed
+    const float* b1[2];
+    const float* W2T[2];  // (hidden, hidden) transposed
+    const float* b2[2];
+    const float* W3[2];   // (hidden,)
+    const float* b3[2];
+    float* q;             // (rows,)
+};
+void launch_critic(const CriticP& p, hipStream_t st);
+
+// TD(lambda) scoring (learner.py:300-316)
+struct ScoreP {
+    const float* rewards;  // (n, h)
+    const float* boot;     // (n, h)
+    int n, h;
+    float boot_scale;      // 1000 for rtg (learner.py:305), 1 for critic
+    float gamma;           // (float)cfg.discount
+    double lmbda;
+    float* expect_return;  // (n,)
+    float* boot_out;       // optional: scaled bootstrap written back (n,h)
+};
+void launch_score(const ScoreP& p, hipStream_t st);
+
+// softmax / weighted mean / argmax over all candidates (learner.py:318-323)
+struct SelectP {
+    const float* er;
+    const float* a0;
+    long long a0_stride;
+    int n, A;
+    float temperature;
+    float* p;
+    float* eval_action;
+    int* argmax;
+    float* scratch;  // >= 4 + A floats
+};
+void launch_select(const SelectP& p, hipStream_t st);
+
+void launch_tokenize(const void* in, int in_f64, float* out, long long rows, int D, const float* mean,
+                     const float* stdv, int normalize, hipStream_t st);
+void launch_detokenize(const float* in, float* out, long long rows, int D, const float* mean, const float* stdv,
+                       int normalize, hipStream_t st);
+void launch_f32_to_bf16(const float* in, bf16_t* out, long long n, hipStream_t st);
+void launch_fill(float* out, float value, long long n, hipStream_t st);
+
+}  // namespace m3pc

@@ -1,0 +1,1285 @@
+// libm3pc_hip.so -- host side of the C ABI declared in include/m3pc_hip.h.
+//
+// Data layout in HBM (one handle = one GPU):
+//   weights   fp32 arena in state_dict layout + bf16 copies of every GEMM weight ([N][K], K contiguous)
+//   tables    per key: transposed encoder-embed weight (D_k,d); E_enc/E_dec (T,d) = bias + per-dim + pos
+//   plans     per mask pattern: token maps, and -- for the candidate pass -- the candidate-independent
+//             part of the decoder (inputs, K/V and Q of every masked token), computed once per weight load
+//   workspace activations for R = max(max_candidates*2T, max_batch*4T) token rows:
+//             X, Y (fp32 residual streams), Hn, QKV, O, F (operand dtype), EncOut (fp32)
+//
+// Candidate pass ("pass 2", learner.py:288-293) is exactly pruned: decoder rows of masked tokens do not
+// depend on the candidate, so only the 2h scored tokens are pushed through out-proj/FFN/heads and only the
+// un-masked tokens through the K/V projection.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/m3pc_hip.h"
+#include "kernels.h"
+
+using namespace m3pc;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(x)                                                                                     \
+    do {                                                                                              \
+        hipError_t e_ = (x);                                                                          \
+        if (e_ != hipSuccess) return fail(M3PC_EHIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define CHK(x)               \
+    do {                     \
+        int rc_ = (x);       \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+static const char* KEYN[4] = {"states", "actions", "rewards", "returns"};
+
+namespace {
+
+struct Tensor {
+    float* f = nullptr;    // fp32 device
+    bf16_t* b = nullptr;   // bf16 copy (GEMM weights only)
+    long long numel = 0;
+    bool gemm = false;
+    bool loaded = false;
+};
+
+struct SharedTables {  // candidate-independent decoder quantities of one plan, one precision
+    bool valid = false;
+    float* Yall = nullptr;   // (4T, d)  decoder inputs with mask tokens everywhere a token is masked
+    void* QKVm = nullptr;    // (Lm, 3d) q|k|v of masked tokens (operand dtype)
+    void* QKVq = nullptr;    // (nq, 3d) rows of the scored tokens (valid when they are all masked)
+    float* Yq = nullptr;     // (nq, d)  decoder inputs of the scored tokens
+};
+
+struct Plan {
+    std::string key;
+    int T = 0, Le = 0, Lm = 0;
+    int kept[4] = {0, 0, 0, 0}, enc_off[4] = {0, 0, 0, 0};
+    bool prefix[4] = {true, true, true, true};
+    std::vector<int> dec_src;    // (4T) encoder index or -1
+    std::vector<int> masked;     // decoder indices of masked tokens
+    int2* d_tokmap = nullptr;    // (Le)
+    int* d_dec_rowsrc = nullptr; // (4T): enc row, or -(key)-1 -> mask token table
+    int* d_masked_rowsrc = nullptr;  // (Lm): -(i)-1 rows of a (4T, *) table
+    // scoring variants (mode-dependent query sets)
+    struct Query {
+        bool built = false;
+        int nq = 0, h = 0;
+        int qkeys[2] = {0, 0};
+        bool all_masked = true;
+        int* d_q_rowsrc_tab = nullptr;  // (nq): -(i)-1 rows of (4T,*) tables
+        int* d_q_rowsrc_mix = nullptr;  // (nq): enc row or -(i)-1 rows of Yall
+        SharedTables tab[2];
+    } query[2];  // index: 0 rtg (rewards, returns), 1 critic (states, rewards)
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    double flops;
+};
+
+}  // namespace
+
+struct m3pc_handle {
+    m3pc_dims dm;
+    int device = 0;
+    int d = 0, nh = 0, hd = 0, T = 0, S = 0, A = 0, ff = 0, feat[4] = {0, 0, 0, 0};
+    std::map<std::string, Tensor> w;
+    bool weights_loaded = false;
+    // derived tables
+    float* WT[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* Eenc[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* Edec[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* mask_tokens = nullptr;  // (4, d)
+    // tokenizer
+    bool tok_set[4] = {false, false, false, false};
+    int tok_norm[4] = {0, 0, 0, 0};
+    float* tok_mean[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* tok_std[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<float> h_mean[4], h_std[4];
+    // critic
+    bool critic_set = false;
+    float *cW1T[2] = {nullptr, nullptr}, *cb1[2] = {nullptr, nullptr}, *cW2T[2] = {nullptr, nullptr},
+          *cb2[2] = {nullptr, nullptr}, *cW3[2] = {nullptr, nullptr}, *cb3[2] = {nullptr, nullptr};
+    float *c_om = nullptr, *c_os = nullptr;
+    // workspace
+    long long R = 0;
+    float *X = nullptr, *Y = nullptr, *EncOut = nullptr, *G = nullptr;
+    void *Hn = nullptr, *QKV = nullptr, *O = nullptr, *F = nullptr, *Z = nullptr;
+    float *cand = nullptr, *loc = nullptr, *sd = nullptr, *rtok = nullptr, *pred[2] = {nullptr, nullptr}, *qv = nullptr;
+    float* sel_scratch = nullptr;
+    std::map<std::string, std::unique_ptr<Plan>> plans;
+    // profiling
+    bool prof = false;
+    std::vector<EventPair> ev;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+template <typename T>
+int dmalloc(T** p, size_t n) {
+    hipError_t e = hipMalloc((void**)p, n * sizeof(T) > 0 ? n * sizeof(T) : 16);
+    if (e != hipSuccess) return fail(M3PC_EHIP, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+    return 0;
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(M3PC_EHIP, "kernel launch failed in %s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+Tensor& W(m3pc_handle* h, const std::string& n) { return h->w.at(n); }
+const void* Wop(m3pc_handle* h, const std::string& n, int dt) {
+    Tensor& t = h->w.at(n);
+    return dt == DT_BF16 ? (const void*)t.b : (const void*)t.f;
+}
+
+void add_tensor(m3pc_handle* h, const std::string& n, long long numel, bool gemm = false) {
+    Tensor t;
+    t.numel = numel;
+    t.gemm = gemm;
+    h->w[n] = t;
+}
+
+void declare_weights(m3pc_handle* h) {
+    const int d = h->d, ff = h->ff;
+    for (int k = 0; k < 4; ++k) {
+        const std::string kn = KEYN[k];
+        add_tensor(h, "encoder_embed_dict." + kn + ".weight", (long long)d * h->feat[k]);
+        add_tensor(h, "encoder_embed_dict." + kn + ".bias", d);
+        add_tensor(h, "decoder_embed_dict." + kn + ".weight", (long long)d * d, true);
+        add_tensor(h, "decoder_embed_dict." + kn + ".bias", d);
+        add_tensor(h, "mask_token_dict." + kn, d);
+        add_tensor(h, "encoder_per_dim_encoding." + kn, d);
+        add_tensor(h, "decoder_per_dim_encoding." + kn, d);
+        if (k == M3PC_ACTIONS) {
+            add_tensor(h, "output_head_dict.actions.mu.weight", (long long)h->A * d);
+            add_tensor(h, "output_head_dict.actions.mu.bias", h->A);
+            add_tensor(h, "output_head_dict.actions.log_std.weight", (long long)h->A * d);
+            add_tensor(h, "output_head_dict.actions.log_std.bias", h->A);
+        } else {
+            add_tensor(h, "output_head_dict." + kn + ".0.weight", d);
+            add_tensor(h, "output_head_dict." + kn + ".0.bias", d);
+            add_tensor(h, "output_head_dict." + kn + ".1.weight", (long long)d * d, true);
+            add_tensor(h, "output_head_dict." + kn + ".1.bias", d);
+            add_tensor(h, "output_head_dict." + kn + ".3.weight", (long long)h->feat[k] * d);
+            add_tensor(h, "output_head_dict." + kn + ".3.bias", h->feat[k]);
+        }
+    }
+    auto block = [&](const std::string& p) {
+        add_tensor(h, p + ".self_attn.in_proj_weight", 3LL * d * d, true);
+        add_tensor(h, p + ".self_attn.in_proj_bias", 3 * d);
+        add_tensor(h, p + ".self_attn.out_proj.weight", (long long)d * d, true);
+        add_tensor(h, p + ".self_attn.out_proj.bias", d);
+        add_tensor(h, p + ".linear1.weight", (long long)ff * d, true);
+        add_tensor(h, p + ".linear1.bias", ff);
+        add_tensor(h, p + ".linear2.weight", (long long)d * ff, true);
+        add_tensor(h, p + ".linear2.bias", d);
+        add_tensor(h, p + ".norm1.weight", d);
+        add_tensor(h, p + ".norm1.bias", d);
+        add_tensor(h, p + ".norm2.weight", d);
+        add_tensor(h, p + ".norm2.bias", d);
+    };
+    for (int i = 0; i < h->dm.n_enc_layer; ++i) block("encoder.layers." + std::to_string(i));
+    for (int i = 0; i < h->dm.n_dec_layer; ++i) block("decoder.layers." + std::to_string(i));
+    add_tensor(h, "encoder.norm.weight", d);
+    add_tensor(h, "encoder.norm.bias", d);
+    add_tensor(h, "decoder.norm.weight", d);
+    add_tensor(h, "decoder.norm.bias", d);
+    add_tensor(h, "pos_embed", (long long)h->T * d);
+}
+
+// ---------------------------------------------------------------------------------- profiling
+struct GemmTimer {
+    m3pc_handle* h;
+    hipStream_t st;
+    EventPair* e = nullptr;
+    GemmTimer(m3pc_handle* h_, hipStream_t st_, double flops) : h(h_), st(st_) {
+        if (!h->prof) return;
+        if (h->ev_used == h->ev.size()) {
+            EventPair n;
+            hipEventCreate(&n.a);
+            hipEventCreate(&n.b);
+            h->ev.push_back(n);
+        }
+        e = &h->ev[h->ev_used++];
+        e->flops = flops;
+        hipEventRecord(e->a, st);
+    }
+    ~GemmTimer() {
+        if (e) hipEventRecord(e->b, st);
+    }
+};
+
+void gemm(m3pc_handle* h, const GemmP& p, int dt, hipStream_t st) {
+    GemmTimer t(h, st, 2.0 * p.M * (double)p.N * p.K);
+    launch_gemm(p, dt, st);
+}
+
+GemmP gemm_basic(const void* A, int lda, const void* Wp, int ldw, int M, int N, int K, const float* bias) {
+    GemmP p;
+    memset(&p, 0, sizeof(p));
+    p.A = A;
+    p.lda = lda;
+    p.W = Wp;
+    p.ldw = ldw;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.bias = bias;
+    p.rt_mod = 1;
+    return p;
+}
+void gemm_out(GemmP& p, int dt_out, void* C, int ldc) {
+    if (dt_out == DT_BF16)
+        p.Cb = (bf16_t*)C;
+    else
+        p.Cf = (float*)C;
+    p.ldc = ldc;
+}
+
+// ---------------------------------------------------------------------------------- plans
+int get_plan(m3pc_handle* h, const unsigned char* const masks[4], Plan** out) {
+    const int T = h->T;
+    std::string key(4 * T, '0');
+    for (int k = 0; k < 4; ++k)
+        for (int t = 0; t < T; ++t) key[k * T + t] = masks[k][t] ? '1' : '0';
+    auto it = h->plans.find(key);
+    if (it != h->plans.end()) {
+        *out = it->second.get();
+        return 0;
+    }
+    std::unique_ptr<Plan> pl(new Plan());
+    pl->key = key;
+    pl->T = T;
+    std::vector<int2> tokmap;
+    pl->dec_src.assign(4 * T, -1);
+    for (int k = 0; k < 4; ++k) {
+        pl->enc_off[k] = (int)tokmap.size();
+        bool seen_zero = false;
+        for (int t = 0; t < T; ++t) {
+            if (masks[k][t]) {
+                if (seen_zero) pl->prefix[k] = false;
+                pl->dec_src[k * T + t] = (int)tokmap.size();
+                tokmap.push_back(make_int2(k, t));
+                pl->kept[k]++;
+            } else {
+                seen_zero = true;
+            }
+        }
+    }
+    pl->Le = (int)tokmap.size();
+    if (pl->Le == 0) return fail(M3PC_EINVAL, "mask keeps no token");
+    std::vector<int> dec_rowsrc(4 * T), masked_rowsrc;
+    for (int i = 0; i < 4 * T; ++i) {
+        if (pl->dec_src[i] >= 0) {
+            dec_rowsrc[i] = pl->dec_src[i];
+        } else {
+            dec_rowsrc[i] = -(i / T) - 1;
+            pl->masked.push_back(i);
+            masked_rowsrc.push_back(-i - 1);
+        }
+    }
+    pl->Lm = (int)pl->masked.size();
+    CHK(dmalloc(&pl->d_tokmap, tokmap.size()));
+    HIPCHK(hipMemcpy(pl->d_tokmap, tokmap.data(), tokmap.size() * sizeof(int2), hipMemcpyHostToDevice));
+    CHK(dmalloc(&pl->d_dec_rowsrc, dec_rowsrc.size()));
+    HIPCHK(hipMemcpy(pl->d_dec_rowsrc, dec_rowsrc.data(), dec_rowsrc.size() * sizeof(int), hipMemcpyHostToDevice));
+    CHK(dmalloc(&pl->d_masked_rowsrc, masked_rowsrc.size() + 1));
+    if (!masked_rowsrc.empty())
+        HIPCHK(hipMemcpy(pl->d_masked_rowsrc, masked_rowsrc.data(), masked_rowsrc.size() * sizeof(int), hipMemcpyHostToDevice));
+    *out = pl.get();
+    h->plans[key] = std::move(pl);
+    return 0;
+}
+
+void free_tables(SharedTables& t) {
+    if (t.Yall) hipFree(t.Yall);
+    if (t.QKVm) hipFree(t.QKVm);
+    if (t.QKVq) hipFree(t.QKVq);
+    if (t.Yq) hipFree(t.Yq);
+    t = SharedTables();
+}
+
+void invalidate_tables(m3pc_handle* h) {
+    for (auto& kv : h->plans)
+        for (int q = 0; q < 2; ++q)
+            for (int pr = 0; pr < 2; ++pr) kv.second->query[q].tab[pr].valid = false;
+}
+
+// ---------------------------------------------------------------------------------- transformer block
+// One pre-LN layer (mtm_model.py:379-409) over `batch` sequences of L rows, in place on X (fp32).
+int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L, int dt, hipStream_t st) {
+    const int d = h->d, ff = h->ff;
+    const int rows = batch * L;
+    const int es = (int)dtype_size(dt);
+    (void)es;
+    LnP ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.X = X;
+    ln.ldx = d;
+    ln.rows = rows;
+    ln.d = d;
+    ln.g1 = W(h, pfx + ".norm1.weight").f;
+    ln.b1 = W(h, pfx + ".norm1.bias").f;
+    if (dt == DT_BF16)
+        ln.Yb = (bf16_t*)h->Hn;
+    else
+        ln.Yf = (float*)h->Hn;
+    launch_layernorm(ln, st);
+    {
+        GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".self_attn.in_proj_weight", dt), d, rows, 3 * d, d,
+                             W(h, pfx + ".self_attn.in_proj_bias").f);
+        gemm_out(p, dt, h->QKV, 3 * d);
+        gemm(h, p, dt, st);
+    }
+    {
+        AttnP a;
+        memset(&a, 0, sizeof(a));
+        const char* q = (const char*)h->QKV;
+        a.Q = q;
+        a.q_bstride = (long long)L * 3 * d;
+        a.ldq = 3 * d;
+        a.K1 = q + (size_t)d * dtype_size(dt);
+        a.V1 = q + (size_t)2 * d * dtype_size(dt);
+        a.kv1_bstride = (long long)L * 3 * d;
+        a.ldkv1 = 3 * d;
+        a.L1 = L;
+        a.O = h->O;
+        a.o_bstride = (long long)L * d;
+        a.ldo = d;
+        a.batch = batch;
+        a.n_head = h->nh;
+        a.hd = h->hd;
+        a.Lq = L;
+        a.scale = 1.0f / sqrtf((float)h->hd);
+        launch_attention(a, dt, st);
+    }
+    {
+        GemmP p = gemm_basic(h->O, d, Wop(h, pfx + ".self_attn.out_proj.weight", dt), d, rows, d, d,
+                             W(h, pfx + ".self_attn.out_proj.bias").f);
+        p.res = X;
+        p.ldr = d;
+        gemm_out(p, DT_F32, X, d);
+        gemm(h, p, dt, st);
+    }
+    ln.g1 = W(h, pfx + ".norm2.weight").f;
+    ln.b1 = W(h, pfx + ".norm2.bias").f;
+    launch_layernorm(ln, st);
+    {
+        GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".linear1.weight", dt), d, rows, ff, d, W(h, pfx + ".linear1.bias").f);
+        p.gelu = 1;
+        gemm_out(p, dt, h->F, ff);
+        gemm(h, p, dt, st);
+    }
+    {
+        GemmP p = gemm_basic(h->F, ff, Wop(h, pfx + ".linear2.weight", dt), ff, rows, d, ff, W(h, pfx + ".linear2.bias").f);
+        p.res = X;
+        p.ldr = d;
+        gemm_out(p, DT_F32, X, d);
+        gemm(h, p, dt, st);
+    }
+    return check_launch(pfx.c_str());
+}
+
+struct TokIn {
+    const float* ptr[4];
+    long long bstride[4];
+    int normalize[4];
+};
+
+// embed + encoder stack + encoder.norm -> EncOut (fp32) [and bf16 copy in Z when dt == bf16 and want_b]
+int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hipStream_t st) {
+    EmbedP e;
+    memset(&e, 0, sizeof(e));
+    for (int k = 0; k < 4; ++k) {
+        e.tok[k] = in.ptr[k];
+        e.bstride[k] = in.bstride[k];
+        e.normalize[k] = in.normalize[k];
+        e.mean[k] = h->tok_mean[k];
+        e.stdv[k] = h->tok_std[k];
+        e.WT[k] = h->WT[k];
+        e.E[k] = h->Eenc[k];
+        e.feat[k] = h->feat[k];
+    }
+    e.tokmap = pl->d_tokmap;
+    e.batch = batch;
+    e.L = pl->Le;
+    e.d = h->d;
+    e.T = h->T;
+    e.X = h->X;
+    launch_embed(e, st);
+    for (int i = 0; i < h->dm.n_enc_layer; ++i) CHK(run_block(h, "encoder.layers." + std::to_string(i), h->X, batch, pl->Le, dt, st));
+    LnP ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.X = h->X;
+    ln.ldx = h->d;
+    ln.rows = batch * pl->Le;
+    ln.d = h->d;
+    ln.g1 = W(h, "encoder.norm.weight").f;
+    ln.b1 = W(h, "encoder.norm.bias").f;
+    ln.Yf = h->EncOut;
+    launch_layernorm(ln, st);
+    return check_launch("encoder");
+}
+
+// decoder-embed of rows of one key: Y[cmap rows] = Z[amap rows] W_dec_k^T + E_dec_k[r % mod]
+void dec_embed(m3pc_handle* h, int k, const void* Zop, RowMap amap, float* Yout, RowMap cmap, int M, int mod, int dt,
+               hipStream_t st) {
+    const int d = h->d;
+    const std::string kn = KEYN[k];
+    GemmP p = gemm_basic(Zop, d, Wop(h, "decoder_embed_dict." + kn + ".weight", dt), d, M, d, d, nullptr);
+    p.amap = amap;
+    p.cmap = cmap;
+    p.rowtab = h->Edec[k];
+    p.rt_mod = mod;
+    p.rt_ld = d;
+    gemm_out(p, DT_F32, Yout, d);
+    gemm(h, p, dt, st);
+}
+
+// Full (un-pruned) decoder on `batch` sequences: Z (4T rows each, operand dtype) -> Y (fp32) after all layers.
+int run_decoder_full(m3pc_handle* h, const void* Zop, int batch, int dt, hipStream_t st) {
+    const int T = h->T;
+    for (int k = 0; k < 4; ++k) {
+        RowMap m{T, 4 * T, k * T};
+        dec_embed(h, k, Zop, m, h->Y, m, batch * T, T, dt, st);
+    }
+    for (int i = 0; i < h->dm.n_dec_layer; ++i) CHK(run_block(h, "decoder.layers." + std::to_string(i), h->Y, batch, 4 * T, dt, st));
+    return check_launch("decoder");
+}
+
+// Output head of key k (not actions) on `rows` logical rows of Ysrc selected by xmap:
+// decoder.norm -> head LN -> Linear+GELU -> Linear(D_k) [-> de-tokenize]
+int run_head(m3pc_handle* h, int k, const float* Ysrc, RowMap xmap, int rows, float* out, int ldy, bool detok, int dt,
+             hipStream_t st) {
+    const int d = h->d;
+    const std::string kn = KEYN[k];
+    LnP ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.X = Ysrc;
+    ln.ldx = d;
+    ln.xmap = xmap;
+    ln.rows = rows;
+    ln.d = d;
+    ln.g1 = W(h, "decoder.norm.weight").f;
+    ln.b1 = W(h, "decoder.norm.bias").f;
+    ln.g2 = W(h, "output_head_dict." + kn + ".0.weight").f;
+    ln.b2 = W(h, "output_head_dict." + kn + ".0.bias").f;
+    if (dt == DT_BF16)
+        ln.Yb = (bf16_t*)h->Hn;
+    else
+        ln.Yf = (float*)h->Hn;
+    launch_layernorm(ln, st);
+    GemmP p = gemm_basic(h->Hn, d, Wop(h, "output_head_dict." + kn + ".1.weight", dt), d, rows, d, d,
+                         W(h, "output_head_dict." + kn + ".1.bias").f);
+    p.gelu = 1;
+    gemm_out(p, DT_F32, h->G, d);
+    gemm(h, p, dt, st);
+    HeadOutP ho;
+    memset(&ho, 0, sizeof(ho));
+    ho.X = h->G;
+    ho.ldx = d;
+    ho.rows = rows;
+    ho.d = d;
+    ho.D = h->feat[k];
+    ho.W = W(h, "output_head_dict." + kn + ".3.weight").f;
+    ho.b = W(h, "output_head_dict." + kn + ".3.bias").f;
+    if (detok && h->tok_norm[k]) {
+        ho.mean = h->tok_mean[k];
+        ho.stdv = h->tok_std[k];
+    }
+    ho.Y = out;
+    ho.ldy = ldy;
+    launch_head_out(ho, st);
+    return check_launch("head");
+}
+
+// Generic forward on `batch` sequences; outputs raw head values (no de-tokenization)
+int forward_impl(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, float* out_states, float* out_rewards,
+                 float* out_returns, float* out_mu, float* out_std, int dt, hipStream_t st) {
+    const int T = h->T, d = h->d;
+    if ((long long)batch * 4 * T > h->R) return fail(M3PC_ENOMEM, "batch %d exceeds workspace (max_batch=%d)", batch, h->dm.max_batch);
+    CHK(run_encoder(h, pl, in, batch, dt, st));
+    GatherP g;
+    memset(&g, 0, sizeof(g));
+    g.Xe = h->EncOut;
+    g.xe_bstride = (long long)pl->Le * d;
+    g.table = h->mask_tokens;
+    g.rowsrc = pl->d_dec_rowsrc;
+    g.rows_per_batch = 4 * T;
+    g.batch = batch;
+    g.d = d;
+    if (dt == DT_BF16)
+        g.outb = (bf16_t*)h->Z;
+    else
+        g.out = (float*)h->Z;
+    launch_gather_rows(g, st);
+    CHK(run_decoder_full(h, h->Z, batch, dt, st));
+    float* outs[4] = {out_states, nullptr, out_rewards, out_returns};
+    for (int k = 0; k < 4; ++k) {
+        if (k == M3PC_ACTIONS || !outs[k]) continue;
+        RowMap m{T, 4 * T, k * T};
+        CHK(run_head(h, k, h->Y, m, batch * T, outs[k], h->feat[k], false, dt, st));
+    }
+    if (out_mu && out_std) {
+        LnP ln;
+        memset(&ln, 0, sizeof(ln));
+        ln.X = h->Y;
+        ln.ldx = d;
+        ln.xmap = RowMap{T, 4 * T, M3PC_ACTIONS * T};
+        ln.rows = batch * T;
+        ln.d = d;
+        ln.g1 = W(h, "decoder.norm.weight").f;
+        ln.b1 = W(h, "decoder.norm.bias").f;
+        ln.Yf = h->G;
+        launch_layernorm(ln, st);
+        ActorP a;
+        memset(&a, 0, sizeof(a));
+        a.X = h->G;
+        a.ldx = d;
+        a.rows = batch * T;
+        a.d = d;
+        a.A = h->A;
+        a.Wmu = W(h, "output_head_dict.actions.mu.weight").f;
+        a.bmu = W(h, "output_head_dict.actions.mu.bias").f;
+        a.Wls = W(h, "output_head_dict.actions.log_std.weight").f;
+        a.bls = W(h, "output_head_dict.actions.log_std.bias").f;
+        a.mu = out_mu;
+        a.sd = out_std;
+        launch_actor_head(a, st);
+    }
+    return check_launch("forward");
+}
+
+// ---------------------------------------------------------------------------------- shared decoder tables
+int build_query(m3pc_handle* h, Plan* pl, int qi, int hh) {
+    Plan::Query& q = pl->query[qi];
+    if (q.built && q.h == hh) return 0;
+    const int T = h->T, idx = T - hh;
+    q.h = hh;
+    q.nq = 2 * hh;
+    q.qkeys[0] = qi == 0 ? M3PC_REWARDS : M3PC_STATES;
+    q.qkeys[1] = qi == 0 ? M3PC_RETURNS : M3PC_REWARDS;
+    std::vector<int> tab(q.nq), mix(q.nq);
+    q.all_masked = true;
+    for (int s = 0; s < 2; ++s)
+        for (int t = 0; t < hh; ++t) {
+            const int i = q.qkeys[s] * T + idx + t;
+            tab[s * hh + t] = -i - 1;
+            if (pl->dec_src[i] >= 0) {
+                q.all_masked = false;
+                mix[s * hh + t] = pl->dec_src[i];
+            } else {
+                mix[s * hh + t] = -i - 1;
+            }
+        }
+    if (!q.d_q_rowsrc_tab) {
+        CHK(dmalloc(&q.d_q_rowsrc_tab, (size_t)2 * T));
+        CHK(dmalloc(&q.d_q_rowsrc_mix, (size_t)2 * T));
+    }
+    HIPCHK(hipMemcpy(q.d_q_rowsrc_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(q.d_q_rowsrc_mix, mix.data(), mix.size() * sizeof(int), hipMemcpyHostToDevice));
+    for (int pr = 0; pr < 2; ++pr) q.tab[pr].valid = false;
+    q.built = true;
+    return 0;
+}
+
+// Candidate-independent decoder rows for plan `pl`: run decoder-embed, LN1 and the QKV projection on a
+// single sequence whose un-masked slots are zero (never read) and masked slots hold the mask tokens.
+int build_tables(m3pc_handle* h, Plan* pl, int qi, int dt, hipStream_t st) {
+    Plan::Query& q = pl->query[qi];
+    SharedTables& tb = q.tab[dt];
+    if (tb.valid) return 0;
+    const int T = h->T, d = h->d;
+    const size_t es = dtype_size(dt);
+    if (!tb.Yall) {
+        CHK(dmalloc(&tb.Yall, (size_t)4 * T * d));
+        CHK(dmalloc((char**)&tb.QKVm, (size_t)4 * T * 3 * d * es));
+        CHK(dmalloc((char**)&tb.QKVq, (size_t)2 * T * 3 * d * es));
+        CHK(dmalloc(&tb.Yq, (size_t)2 * T * d));
+    }
+    // Z: mask tokens everywhere (un-masked rows are ignored downstream)
+    std::vector<int> rs(4 * T);
+    for (int i = 0; i < 4 * T; ++i) rs[i] = -(i / T) - 1;
+    int* d_rs = nullptr;
+    CHK(dmalloc(&d_rs, rs.size()));
+    HIPCHK(hipMemcpyAsync(d_rs, rs.data(), rs.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    GatherP g;
+    memset(&g, 0, sizeof(g));
+    g.table = h->mask_tokens;
+    g.rowsrc = d_rs;
+    g.rows_per_batch = 4 * T;
+    g.batch = 1;
+    g.d = d;
+    if (dt == DT_BF16)
+        g.outb = (bf16_t*)h->Z;
+    else
+        g.out = (float*)h->Z;
+    launch_gather_rows(g, st);
+    for (int k = 0; k < 4; ++k) {
+        RowMap m{T, 4 * T, k * T};
+        dec_embed(h, k, h->Z, m, tb.Yall, m, T, T, dt, st);
+    }
+    const std::string pfx = "decoder.layers.0";
+    LnP ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.X = tb.Yall;
+    ln.ldx = d;
+    ln.rows = 4 * T;
+    ln.d = d;
+    ln.g1 = W(h, pfx + ".norm1.weight").f;
+    ln.b1 = W(h, pfx + ".norm1.bias").f;
+    if (dt == DT_BF16)
+        ln.Yb = (bf16_t*)h->Hn;
+    else
+        ln.Yf = (float*)h->Hn;
+    launch_layernorm(ln, st);
+    // full q|k|v rows of the 4T-token sequence go to h->QKV (fp32 copy for the gather), then compacted
+    {
+        GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".self_attn.in_proj_weight", dt), d, 4 * T, 3 * d, d,
+                             W(h, pfx + ".self_attn.in_proj_bias").f);
+        gemm_out(p, DT_F32, h->QKV, 3 * d);
+        gemm(h, p, dt, st);
+    }
+    g.table = (const float*)h->QKV;
+    g.d = 3 * d;
+    g.rowsrc = pl->d_masked_rowsrc;
+    g.rows_per_batch = pl->Lm;
+    g.out = dt == DT_F32 ? (float*)tb.QKVm : nullptr;
+    g.outb = dt == DT_BF16 ? (bf16_t*)tb.QKVm : nullptr;
+    launch_gather_rows(g, st);
+    g.rowsrc = q.d_q_rowsrc_tab;
+    g.rows_per_batch = q.nq;
+    g.out = dt == DT_F32 ? (float*)tb.QKVq : nullptr;
+    g.outb = dt == DT_BF16 ? (bf16_t*)tb.QKVq : nullptr;
+    launch_gather_rows(g, st);
+    g.table = tb.Yall;
+    g.d = d;
+    g.out = tb.Yq;
+    g.outb = nullptr;
+    launch_gather_rows(g, st);
+    HIPCHK(hipStreamSynchronize(st));
+    hipFree(d_rs);
+    tb.valid = true;
+    return check_launch("tables");
+}
+
+// ---------------------------------------------------------------------------------- candidate pass
+int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* rewards, int n,
+                   const float* sample_actions, float* expect_return, float* pred_rewards, float* pred_boot, int dt,
+                   hipStream_t st) {
+    const int T = h->T, d = h->d, hh = a->horizon, idx = T - hh;
+    const size_t es = dtype_size(dt);
+    std::vector<unsigned char> m[4];
+    for (int k = 0; k < 4; ++k) m[k].assign(T, 0);
+    for (int t = 0; t <= idx; ++t) m[M3PC_STATES][t] = 1;
+    for (int t = 0; t < T; ++t) m[M3PC_ACTIONS][t] = 1;
+    const unsigned char* mp[4] = {m[0].data(), m[1].data(), m[2].data(), m[3].data()};
+    Plan* pl = nullptr;
+    CHK(get_plan(h, mp, &pl));  // fd mask (finetune_omtm/masks.py:30-44)
+    const int qi = a->mode == M3PC_MODE_RTG ? 0 : 1;
+    CHK(build_query(h, pl, qi, hh));
+    CHK(build_tables(h, pl, qi, dt, st));
+    Plan::Query& q = pl->query[qi];
+    SharedTables& tb = q.tab[dt];
+    const int Le = pl->Le, nq = q.nq;
+    if ((long long)n * Le > h->R || (long long)n * nq > h->R) return fail(M3PC_ENOMEM, "n_count %d exceeds workspace", n);
+
+    TokIn in;
+    memset(&in, 0, sizeof(in));
+    in.ptr[M3PC_STATES] = states;
+    in.normalize[M3PC_STATES] = h->tok_norm[M3PC_STATES];
+    in.ptr[M3PC_ACTIONS] = h->cand;
+    in.bstride[M3PC_ACTIONS] = (long long)T * h->A;
+    in.normalize[M3PC_ACTIONS] = h->tok_norm[M3PC_ACTIONS];
+    in.ptr[M3PC_REWARDS] = rewards;
+    in.ptr[M3PC_RETURNS] = h->rtok;
+    CHK(run_encoder(h, pl, in, n, dt, st));
+
+    // decoder inputs of the un-masked tokens (kept sets are prefixes 0..kept-1 for the fd mask)
+    const void* enc_op = h->EncOut;
+    if (dt == DT_BF16) {
+        launch_f32_to_bf16(h->EncOut, (bf16_t*)h->Z, (long long)n * Le * d, st);
+        enc_op = h->Z;
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (!pl->kept[k]) continue;
+        RowMap mm{pl->kept[k], Le, pl->enc_off[k]};
+        dec_embed(h, k, enc_op, mm, h->Y, mm, n * pl->kept[k], pl->kept[k], dt, st);
+    }
+    const std::string pfx = "decoder.layers.0";
+    LnP ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.X = h->Y;
+    ln.ldx = d;
+    ln.rows = n * Le;
+    ln.d = d;
+    ln.g1 = W(h, pfx + ".norm1.weight").f;
+    ln.b1 = W(h, pfx + ".norm1.bias").f;
+    if (dt == DT_BF16)
+        ln.Yb = (bf16_t*)h->Hn;
+    else
+        ln.Yf = (float*)h->Hn;
+    launch_layernorm(ln, st);
+    {  // K|V of the un-masked tokens: in_proj rows [d, 3d)
+        const char* wkv = (const char*)Wop(h, pfx + ".self_attn.in_proj_weight", dt) + (size_t)d * d * es;
+        GemmP p = gemm_basic(h->Hn, d, wkv, d, n * Le, 2 * d, d, W(h, pfx + ".self_attn.in_proj_bias").f + d);
+        gemm_out(p, dt, h->QKV, 2 * d);
+        gemm(h, p, dt, st);
+    }
+    // queries
+    const void* Qp;
+    long long q_bstride;
+    int ldq;
+    float* Yq_rows = nullptr;  // per-candidate residual rows (n*nq, d) when some scored token is un-masked
+    char* kvu = (char*)h->QKV;
+    char* qbuf = kvu + (size_t)n * Le * 2 * d * es;  // behind K|V in the same buffer
+    if (q.all_masked) {
+        Qp = tb.QKVq;
+        q_bstride = 0;
+        ldq = 3 * d;
+    } else {
+        Yq_rows = h->X;  // encoder residual stream is dead by now
+        GatherP g;
+        memset(&g, 0, sizeof(g));
+        g.Xe = h->Y;
+        g.xe_bstride = (long long)Le * d;
+        g.table = tb.Yall;
+        g.rowsrc = q.d_q_rowsrc_mix;
+        g.rows_per_batch = nq;
+        g.batch = n;
+        g.d = d;
+        g.out = Yq_rows;
+        launch_gather_rows(g, st);
+        ln.X = Yq_rows;
+        ln.rows = n * nq;
+        launch_layernorm(ln, st);
+        GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".self_attn.in_proj_weight", dt), d, n * nq, d, d,
+                             W(h, pfx + ".self_attn.in_proj_bias").f);
+        gemm_out(p, dt, qbuf, d);
+        gemm(h, p, dt, st);
+        Qp = qbuf;
+        q_bstride = (long long)nq * d;
+        ldq = d;
+    }
+    {
+        AttnP at;
+        memset(&at, 0, sizeof(at));
+        at.Q = Qp;
+        at.q_bstride = q_bstride;
+        at.ldq = ldq;
+        at.K1 = kvu;
+        at.V1 = kvu + (size_t)d * es;
+        at.kv1_bstride = (long long)Le * 2 * d;
+        at.ldkv1 = 2 * d;
+        at.L1 = Le;
+        at.K2 = (const char*)tb.QKVm + (size_t)d * es;
+        at.V2 = (const char*)tb.QKVm + (size_t)2 * d * es;
+        at.ldkv2 = 3 * d;
+        at.L2 = pl->Lm;
+        at.O = h->O;
+        at.o_bstride = (long long)nq * d;
+        at.ldo = d;
+        at.batch = n;
+        at.n_head = h->nh;
+        at.hd = h->hd;
+        at.Lq = nq;
+        at.scale = 1.0f / sqrtf((float)h->hd);
+        launch_attention(at, dt, st);
+    }
+    float* Y1 = h->EncOut;  // (n*nq, d) decoder residual of the scored tokens (EncOut is dead: Z/Y hold its uses)
+    {
+        GemmP p = gemm_basic(h->O, d, Wop(h, pfx + ".self_attn.out_proj.weight", dt), d, n * nq, d, d,
+                             W(h, pfx + ".self_attn.out_proj.bias").f);
+        if (q.all_masked) {
+            p.rowtab = tb.Yq;
+            p.rt_mod = nq;
+            p.rt_ld = d;
+        } else {
+            p.res = Yq_rows;
+            p.ldr = d;
+        }
+        gemm_out(p, DT_F32, Y1, d);
+        gemm(h, p, dt, st);
+    }
+    ln.X = Y1;
+    ln.rows = n * nq;
+    ln.g1 = W(h, pfx + ".norm2.weight").f;
+    ln.b1 = W(h, pfx + ".norm2.bias").f;
+    launch_layernorm(ln, st);
+    {
+        GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".linear1.weight", dt), d, n * nq, h->ff, d, W(h, pfx + ".linear1.bias").f);
+        p.gelu = 1;
+        gemm_out(p, dt, h->F, h->ff);
+        gemm(h, p, dt, st);
+    }
+    {
+        GemmP p = gemm_basic(h->F, h->ff, Wop(h, pfx + ".linear2.weight", dt), h->ff, n * nq, d, h->ff, W(h, pfx + ".linear2.bias").f);
+        p.res = Y1;
+        p.ldr = d;
+        gemm_out(p, DT_F32, Y1, d);
+        gemm(h, p, dt, st);
+    }
+    // heads of the two scored keys -> pred[s] (n*h, D_k), de-tokenized
+    for (int s = 0; s < 2; ++s) {
+        RowMap xm{hh, nq, s * hh};
+        CHK(run_head(h, q.qkeys[s], Y1, xm, n * hh, h->pred[s], h->feat[q.qkeys[s]], true, dt, st));
+    }
+    const float* rw;
+    const float* boot;
+    float boot_scale;
+    if (a->mode == M3PC_MODE_RTG) {
+        rw = h->pred[0];
+        boot = h->pred[1];
+        boot_scale = 1000.0f;  // learner.py:305
+    } else {
+        if (!h->critic_set) return fail(M3PC_ESTATE, "critic weights not set");
+        CriticP c;
+        memset(&c, 0, sizeof(c));
+        c.states = h->pred[0];
+        c.actions = sample_actions;
+        c.rows = n * hh;
+        c.S = h->S;
+        c.A = h->A;
+        c.hidden = h->dm.critic_hidden;
+        c.om = h->c_om;
+        c.os = h->c_os;
+        for (int i = 0; i < 2; ++i) {
+            c.W1T[i] = h->cW1T[i];
+            c.b1[i] = h->cb1[i];
+            c.W2T[i] = h->cW2T[i];
+            c.b2[i] = h->cb2[i];
+            c.W3[i] = h->cW3[i];
+            c.b3[i] = h->cb3[i];
+        }
+        c.q = h->qv;
+        launch_critic(c, st);
+        rw = h->pred[1];
+        boot = h->qv;
+        boot_scale = 1.0f;
+    }
+    ScoreP sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.rewards = rw;
+    sc.boot = boot;
+    sc.n = n;
+    sc.h = hh;
+    sc.boot_scale = boot_scale;
+    sc.gamma = (float)a->discount;
+    sc.lmbda = a->lmbda;
+    sc.expect_return = expect_return;
+    sc.boot_out = pred_boot;
+    launch_score(sc, st);
+    if (pred_rewards) HIPCHK(hipMemcpyAsync(pred_rewards, rw, (size_t)n * hh * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return check_launch("candidate_pass");
+}
+
+int find_tensor(const m3pc_named_tensor* list, int n, const std::string& name) {
+    for (int i = 0; i < n; ++i)
+        if (list[i].name && name == list[i].name) return i;
+    return -1;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+const char* m3pc_last_error(void) { return g_err; }
+int m3pc_abi_version(void) { return M3PC_ABI_VERSION; }
+
+int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out) {
+    if (!dims || !out) return fail(M3PC_EINVAL, "null argument");
+    const m3pc_dims& D = *dims;
+    if (D.n_embd % 64 || D.n_embd > 1024 || D.n_head <= 0 || D.n_embd % D.n_head)
+        return fail(M3PC_EINVAL, "n_embd must be a multiple of 64 (<=1024) and divisible by n_head");
+    const int hd = D.n_embd / D.n_head;
+    if (hd != 32 && hd != 64 && hd != 128) return fail(M3PC_EINVAL, "head_dim %d unsupported (32, 64, 128)", hd);
+    if (D.state_dim < 1 || D.state_dim > 32 || D.action_dim < 1 || D.action_dim > 32)
+        return fail(M3PC_EINVAL, "state_dim/action_dim must be in [1,32]");
+    if (D.traj_length < 1 || D.traj_length > 64) return fail(M3PC_EINVAL, "traj_length must be in [1,64]");
+    if (D.n_dec_layer != 1) return fail(M3PC_EINVAL, "n_dec_layer must be 1 (every shipped m3pc config)");
+    if (D.n_enc_layer < 1 || D.max_candidates < 1 || D.max_batch < 1) return fail(M3PC_EINVAL, "bad sizes");
+    if (D.critic_hidden < 0 || D.critic_hidden > 256) return fail(M3PC_EINVAL, "critic_hidden must be <= 256");
+    HIPCHK(hipSetDevice(device));
+    std::unique_ptr<m3pc_handle> h(new m3pc_handle());
+    h->dm = D;
+    h->device = device;
+    h->d = D.n_embd;
+    h->nh = D.n_head;
+    h->hd = hd;
+    h->T = D.traj_length;
+    h->S = D.state_dim;
+    h->A = D.action_dim;
+    h->ff = 4 * D.n_embd;
+    h->feat[0] = D.state_dim;
+    h->feat[1] = D.action_dim;
+    h->feat[2] = 1;
+    h->feat[3] = 1;
+    declare_weights(h.get());
+    for (auto& kv : h->w) {
+        CHK(dmalloc(&kv.second.f, (size_t)kv.second.numel));
+        if (kv.second.gemm) CHK(dmalloc(&kv.second.b, (size_t)kv.second.numel));
+    }
+    const int d = h->d, T = h->T;
+    for (int k = 0; k < 4; ++k) {
+        CHK(dmalloc(&h->WT[k], (size_t)h->feat[k] * d));
+        CHK(dmalloc(&h->Eenc[k], (size_t)T * d));
+        CHK(dmalloc(&h->Edec[k], (size_t)T * d));
+        CHK(dmalloc(&h->tok_mean[k], 32));
+        CHK(dmalloc(&h->tok_std[k], 32));
+    }
+    CHK(dmalloc(&h->mask_tokens, (size_t)4 * d));
+    const long long r1 = (long long)D.max_candidates * 2 * T, r2 = (long long)D.max_batch * 4 * T;
+    h->R = r1 > r2 ? r1 : r2;
+    if (h->R < 4 * T) h->R = 4 * T;
+    const size_t R = (size_t)h->R;
+    CHK(dmalloc(&h->X, R * d));
+    CHK(dmalloc(&h->Y, R * d));
+    CHK(dmalloc(&h->EncOut, R * d));
+    CHK(dmalloc(&h->G, R * d));
+    CHK(dmalloc((float**)&h->Hn, R * d));
+    CHK(dmalloc((float**)&h->QKV, R * 3 * d));
+    CHK(dmalloc((float**)&h->O, R * d));
+    CHK(dmalloc((float**)&h->F, R * 4 * d));
+    CHK(dmalloc((float**)&h->Z, R * d));
+    CHK(dmalloc(&h->cand, (size_t)D.max_candidates * T * h->A));
+    CHK(dmalloc(&h->loc, (size_t)D.max_batch * T * h->A + 64));
+    CHK(dmalloc(&h->sd, (size_t)D.max_batch * T * h->A + 64));
+    CHK(dmalloc(&h->rtok, (size_t)T));
+    CHK(dmalloc(&h->pred[0], (size_t)D.max_candidates * T * 32));
+    CHK(dmalloc(&h->pred[1], (size_t)D.max_candidates * T * 32));
+    CHK(dmalloc(&h->qv, (size_t)D.max_candidates * T));
+    CHK(dmalloc(&h->sel_scratch, 64));
+    if (D.critic_hidden > 0) {
+        const int Hd = D.critic_hidden, SA = h->S + h->A;
+        for (int i = 0; i < 2; ++i) {
+            CHK(dmalloc(&h->cW1T[i], (size_t)SA * Hd));
+            CHK(dmalloc(&h->cb1[i], Hd));
+            CHK(dmalloc(&h->cW2T[i], (size_t)Hd * Hd));
+            CHK(dmalloc(&h->cb2[i], Hd));
+            CHK(dmalloc(&h->cW3[i], Hd));
+            CHK(dmalloc(&h->cb3[i], 4));
+        }
+        CHK(dmalloc(&h->c_om, 32));
+        CHK(dmalloc(&h->c_os, 32));
+    }
+    *out = h.release();
+    return 0;
+}
+
+int m3pc_destroy(m3pc_handle* h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    for (auto& kv : h->w) {
+        hipFree(kv.second.f);
+        if (kv.second.b) hipFree(kv.second.b);
+    }
+    for (int k = 0; k < 4; ++k) {
+        hipFree(h->WT[k]);
+        hipFree(h->Eenc[k]);
+        hipFree(h->Edec[k]);
+        hipFree(h->tok_mean[k]);
+        hipFree(h->tok_std[k]);
+    }
+    hipFree(h->mask_tokens);
+    void* bufs[] = {h->X, h->Y, h->EncOut, h->G, h->Hn, h->QKV, h->O, h->F, h->Z, h->cand, h->loc, h->sd, h->rtok,
+                    h->pred[0], h->pred[1], h->qv, h->sel_scratch, h->c_om, h->c_os};
+    for (void* b : bufs)
+        if (b) hipFree(b);
+    for (int i = 0; i < 2; ++i) {
+        void* cb[] = {h->cW1T[i], h->cb1[i], h->cW2T[i], h->cb2[i], h->cW3[i], h->cb3[i]};
+        for (void* b : cb)
+            if (b) hipFree(b);
+    }
+    for (auto& kv : h->plans) {
+        Plan* pl = kv.second.get();
+        hipFree(pl->d_tokmap);
+        hipFree(pl->d_dec_rowsrc);
+        hipFree(pl->d_masked_rowsrc);
+        for (int q = 0; q < 2; ++q) {
+            if (pl->query[q].d_q_rowsrc_tab) hipFree(pl->query[q].d_q_rowsrc_tab);
+            if (pl->query[q].d_q_rowsrc_mix) hipFree(pl->query[q].d_q_rowsrc_mix);
+            for (int pr = 0; pr < 2; ++pr) free_tables(pl->query[q].tab[pr]);
+        }
+    }
+    for (auto& e : h->ev) {
+        hipEventDestroy(e.a);
+        hipEventDestroy(e.b);
+    }
+    delete h;
+    return 0;
+}
+
+int m3pc_load_weights(m3pc_handle* h, const m3pc_named_tensor* tensors, int n, void* stream) {
+    if (!h || !tensors) return fail(M3PC_EINVAL, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->device));
+    for (auto& kv : h->w) {
+        const int i = find_tensor(tensors, n, kv.first);
+        if (i < 0) return fail(M3PC_EINVAL, "state_dict is missing '%s'", kv.first.c_str());
+        if (tensors[i].numel != kv.second.numel)
+            return fail(M3PC_EINVAL, "'%s' has %lld elements, expected %lld", kv.first.c_str(), tensors[i].numel, kv.second.numel);
+        HIPCHK(hipMemcpyAsync(kv.second.f, tensors[i].data, (size_t)kv.second.numel * sizeof(float),
+                              tensors[i].on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        if (kv.second.gemm) launch_f32_to_bf16(kv.second.f, kv.second.b, kv.second.numel, st);
+        kv.second.loaded = true;
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    // small derived tables on the host
+    const int d = h->d, T = h->T;
+    std::vector<float> pos((size_t)T * d);
+    HIPCHK(hipMemcpy(pos.data(), W(h, "pos_embed").f, pos.size() * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<float> mt((size_t)4 * d);
+    for (int k = 0; k < 4; ++k) {
+        const std::string kn = KEYN[k];
+        const int f = h->feat[k];
+        std::vector<float> w((size_t)d * f), wt((size_t)d * f), b(d), pd(d), e((size_t)T * d);
+        HIPCHK(hipMemcpy(w.data(), W(h, "encoder_embed_dict." + kn + ".weight").f, w.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int c = 0; c < d; ++c)
+            for (int j = 0; j < f; ++j) wt[(size_t)j * d + c] = w[(size_t)c * f + j];
+        HIPCHK(hipMemcpy(h->WT[k], wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+        for (int pass = 0; pass < 2; ++pass) {
+            const std::string side = pass == 0 ? "encoder" : "decoder";
+            HIPCHK(hipMemcpy(b.data(), W(h, side + "_embed_dict." + kn + ".bias").f, d * sizeof(float), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(pd.data(), W(h, side + "_per_dim_encoding." + kn).f, d * sizeof(float), hipMemcpyDeviceToHost));
+            for (int t = 0; t < T; ++t)
+                for (int c = 0; c < d; ++c) e[(size_t)t * d + c] = (b[c] + pd[c]) + pos[(size_t)t * d + c];
+            HIPCHK(hipMemcpy(pass == 0 ? h->Eenc[k] : h->Edec[k], e.data(), e.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        HIPCHK(hipMemcpy(mt.data() + (size_t)k * d, W(h, "mask_token_dict." + kn).f, d * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    HIPCHK(hipMemcpy(h->mask_tokens, mt.data(), mt.size() * sizeof(float), hipMemcpyHostToDevice));
+    invalidate_tables(h);
+    h->weights_loaded = true;
+    return 0;
+}
+
+int m3pc_set_tokenizer(m3pc_handle* h, int key, const float* mean, const float* std_, int dim, int normalize) {
+    if (!h || key < 0 || key > 3 || !mean || !std_) return fail(M3PC_EINVAL, "bad argument");
+    if (dim != h->feat[key]) return fail(M3PC_EINVAL, "tokenizer '%s' has dim %d, expected %d", KEYN[key], dim, h->feat[key]);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpy(h->tok_mean[key], mean, dim * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->tok_std[key], std_, dim * sizeof(float), hipMemcpyHostToDevice));
+    h->h_mean[key].assign(mean, mean + dim);
+    h->h_std[key].assign(std_, std_ + dim);
+    h->tok_norm[key] = normalize ? 1 : 0;
+    h->tok_set[key] = true;
+    return 0;
+}
+
+int m3pc_set_critic(m3pc_handle* h, const m3pc_named_tensor* tensors, int n, const float* obs_mean, const float* obs_std,
+                    void* stream) {
+    if (!h || !tensors || !obs_mean || !obs_std) return fail(M3PC_EINVAL, "null argument");
+    if (h->dm.critic_hidden <= 0) return fail(M3PC_EINVAL, "handle was created without a critic");
+    (void)stream;
+    HIPCHK(hipSetDevice(h->device));
+    const int Hd = h->dm.critic_hidden, SA = h->S + h->A;
+    auto fetch = [&](const std::string& name, long long numel, std::vector<float>& out) -> int {
+        const int i = find_tensor(tensors, n, name);
+        if (i < 0) return fail(M3PC_EINVAL, "critic state_dict is missing '%s'", name.c_str());
+        if (tensors[i].numel != numel) return fail(M3PC_EINVAL, "'%s' has %lld elements, expected %lld", name.c_str(), tensors[i].numel, numel);
+        out.resize((size_t)numel);
+        HIPCHK(hipMemcpy(out.data(), tensors[i].data, (size_t)numel * sizeof(float),
+                         tensors[i].on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+        return 0;
+    };
+    for (int qn = 0; qn < 2; ++qn) {
+        const std::string q = qn == 0 ? "q1" : "q2";
+        std::vector<float> w1, b1, w2, b2, w3, b3;
+        CHK(fetch(q + ".net.0.weight", (long long)Hd * SA, w1));
+        CHK(fetch(q + ".net.0.bias", Hd, b1));
+        CHK(fetch(q + ".net.2.weight", (long long)Hd * Hd, w2));
+        CHK(fetch(q + ".net.2.bias", Hd, b2));
+        CHK(fetch(q + ".net.4.weight", Hd, w3));
+        CHK(fetch(q + ".net.4.bias", 1, b3));
+        std::vector<float> w1t((size_t)SA * Hd), w2t((size_t)Hd * Hd);
+        for (int c = 0; c < Hd; ++c)
+            for (int f = 0; f < SA; ++f) w1t[(size_t)f * Hd + c] = w1[(size_t)c * SA + f];
+        for (int c = 0; c < Hd; ++c)
+            for (int k = 0; k < Hd; ++k) w2t[(size_t)k * Hd + c] = w2[(size_t)c * Hd + k];
+        HIPCHK(hipMemcpy(h->cW1T[qn], w1t.data(), w1t.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->cb1[qn], b1.data(), b1.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->cW2T[qn], w2t.data(), w2t.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->cb2[qn], b2.data(), b2.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->cW3[qn], w3.data(), w3.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->cb3[qn], b3.data(), sizeof(float), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(h->c_om, obs_mean, h->S * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->c_os, obs_std, h->S * sizeof(float), hipMemcpyHostToDevice));
+    h->critic_set = true;
+    return 0;
+}
+
+int m3pc_tokenize(m3pc_handle* h, int key, const void* in, int in_f64, float* out, long long rows, void* stream) {
+    if (!h || key < 0 || key > 3 || !in || !out) return fail(M3PC_EINVAL, "bad argument");
+    if (!h->tok_set[key]) return fail(M3PC_ESTATE, "tokenizer '%s' not set", KEYN[key]);
+    HIPCHK(hipSetDevice(h->device));
+    launch_tokenize(in, in_f64, out, rows, h->feat[key], h->tok_mean[key], h->tok_std[key], h->tok_norm[key], (hipStream_t)stream);
+    return check_launch("tokenize");
+}
+
+int m3pc_detokenize(m3pc_handle* h, int key, const float* in, float* out, long long rows, void* stream) {
+    if (!h || key < 0 || key > 3 || !in || !out) return fail(M3PC_EINVAL, "bad argument");
+    if (!h->tok_set[key]) return fail(M3PC_ESTATE, "tokenizer '%s' not set", KEYN[key]);
+    HIPCHK(hipSetDevice(h->device));
+    launch_detokenize(in, out, rows, h->feat[key], h->tok_mean[key], h->tok_std[key], h->tok_norm[key], (hipStream_t)stream);
+    return check_launch("detokenize");
+}
+
+int m3pc_forward(m3pc_handle* h, int batch, const float* const tokens[4], const unsigned char* const masks[4],
+                 float* out_states, float* out_rewards, float* out_returns, float* out_mu, float* out_std, int precision,
+                 void* stream) {
+    if (!h || !tokens || !masks) return fail(M3PC_EINVAL, "null argument");
+    if (!h->weights_loaded) return fail(M3PC_ESTATE, "weights not loaded");
+    if (batch < 1 || batch > h->dm.max_batch) return fail(M3PC_EINVAL, "batch %d outside [1, max_batch=%d]", batch, h->dm.max_batch);
+    if (precision != M3PC_PREC_FP32 && precision != M3PC_PREC_BF16) return fail(M3PC_EINVAL, "bad precision");
+    if ((out_mu == nullptr) != (out_std == nullptr)) return fail(M3PC_EINVAL, "out_mu and out_std go together");
+    HIPCHK(hipSetDevice(h->device));
+    Plan* pl = nullptr;
+    CHK(get_plan(h, masks, &pl));
+    TokIn in;
+    memset(&in, 0, sizeof(in));
+    for (int k = 0; k < 4; ++k) {
+        if (pl->kept[k] && !tokens[k]) return fail(M3PC_EINVAL, "tokens[%s] is null but its mask keeps tokens", KEYN[k]);
+        in.ptr[k] = tokens[k];
+        in.bstride[k] = (long long)h->T * h->feat[k];
+    }
+    return forward_impl(h, pl, in, batch, out_states, out_rewards, out_returns, out_mu, out_std,
+                        precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32, (hipStream_t)stream);
+}
+
+int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* actions, const float* rewards,
+                   const float* eps, float* loc, float* std_, float* sample_actions, float* expect_return,
+                   float* pred_rewards, float* pred_boot, void* stream) {
+    if (!h || !a || !states || !actions || !rewards || !eps || !sample_actions || !expect_return)
+        return fail(M3PC_EINVAL, "null argument");
+    if (!h->weights_loaded) return fail(M3PC_ESTATE, "weights not loaded");
+    for (int k = 0; k < 4; ++k)
+        if (!h->tok_set[k]) return fail(M3PC_ESTATE, "tokenizer '%s' not set", KEYN[k]);
+    const int T = h->T;
+    if (a->horizon < 1 || a->horizon > T) return fail(M3PC_EINVAL, "horizon %d outside [1, T=%d]", a->horizon, T);
+    if (a->mode < 0 || a->mode > 2) return fail(M3PC_EINVAL, "bad mode %d", a->mode);
+    if (a->precision != M3PC_PREC_FP32 && a->precision != M3PC_PREC_BF16) return fail(M3PC_EINVAL, "bad precision");
+    if (a->n_count < 1 || a->n_begin < 0 || a->n_begin + a->n_count > a->n_total)
+        return fail(M3PC_EINVAL, "candidate range [%d,+%d) outside n_total=%d", a->n_begin, a->n_count, a->n_total);
+    if (a->n_count > h->dm.max_candidates) return fail(M3PC_ENOMEM, "n_count %d > max_candidates %d", a->n_count, h->dm.max_candidates);
+    if (a->mode != M3PC_MODE_RTG && !h->critic_set) return fail(M3PC_ESTATE, "critic weights not set");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->device));
+    const int hh = a->horizon, idx = T - hh;
+
+    // returns token: float64 normalisation then cast (learner.py:371-374, continuous.py:74-79)
+    double rt = a->rtg;
+    if (h->tok_norm[M3PC_RETURNS]) rt = (rt - (double)h->h_mean[M3PC_RETURNS][0]) / (double)h->h_std[M3PC_RETURNS][0];
+    launch_fill(h->rtok, (float)rt, T, st);
+
+    // PASS 1: return-conditioned policy, batch 1, rcbc mask (finetune_omtm/masks.py:7-27), always fp32
+    std::vector<unsigned char> m[4];
+    for (int k = 0; k < 4; ++k) m[k].assign(T, 0);
+    for (int t = 0; t <= idx; ++t) m[M3PC_STATES][t] = 1;
+    for (int t = 0; t < idx; ++t) m[M3PC_ACTIONS][t] = 1;
+    for (int t = 0; t < T; ++t) m[M3PC_RETURNS][t] = 1;
+    const unsigned char* mp[4] = {m[0].data(), m[1].data(), m[2].data(), m[3].data()};
+    Plan* pl = nullptr;
+    CHK(get_plan(h, mp, &pl));
+    TokIn in;
+    memset(&in, 0, sizeof(in));
+    in.ptr[M3PC_STATES] = states;
+    in.normalize[M3PC_STATES] = h->tok_norm[M3PC_STATES];
+    in.ptr[M3PC_ACTIONS] = actions;
+    in.normalize[M3PC_ACTIONS] = h->tok_norm[M3PC_ACTIONS];
+    in.ptr[M3PC_REWARDS] = rewards;
+    in.normalize[M3PC_REWARDS] = h->tok_norm[M3PC_REWARDS];
+    in.ptr[M3PC_RETURNS] = h->rtok;
+    CHK(forward_impl(h, pl, in, 1, nullptr, nullptr, nullptr, h->loc, h->sd, DT_F32, st));
+    if (loc) HIPCHK(hipMemcpyAsync(loc, h->loc, (size_t)T * h->A * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (std_) HIPCHK(hipMemcpyAsync(std_, h->sd, (size_t)T * h->A * sizeof(float), hipMemcpyDeviceToDevice, st));
+
+    // candidates
+    SampleP sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.hist_actions = actions;
+    sp.loc = h->loc;
+    sp.sd = h->sd;
+    sp.eps = eps;
+    sp.mode = a->mode == M3PC_MODE_NOISE ? 1 : 0;
+    sp.T = T;
+    sp.A = h->A;
+    sp.idx = idx;
+    sp.h = hh;
+    sp.n_begin = a->n_begin;
+    sp.n_count = a->n_count;
+    sp.cand = h->cand;
+    sp.sample_actions = sample_actions;
+    launch_sample(sp, st);
+
+    // PASS 2 + scoring
+    return candidate_pass(h, a, states, rewards, a->n_count, sample_actions, expect_return, pred_rewards, pred_boot,
+                          a->precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32, st);
+}
+
+int m3pc_select(m3pc_handle* h, const float* expect_return, const float* a0, long long a0_stride, int n, float temperature,
+                float* p, float* eval_action, int* argmax, void* stream) {
+    if (!h || !expect_return || n < 1) return fail(M3PC_EINVAL, "bad argument");
+    if (eval_action && !a0) return fail(M3PC_EINVAL, "eval_action needs a0");
+    HIPCHK(hipSetDevice(h->device));
+    SelectP s;
+    memset(&s, 0, sizeof(s));
+    s.er = expect_return;
+    s.a0 = a0;
+    s.a0_stride = a0_stride;
+    s.n = n;
+    s.A = h->A;
+    s.temperature = temperature;
+    s.p = p;
+    s.eval_action = eval_action;
+    s.argmax = argmax;
+    s.scratch = h->sel_scratch;
+    launch_select(s, (hipStream_t)stream);
+    return check_launch("select");
+}
+
+int m3pc_profile_enable(m3pc_handle* h, int enable) {
+    if (!h) return fail(M3PC_EINVAL, "null handle");
+    h->prof = enable != 0;
+    return 0;
+}
+
+int m3pc_profile_read(m3pc_handle* h, long long* launches, double* gemm_ms, double* gemm_flops, int reset) {
+    if (!h) return fail(M3PC_EINVAL, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    double ms = 0, fl = 0;
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, h->ev[i].a, h->ev[i].b));
+        ms += t;
+        fl += h->ev[i].flops;
+    }
+    if (launches) *launches = (long long)h->ev_used;
+    if (gemm_ms) *gemm_ms = ms;
+    if (gemm_flops) *gemm_flops = fl;
+    if (reset) h->ev_used = 0;
+    return 0;
+}
+
+}  // extern "C"

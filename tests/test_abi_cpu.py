@@ -1,0 +1,59 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds for gfx950, loads without a GPU and exports
+every symbol include/m3pc_hip.h declares; the ctypes struct layouts match the header."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from m3pc_amd import build, capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    path = build.build_library()
+    return capi.load_library(path)
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "m3pc_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(m3pc_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/m3pc_hip.h but not exported"
+    assert set(names) == set(capi.EXPORTS)
+
+
+def test_abi_version_and_error_string(lib):
+    assert lib.m3pc_abi_version() == capi.ABI_VERSION
+    assert isinstance(lib.m3pc_last_error(), bytes)
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(capi.Dims) == 10 * 4
+    assert ctypes.sizeof(capi.PlanArgs) == 6 * 4 + 3 * 8
+    assert capi.PlanArgs.lmbda.offset == 24 and capi.PlanArgs.rtg.offset == 40
+    assert ctypes.sizeof(capi.NamedTensor) == 32
+
+
+def test_argument_validation_without_gpu(lib):
+    # null arguments are rejected before any HIP call is made
+    assert lib.m3pc_create(None, 0, None) == -1
+    assert b"null" in lib.m3pc_last_error()
+    assert lib.m3pc_destroy(None) == 0
+
+
+def test_no_cpu_fallback_in_package():
+    """The product path must not import the oracle or silently run on the CPU."""
+    pkg = os.path.join(ROOT, "m3pc_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            text = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in text and "from oracle" not in text and "mtm_oracle" not in text, fn
