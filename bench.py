@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC plan-steps/sec of the m3pc test-time planner on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+One "step" = one complete plan step of rtg_guiding (research/finetune_omtm/learner.py:271-327): draw eps,
+policy pass (batch 1), sample N candidates, batched candidate pass, TD(lambda) scoring, all-gather of the
+shards (N > 1 GPU), fp32 re-score of the bf16 top-32, softmax / weighted mean / argmax, multinomial draw.
+Inputs (window, weights) are resident in HBM when the timed region starts.
+
+Workload at 1 GPU: BASELINE configs[1] = hopper-medium-v2 shapes (S=11, A=3), rtg_guiding, N=1024
+candidates, H=16, T=32 (=2H, the reference's shipped T/H ratio), bf16 candidate pass, synthetic data.
+Multi-GPU: weak scaling -- 1024 candidates PER GPU (global N = 1024*G, sharded by candidate, one RCCL
+all-gather of scores + first actions per step); value counts 1024-candidate plan-step units:
+value = G * K / t.  `--strong` keeps the global N at 1024 instead.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # /opt/skills/guides/MI355X_MICROARCH.md, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def alg_flops(N, T, H, S, A, d=512, n_enc=2, mode="rtg"):
+    """Algorithmic (exactly pruned) FLOPs of one plan step, SURVEY.md section 8(d)."""
+    idx = T - H
+    Le = (idx + 1) + T
+    Ld = 4 * T
+    c, q, e = 24 * d * d, 4 * d, 2 * d * d
+    nq = 2 * H
+    feats = {"states": S, "actions": A}
+    embed = 2 * d * (S * (idx + 1) + A * T)
+    dbar = 1.0 if mode == "rtg" else (S + 1) / 2.0
+    per_cand = (n_enc * (c * Le + q * Le * Le) + embed + Le * e + Le * 2 * e + nq * Ld * q + nq * e + nq * 16 * d * d
+                + nq * (e + 2 * d * dbar))
+    Le1 = (idx + 1) + idx + T
+    pass1 = n_enc * (c * Le1 + q * Le1 * Le1) + Ld * e + (c * Ld + q * Ld * Ld) + T * (e + 2 * d * A)
+    critic = 0 if mode == "rtg" else N * H * 2 * 2 * ((S + A) * 256 + 256 * 256 + 256)
+    return N * per_cand + pass1 + critic
+
+
+def alg_bytes(N, T, S, A, n_params=11_326_995):
+    """Algorithmic HBM bytes of one plan step: bf16 weights once + window + eps + outputs."""
+    return 2 * n_params + 4 * T * (S + A + 2) + 4 * N * T * A + 4 * N + 4 * N * A
+
+
+def cpu_baseline(dims, cfg_kw, hist, rtg):
+    """The oracle (fp32 PyTorch-CPU restatement of the reference path) timed on this host's cores."""
+    from m3pc_amd import synth
+    from oracle import mtm_oracle as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = min(avail, 64)  # MKL stops scaling on these GEMM shapes well before 64 threads
+    torch.set_num_threads(cores)
+    sd = synth.make_state_dict(dims, 0)
+    stats = O.make_stats(synth.make_tokenizer_stats(dims, 0))
+    N = cfg_kw["action_samples"]
+    n_s = min(N, 256)  # bounded sample: a 256-candidate plan step, scaled to the N-candidate unit
+    cfg = O.PlanCfg(dims.traj_length, cfg_kw["horizon"], n_s, 0.99, 0.01, 0.6)
+    win, h = O.assemble_window(cfg, hist, 500, rtg)
+    eps = synth.make_eps(N, dims, 1)[:n_s]
+    small = O.PlanCfg(dims.traj_length, cfg_kw["horizon"], 32, 0.99, 0.01, 0.6)
+    O.guiding(sd, stats, small, win, h, 0.6, eps[:32], "rtg")  # warm-up (thread pools, allocator)
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 1 or (time.perf_counter() - t0 < 10.0 and reps < 8):
+        O.guiding(sd, stats, cfg, win, h, 0.6, eps, "rtg")
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": (n_s / float(N)) / dt, "unit": "plan-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x plan step at {n_s} of {N} candidates (rtg_guiding H={h} T={dims.traj_length}, fp32 "
+                      f"torch-CPU oracle, {cores} threads, {dt:.2f}s each), scaled by {n_s}/{N}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--candidates", type=int, default=1024, help="candidates per GPU")
+    ap.add_argument("--horizon", type=int, default=16)
+    ap.add_argument("--traj-length", type=int, default=32)
+    ap.add_argument("--rescore-topk", type=int, default=32)
+    ap.add_argument("--strong", action="store_true", help="keep the global candidate count fixed")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from m3pc_amd import capi, synth
+    from m3pc_amd.planner import HipPlanner
+    import types
+
+    S, A = synth.ENV_DIMS["hopper"]
+    T, H = args.traj_length, args.horizon
+    n_global = args.candidates if args.strong else args.candidates * world
+    dims = synth.Dims(S, A, T)
+    cfg = types.SimpleNamespace(traj_length=T, action_samples=n_global, horizon=H, discount=0.99, temperature=0.01,
+                                lmbda=0.6, plan_guidance="rtg_guiding")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1)  # same seed on every rank: identical eps and multinomial draws
+    planner = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None,
+                         precision=args.precision, rescore_topk=args.rescore_topk, device=local_rank, generator=gen)
+    hist = synth.make_history(dims, 0)
+    hist["path_length"] = 500
+    states, actions, rewards, h, rtg = planner.assemble_window(hist, rtg=3.0)
+    assert h == H
+
+    def step():
+        return planner._guide(capi.MODE_RTG, states, actions, rewards, rtg, h, 0.6)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    units = args.steps * (n_global / float(args.candidates))
+    value = units / elapsed
+
+    # roofline of the dominant kernel class (the MFMA GEMM): a second, instrumented pass of the same K
+    # steps with hipEvents around every GEMM launch on the launch stream (events perturb the step time,
+    # so they are kept out of the timed region above).
+    n_local = mdist_count(n_global, rank, world)
+    planner.handle.profile_enable(True)
+    planner.handle.profile_read(reset=True)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    launches, gemm_ms, gemm_flops = planner.handle.profile_read(reset=True)
+    planner.handle.profile_enable(False)
+    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    peak = MFMA_PEAK_TFLOPS[args.precision]
+    f_step = alg_flops(n_local, T, H, S, A)
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
+                "kernel": "m3pc::gemm_kernel (all MFMA GEMM launches of a step)",
+                "flops_per_launch": gemm_flops / max(launches, 1), "avg_launch_us": 1e3 * gemm_ms / max(launches, 1),
+                "launches_per_step": launches / args.steps, "gemm_ms_per_step": gemm_ms / args.steps,
+                "step_alg_tflop": round(f_step / 1e12, 4),
+                "step_mfma_frac": round(f_step / (elapsed / args.steps) / 1e12 / peak, 4),
+                "step_alg_bytes": alg_bytes(n_local, T, S, A),
+                "step_hbm_frac_alg": round(alg_bytes(n_local, T, S, A) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
+
+    if rank == 0:
+        out = {"metric": "MPC plan-steps/sec (N=1024, H=16, hopper-medium-v2)", "value": round(value, 2),
+               "unit": "plan-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+               "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.precision,
+               "data": "synthetic",
+               "config": {"workload": f"hopper-medium-v2 shapes (S={S},A={A}) rtg_guiding N={args.candidates}/GPU H={H} "
+                                      f"T={T} {args.precision} candidate pass + fp32 policy pass + fp32 top-{args.rescore_topk} re-score",
+                          "candidates_per_gpu": n_local, "global_candidates": n_global, "horizon": H, "traj_length": T,
+                          "parallelism": f"candidate-shard x{world}"},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dims, dict(horizon=H, action_samples=args.candidates), hist, 3.0)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def mdist_count(n, rank, world):
+    from m3pc_amd.dist import shard_range
+    return shard_range(n, rank, world)[1]
+
+
+if __name__ == "__main__":
+    main()

@@ -144,12 +144,37 @@ int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* args, const float* stat
                    const float* rewards, const float* eps, float* loc, float* std, float* sample_actions,
                    float* expect_return, float* pred_rewards, float* pred_boot, void* stream);
 
-/* The cross-candidate tail (learner.py:318-323) over all N candidates (after an all-gather when
- * sharded): p = softmax(temperature * (E - max E)), eval_action = sum p*a0 / sum p, argmax E.
+/* fp32 re-scoring of an arbitrary subset of the candidates of the LAST m3pc_plan_step on this handle
+ * (its policy-pass loc/std are reused; same window, eps and args as that call, args->precision ignored).
+ * Used after a bf16 candidate pass to make the reported arg-max independent of bf16 rounding: the same
+ * learner.py:288-316 arithmetic, restricted to rows `index`.
+ *   index           device (n,) int32 candidate ids in [0, n_total)
+ *   sample_actions  device out (n,h,A), optional
+ *   expect_return   device out (n,) */
+int m3pc_rescore(m3pc_handle* h, const m3pc_plan_args* args, const float* states, const float* actions,
+                 const float* rewards, const float* eps, const int* index, int n, float* sample_actions,
+                 float* expect_return, void* stream);
+
+/* m3pc_rescore of the k best entries of a full score vector, written back in place:
+ *   expect_return  device in/out (n_total,): scores of ALL candidates (after the all-gather when
+ *                  sharded); its k largest entries are replaced by their fp32 re-scores
+ *   topk_index     device out (k,) int32, optional: the re-scored candidate ids, best first */
+int m3pc_rescore_topk(m3pc_handle* h, const m3pc_plan_args* args, const float* states, const float* actions,
+                      const float* rewards, const float* eps, float* expect_return, int k, int* topk_index,
+                      void* stream);
+
+/* The cross-candidate tail (learner.py:318-325) over all N candidates (after an all-gather when
+ * sharded): p = softmax(temperature * (E - max E)), eval_action = sum p*a0 / sum p, argmax E, and the
+ * multinomial draw sample_action = a0[multinomial(p, 1)].
  *   a0 device (n, A) rows with stride a0_stride floats (sample_actions[:,0,:] => stride h*A)
- *   p device out (n,), eval_action device out (A,), argmax device out (1,) -- each optional */
+ *   expo      device (n,) Exp(1) variates, optional.  torch.multinomial(p, 1) is argmax(p / q) with
+ *             q = empty_like(p).exponential_(1) drawn from the caller's generator; passing that q
+ *             here reproduces torch's draw without its dozen tiny launches.
+ *   p device out (n,), eval_action device out (A,), argmax device out (1,),
+ *   sample_idx device out (1,), sample_action device out (A,) -- each optional */
 int m3pc_select(m3pc_handle* h, const float* expect_return, const float* a0, long long a0_stride, int n,
-                float temperature, float* p, float* eval_action, int* argmax, void* stream);
+                float temperature, const float* expo, float* p, float* eval_action, int* argmax,
+                int* sample_idx, float* sample_action, void* stream);
 
 /* kernel-level timing of the last plan_step for bench.py / profiling: when enabled the library
  * brackets the dominant kernel class (the MFMA GEMMs) with hipEvents on `stream`. */

@@ -25,7 +25,8 @@ ABI_VERSION = 1
 EXPORTS = (
     "m3pc_last_error", "m3pc_abi_version", "m3pc_create", "m3pc_destroy", "m3pc_load_weights",
     "m3pc_set_tokenizer", "m3pc_set_critic", "m3pc_tokenize", "m3pc_detokenize", "m3pc_forward",
-    "m3pc_plan_step", "m3pc_select", "m3pc_profile_enable", "m3pc_profile_read",
+    "m3pc_plan_step", "m3pc_rescore", "m3pc_rescore_topk", "m3pc_select", "m3pc_profile_enable",
+    "m3pc_profile_read",
 )
 
 
@@ -76,7 +77,9 @@ def load_library(path: Optional[str] = None):
         "m3pc_detokenize": [vp, i, vp, vp, ll, vp],
         "m3pc_forward": [vp, i, C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp, vp, i, vp],
         "m3pc_plan_step": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-        "m3pc_select": [vp, vp, vp, ll, i, f, vp, vp, vp, vp],
+        "m3pc_rescore": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, i, vp, vp, vp],
+        "m3pc_rescore_topk": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, i, vp, vp],
+        "m3pc_select": [vp, vp, vp, ll, i, f, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_profile_enable": [vp, i],
         "m3pc_profile_read": [vp, C.POINTER(ll), C.POINTER(d), C.POINTER(d), i],
     }
@@ -230,17 +233,54 @@ class Handle:
             res["pred_rewards"], res["pred_boot"] = pr, pb
         return res
 
-    def select(self, expect_return: torch.Tensor, a0: torch.Tensor, temperature: float):
-        """a0: (N, A) view (may be a strided slice sample_actions[:, 0])."""
+    def rescore(self, mode: int, states, actions, rewards, eps, index: torch.Tensor, horizon: int, rtg: float,
+                lmbda: float, discount: float, n_total: int):
+        """fp32 scores (and candidates) of rows ``index`` (int32 cuda) of the last plan_step."""
+        n = index.numel()
+        dev = self.device
+        acts = torch.empty((n, horizon, self.A), dtype=torch.float32, device=dev)
+        er = torch.empty((n,), dtype=torch.float32, device=dev)
+        args = PlanArgs(mode, PREC_FP32, horizon, n_total, 0, n, lmbda, discount, rtg)
+        ins = [t.to(torch.float32).contiguous() for t in (states, actions, rewards, eps)]
+        idx = index.to(torch.int32).contiguous()
+        check(self.lib.m3pc_rescore(self._h, C.byref(args), _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), _ptr(ins[3]),
+                                    _ptr(idx), n, _ptr(acts), _ptr(er), _stream(dev)))
+        return er, acts
+
+    def rescore_topk(self, mode: int, states, actions, rewards, eps, expect_return: torch.Tensor, k: int,
+                     horizon: int, rtg: float, lmbda: float, discount: float):
+        """Replace the k largest entries of ``expect_return`` (all N candidates, contiguous fp32 cuda) by
+        their fp32 re-scores, in place.  Returns the re-scored candidate ids (k,) int32."""
+        n = expect_return.numel()
+        assert expect_return.is_contiguous() and expect_return.dtype == torch.float32
+        top = torch.empty((k,), dtype=torch.int32, device=self.device)
+        args = PlanArgs(mode, PREC_FP32, horizon, n, 0, n, lmbda, discount, rtg)
+        ins = [t.to(torch.float32).contiguous() for t in (states, actions, rewards, eps)]
+        check(self.lib.m3pc_rescore_topk(self._h, C.byref(args), _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]),
+                                         _ptr(ins[3]), _ptr(expect_return), k, _ptr(top), _stream(self.device)))
+        return top
+
+    def select(self, expect_return: torch.Tensor, a0: torch.Tensor, temperature: float,
+               expo: Optional[torch.Tensor] = None):
+        """a0: (N, A) view (may be a strided slice sample_actions[:, 0]).  Returns (p, eval_action, argmax)
+        and, when ``expo`` (N Exp(1) variates) is given, also (sample_idx, sample_action (1, A))."""
         n = expect_return.numel()
         assert a0.shape[0] == n and a0.stride(-1) == 1
         dev = self.device
         p = torch.empty((n,), dtype=torch.float32, device=dev)
         ev = torch.empty((self.A,), dtype=torch.float32, device=dev)
         am = torch.empty((1,), dtype=torch.int32, device=dev)
+        si = sa = None
+        if expo is not None:
+            assert expo.numel() == n and expo.dtype == torch.float32 and expo.is_contiguous()
+            si = torch.empty((1,), dtype=torch.int32, device=dev)
+            sa = torch.empty((1, self.A), dtype=torch.float32, device=dev)
         check(self.lib.m3pc_select(self._h, _ptr(expect_return.contiguous()), _ptr(a0), a0.stride(0), n,
-                                   float(temperature), _ptr(p), _ptr(ev), _ptr(am), _stream(dev)))
-        return p, ev, am
+                                   float(temperature), _ptr(expo), _ptr(p), _ptr(ev), _ptr(am), _ptr(si), _ptr(sa),
+                                   _stream(dev)))
+        if expo is None:
+            return p, ev, am
+        return p, ev, am, si, sa
 
     # -- profiling ---------------------------------------------------------------------------------
     def profile_enable(self, on: bool):

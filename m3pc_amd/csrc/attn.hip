@@ -234,7 +234,7 @@ static void launch_t(const AttnP& p, hipStream_t st) {
 void launch_attention(const AttnP& p, int dtype, hipStream_t st) {
     if (p.batch <= 0 || p.Lq <= 0) return;
     if (dtype == DT_BF16)
-        launch_t<bf16_t>(p, st);
+        launch_attention_bf16(p, st);  // native bf16 MFMA kernel (attn_bf16.hip)
     else
         launch_t<float>(p, st);
 }

@@ -1,0 +1,215 @@
+// bf16 attention on v_mfma_f32_32x32x16_bf16 (gfx950).  Same structure as attn.hip (scores transposed,
+// S^T = K Q^T, whole key range in accumulators, softmax lane-local), with bf16 operands end to end:
+//   * Q, K chunks and V chunks are staged to LDS as bf16 rows ([row][hd], 16-byte row pad);
+//   * S^T tiles: A = K rows (ds_read_b128 fragments), B = Q rows (kept in registers for all chunks);
+//   * P = softmax(S) stays in the accumulator registers, is normalised, converted to bf16 in place and
+//     becomes the A operand of O = P V (accumulator rows = k index; k order inside a 16-step is
+//     16s + 8(e>>2) + 4h + (e&3));
+//   * the matching B operand V[key][dim] needs, per lane (fixed dim), 4 consecutive keys: exactly what
+//     ds_read_b64_tr_b16 delivers from the row-major V image -- two transposed reads per fragment,
+//     no transposing stores.
+#include "kernels.h"
+
+namespace m3pc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <int HDT, int NCH>
+__global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
+    constexpr int HD = HDT * 32;
+    constexpr int ROWB = HD * 2 + 16;  // LDS row stride in bytes
+    constexpr int NS = HD / 16;        // MFMA k-steps over the head dim
+    constexpr int CPR = HD / 8;        // 16-byte chunks per row
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nthr = blockDim.x, nw = nthr >> 6;
+    const int b = blockIdx.x, head = blockIdx.y, qg = blockIdx.z;
+    const int q0 = qg * 128;
+    const int Lk = p.L1 + p.L2;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const bf16_t* Qb = (const bf16_t*)p.Q + b * p.q_bstride + head * HD;
+    const bf16_t* K1 = (const bf16_t*)p.K1 + b * p.kv1_bstride + head * HD;
+    const bf16_t* V1 = (const bf16_t*)p.V1 + b * p.kv1_bstride + head * HD;
+    const bf16_t* K2 = p.K2 ? (const bf16_t*)p.K2 + head * HD : nullptr;
+    const bf16_t* V2 = p.V2 ? (const bf16_t*)p.V2 + head * HD : nullptr;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    // ---- Q: stage nw*32 rows, keep this wave's B fragments in registers
+    for (int c = tid; c < nw * 32 * CPR; c += nthr) {
+        const int r = c / CPR, kc = c % CPR;
+        u32x4 v = zero4;
+        if (q0 + r < p.Lq) v = *(const u32x4*)(Qb + (long long)(q0 + r) * p.ldq + kc * 8);
+        *(u32x4*)(lds + r * ROWB + kc * 16) = v;
+    }
+    __syncthreads();
+    u32x4 qf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = *(const u32x4*)(lds + (wid * 32 + l31) * ROWB + 32 * s + 16 * lh);
+    __syncthreads();
+
+    f32x16 sacc[NCH][2];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[c][jt][e] = 0.f;
+
+    // ---- S^T = K Q^T, 64 keys per staged chunk
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int j0 = c * 64;
+        if (j0 < Lk) {
+            for (int x = tid; x < 64 * CPR; x += nthr) {
+                const int r = x / CPR, kc = x % CPR, j = j0 + r;
+                u32x4 v = zero4;
+                if (j < p.L1)
+                    v = *(const u32x4*)(K1 + (long long)j * p.ldkv1 + kc * 8);
+                else if (j < Lk)
+                    v = *(const u32x4*)(K2 + (long long)(j - p.L1) * p.ldkv2 + kc * 8);
+                *(u32x4*)(lds + r * ROWB + kc * 16) = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                if (j0 + jt * 32 < Lk) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const u32x4 kf = *(const u32x4*)(lds + (jt * 32 + l31) * ROWB + 32 * s + 16 * lh);
+                        sacc[c][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[s]), sacc[c][jt], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- softmax over keys (register index + lane half) for the lane's query
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int j = c * 64 + jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const float v = (j < Lk) ? sacc[c][jt][e] * p.scale : -INFINITY;
+                sacc[c][jt][e] = v;
+                m = fmaxf(m, v);
+            }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float v = __builtin_amdgcn_exp2f((sacc[c][jt][e] - m) * 1.44269504088896340736f);
+                sacc[c][jt][e] = v;
+                l += v;
+            }
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+
+    // ---- O = P V
+    f32x16 oacc[HDT];
+#pragma unroll
+    for (int d = 0; d < HDT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+    // transposed-read addressing: 16-lane group g reads the 4-key x 16-dim block at dims (g&1)*16..+15;
+    // lane 4q+p of the group supplies row q, dims 4p..4p+3
+    const int gi = lane & 15;
+    const int tr_off = (gi >> 2) * ROWB + (((lane >> 4) & 1) * 16 + (gi & 3) * 4) * 2;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int j0 = c * 64;
+        if (j0 < Lk) {
+            for (int x = tid; x < 64 * CPR; x += nthr) {
+                const int r = x / CPR, kc = x % CPR, j = j0 + r;
+                u32x4 v = zero4;
+                if (j < p.L1)
+                    v = *(const u32x4*)(V1 + (long long)j * p.ldkv1 + kc * 8);
+                else if (j < Lk)
+                    v = *(const u32x4*)(V2 + (long long)(j - p.L1) * p.ldkv2 + kc * 8);
+                *(u32x4*)(lds + r * ROWB + kc * 16) = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                if (j0 + jt * 32 < Lk) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        bf16x8 pa;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pa[e] = (bf16_t)(sacc[c][jt][8 * s2 + e] * inv);
+                        const int kb = jt * 32 + 16 * s2 + 4 * lh;  // key rows kb..kb+3 and kb+8..kb+11
+#pragma unroll
+                        for (int d = 0; d < HDT; ++d) {
+                            const char* base = lds + kb * ROWB + d * 64 + tr_off;
+                            const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (s16x4 __attribute__((address_space(3)))*)(base));
+                            const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (s16x4 __attribute__((address_space(3)))*)(base + 8 * ROWB));
+                            const s16x8 vb = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8, vb), oacc[d], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- store O[i][dim]: row i = (e&3) + 8(e>>2) + 4h of this wave's 32 queries, dim = d*32 + l31
+    bf16_t* Ob = (bf16_t*)p.O + b * p.o_bstride + head * HD;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = q0 + wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (i < p.Lq) {
+#pragma unroll
+            for (int d = 0; d < HDT; ++d) Ob[(long long)i * p.ldo + d * 32 + l31] = (bf16_t)oacc[d][e];
+        }
+    }
+}
+
+template <int HDT, int NCH>
+static void launch_nch(const AttnP& p, dim3 grid, dim3 block, size_t smem, hipStream_t st) {
+    hipLaunchKernelGGL((attn_bf16_kernel<HDT, NCH>), grid, block, smem, st, p);
+}
+
+template <int HDT>
+static void launch_hd(const AttnP& p, hipStream_t st) {
+    const int Lk = p.L1 + p.L2;
+    const int qgroups = (p.Lq + 127) / 128;
+    const int nw = p.Lq >= 128 ? 4 : (p.Lq + 31) / 32;
+    const int rows = nw * 32 > 64 ? nw * 32 : 64;
+    const size_t smem = (size_t)rows * (HDT * 64 + 16);
+    dim3 grid(p.batch, p.n_head, qgroups), block(nw * 64);
+    if (Lk <= 64)
+        launch_nch<HDT, 1>(p, grid, block, smem, st);
+    else if (Lk <= 128)
+        launch_nch<HDT, 2>(p, grid, block, smem, st);
+    else
+        launch_nch<HDT, 4>(p, grid, block, smem, st);
+}
+
+void launch_attention_bf16(const AttnP& p, hipStream_t st) {
+    switch (p.hd) {
+        case 32: launch_hd<1>(p, st); break;
+        case 64: launch_hd<2>(p, st); break;
+        case 128: launch_hd<4>(p, st); break;
+        default: break;  // validated by the caller
+    }
+}
+
+}  // namespace m3pc

@@ -209,11 +209,12 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleP p) {
             v = p.hist_actions[t * p.A + a];
         } else {
             const int ta = t * p.A + a;
+            const long long src = p.index ? (long long)p.index[n] : p.n_begin + n;
             if (p.mode == 0) {
-                const float e = p.eps[((p.n_begin + n) * p.T + t) * p.A + a];
+                const float e = p.eps[(src * p.T + t) * p.A + a];
                 v = tanhf(__fadd_rn(__fmul_rn(e, p.sd[ta]), p.loc[ta]));
             } else {
-                const float e = p.eps[((p.n_begin + n) * p.h + (t - p.idx)) * p.A + a];
+                const float e = p.eps[(src * p.h + (t - p.idx)) * p.A + a];
                 v = __fadd_rn(tanhf(p.loc[ta]), __fmul_rn(e, 0.09f));
                 v = fminf(fmaxf(v, -0.99999f), 0.99999f);
             }
@@ -331,104 +332,6 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreP p) {
 void launch_score(const ScoreP& p, hipStream_t st) {
     if (p.n <= 0) return;
     hipLaunchKernelGGL(score_kernel, dim3((p.n + 255) / 256), dim3(256), 0, st, p);
-}
-
-// ------------------------------------------------------------------------------------------ select
-// One 1024-thread block: max / argmax, sum exp, p, weighted mean of the first actions.
-__global__ __launch_bounds__(1024) void select_kernel(SelectP p) {
-    __shared__ float smax[16];
-    __shared__ int sarg[16];
-    __shared__ float ssum[16];
-    __shared__ float bc[2];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    float m = -INFINITY;
-    int am = 0x7fffffff;
-    for (int i = tid; i < p.n; i += 1024) {
-        const float v = p.er[i];
-        if (v > m || (v == m && i < am)) {
-            m = v;
-            am = i;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float om = __shfl_xor(m, o);
-        const int oa = __shfl_xor(am, o);
-        if (om > m || (om == m && oa < am)) {
-            m = om;
-            am = oa;
-        }
-    }
-    if (lane == 0) {
-        smax[wid] = m;
-        sarg[wid] = am;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float mm = smax[0];
-        int aa = sarg[0];
-        for (int w = 1; w < 16; ++w)
-            if (smax[w] > mm || (smax[w] == mm && sarg[w] < aa)) {
-                mm = smax[w];
-                aa = sarg[w];
-            }
-        bc[0] = mm;
-        if (p.argmax) *p.argmax = aa;
-    }
-    __syncthreads();
-    const float mx = bc[0];
-    float s = 0.f;
-    for (int i = tid; i < p.n; i += 1024) s += expf(__fmul_rn(__fsub_rn(p.er[i], mx), p.temperature));
-    s = wave_sum(s);
-    if (lane == 0) ssum[wid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        float t = 0.f;
-        for (int w = 0; w < 16; ++w) t += ssum[w];
-        bc[1] = t;
-    }
-    __syncthreads();
-    const float tot = bc[1];
-    // p and sum p
-    float ps = 0.f;
-    for (int i = tid; i < p.n; i += 1024) {
-        const float pi = expf(__fmul_rn(__fsub_rn(p.er[i], mx), p.temperature)) / tot;
-        if (p.p) p.p[i] = pi;
-        ps += pi;
-    }
-    ps = wave_sum(ps);
-    __syncthreads();
-    if (lane == 0) ssum[wid] = ps;
-    __syncthreads();
-    if (tid == 0) {
-        float t = 0.f;
-        for (int w = 0; w < 16; ++w) t += ssum[w];
-        bc[1] = t;
-    }
-    __syncthreads();
-    const float psum = bc[1];
-    if (p.eval_action) {
-        for (int a = 0; a < p.A; ++a) {
-            float acc = 0.f;
-            for (int i = tid; i < p.n; i += 1024) {
-                const float pi = expf(__fmul_rn(__fsub_rn(p.er[i], mx), p.temperature)) / tot;
-                acc = fmaf(p.a0[(long long)i * p.a0_stride + a], pi, acc);
-            }
-            acc = wave_sum(acc);
-            __syncthreads();
-            if (lane == 0) ssum[wid] = acc;
-            __syncthreads();
-            if (tid == 0) {
-                float t = 0.f;
-                for (int w = 0; w < 16; ++w) t += ssum[w];
-                p.eval_action[a] = t / psum;
-            }
-        }
-    }
-}
-void launch_select(const SelectP& p, hipStream_t st) {
-    if (p.n <= 0) return;
-    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, st, p);
 }
 
 // ------------------------------------------------------------------------------------------ tokenizer

@@ -8,6 +8,9 @@
 //         v_mfma_f32_32x32x2_f32 (e = 0..3), each pairing k = 8s+e (h=0) with 8s+4+e (h=1).  A and B use
 //         the same permutation, so the dot product is complete and each product is an exact fp32 fma.
 // LDS rows are padded to 144 B: the 16-lane groups of ds_read_b128 then hit 16 distinct 4-bank slots.
+//
+// Pipeline: two LDS buffers; tile k+1 travels HBM/L2 -> registers while tile k is multiplied, and is
+// written to the other buffer after the MFMAs: one barrier per k-tile.
 #include "kernels.h"
 
 namespace m3pc {
@@ -15,23 +18,42 @@ namespace m3pc {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define LDS_ROW 144
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// epilogue flags (template parameter)
+enum { EPI_GELU = 1, EPI_RES = 2, EPI_ROWTAB = 4, EPI_F32OUT = 8, EPI_SPLITK = 16 };
+
+// exact-erf GELU.  fp32 path: libm erff.  bf16 path: Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7 on erf,
+// far below bf16 resolution) -- 2 transcendentals instead of a ~35-instruction erff, which would
+// otherwise make the FFN epilogue VALU-bound beside the matrix pipe.
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float ax = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
+    const float erf_abs = fmaf(-p, e, 1.0f);
+    const float hx = 0.5f * x;
+    return fmaf(fabsf(hx), erf_abs, hx);  // 0.5x(1+erf(x/sqrt2)) with erf odd
+}
 
 __device__ __forceinline__ int map_row(const RowMap& m, int r) {
     if (m.rpg == 0) return r;
     return (r / m.rpg) * m.gstride + (r % m.rpg) + m.off;
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
-    constexpr int TM = BM / 64, TN = BN / 64;         // 32x32 MFMA tiles per wave (2x2 waves)
+    constexpr int TM = BM / 64, TN = BN / 64;                // 32x32 MFMA tiles per wave (2x2 waves)
     constexpr int A_CH = BM * 8 / 256, W_CH = BN * 8 / 256;  // 16-byte chunks per thread per k-tile
-    __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * LDS_ROW];
-    char* sA = smem;
-    char* sW = smem + BM * LDS_ROW;
+    constexpr int BUF = (BM + BN) * LDS_ROW;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -53,8 +75,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     const char* Wb = (const char*)p.W;
     const long long lda_b = (long long)p.lda * sizeof(T), ldw_b = (long long)p.ldw * sizeof(T);
     const int nkt = (int)((long long)p.K * sizeof(T) / 128);
+    int kt0 = 0, kt1 = nkt;  // split-K: blockIdx.y owns a contiguous run of k-tiles, raw partials go to p.ws
+    if constexpr (EPI & EPI_SPLITK) {
+        kt0 = (int)((long long)nkt * blockIdx.y / gridDim.y);
+        kt1 = (int)((long long)nkt * (blockIdx.y + 1) / gridDim.y);
+    }
 
-    // per-thread global source rows (fixed over the K loop)
+    // per-thread global sources (fixed rows, advancing 128 B per k-tile) and LDS destinations
     const char* a_src[A_CH];
     int a_dst[A_CH];
 #pragma unroll
@@ -62,7 +89,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         const int c = tid + i * 256, r = c >> 3, kc = c & 7;
         int gr = row0 + r;
         if (gr >= p.M) gr = p.M - 1;
-        a_src[i] = Ab + (long long)map_row(p.amap, gr) * lda_b + kc * 16;
+        a_src[i] = Ab + (long long)map_row(p.amap, gr) * lda_b + kc * 16 + (long long)kt0 * 128;
         a_dst[i] = r * LDS_ROW + kc * 16;
     }
     const char* w_src[W_CH];
@@ -70,8 +97,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
     for (int i = 0; i < W_CH; ++i) {
         const int c = tid + i * 256, r = c >> 3, kc = c & 7;
-        w_src[i] = Wb + (long long)(col0 + r) * ldw_b + kc * 16;
-        w_dst[i] = r * LDS_ROW + kc * 16;
+        w_src[i] = Wb + (long long)(col0 + r) * ldw_b + kc * 16 + (long long)kt0 * 128;
+        w_dst[i] = BM * LDS_ROW + r * LDS_ROW + kc * 16;
     }
 
     f32x16 acc[TM][TN];
@@ -82,35 +109,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    uint4 ra[A_CH], rw[W_CH];
+    u32x4 ra[A_CH], rw[W_CH];
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) ra[i] = *(const uint4*)(a_src[i]);
+    for (int i = 0; i < A_CH; ++i) ra[i] = *(const u32x4*)(a_src[i]);
 #pragma unroll
-    for (int i = 0; i < W_CH; ++i) rw[i] = *(const uint4*)(w_src[i]);
+    for (int i = 0; i < W_CH; ++i) rw[i] = *(const u32x4*)(w_src[i]);
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) *(u32x4*)(smem + a_dst[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < W_CH; ++i) *(u32x4*)(smem + w_dst[i]) = rw[i];
+    __syncthreads();
 
     const int fragA = (wr * (BM / 2) + (lane & 31)) * LDS_ROW + 16 * (lane >> 5);
-    const int fragW = (wc * (BN / 2) + (lane & 31)) * LDS_ROW + 16 * (lane >> 5);
+    const int fragW = BM * LDS_ROW + (wc * (BN / 2) + (lane & 31)) * LDS_ROW + 16 * (lane >> 5);
 
-    for (int kt = 0; kt < nkt; ++kt) {
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) *(uint4*)(sA + a_dst[i]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < W_CH; ++i) *(uint4*)(sW + w_dst[i]) = rw[i];
-        __syncthreads();
-        if (kt + 1 < nkt) {
+    const int nloc = kt1 - kt0;
+    for (int kt = 0; kt < nloc; ++kt) {
+        const char* cur = smem + (kt & 1) * BUF;
+        char* nxt = smem + ((kt + 1) & 1) * BUF;
+        const bool more = kt + 1 < nloc;
+        if (more) {
             const long long ko = (long long)(kt + 1) * 128;
 #pragma unroll
-            for (int i = 0; i < A_CH; ++i) ra[i] = *(const uint4*)(a_src[i] + ko);
+            for (int i = 0; i < A_CH; ++i) ra[i] = *(const u32x4*)(a_src[i] + ko);
 #pragma unroll
-            for (int i = 0; i < W_CH; ++i) rw[i] = *(const uint4*)(w_src[i] + ko);
+            for (int i = 0; i < W_CH; ++i) rw[i] = *(const u32x4*)(w_src[i] + ko);
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            uint4 fa[TM], fw[TN];
+            u32x4 fa[TM], fw[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *(const uint4*)(sA + fragA + i * 32 * LDS_ROW + 32 * s);
+            for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4*)(cur + fragA + i * 32 * LDS_ROW + 32 * s);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fw[j] = *(const uint4*)(sW + fragW + j * 32 * LDS_ROW + 32 * s);
+            for (int j = 0; j < TN; ++j) fw[j] = *(const u32x4*)(cur + fragW + j * 32 * LDS_ROW + 32 * s);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -127,49 +158,133 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                     }
                 }
         }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) *(u32x4*)(nxt + a_dst[i]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < W_CH; ++i) *(u32x4*)(nxt + w_dst[i]) = rw[i];
+        }
         __syncthreads();
     }
 
     // epilogue.  acc[i][j][reg]: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31 of the 32x32 tile
+    if constexpr (EPI & EPI_SPLITK) {
+        float* slab = p.ws + (long long)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = row0 + wr * (BM / 2) + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (r < p.M) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        slab[(long long)r * p.N + col0 + wc * (BN / 2) + j * 32 + (lane & 31)] = acc[i][j][reg];
+                }
+            }
+        return;
+    }
+    float bj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bj[j] = p.bias ? p.bias[col0 + wc * (BN / 2) + j * 32 + (lane & 31)] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int r = row0 + wr * (BM / 2) + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-            if (r >= p.M) continue;
-            const long long pr = map_row(p.cmap, r);
-            const float* rt = p.rowtab ? p.rowtab + (long long)(r % p.rt_mod) * p.rt_ld : nullptr;
+            if (r < p.M) {
+                const long long pr = map_row(p.cmap, r);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int c = col0 + wc * (BN / 2) + j * 32 + (lane & 31);
-                float v = acc[i][j][reg];
-                if (p.bias) v += p.bias[c];
-                if (rt) v += rt[c];
-                if (p.gelu) v = gelu_erf(v);
-                if (p.res) v += p.res[pr * p.ldr + c];
-                if (p.Cf) p.Cf[pr * p.ldc + c] = v;
-                if (p.Cb) p.Cb[pr * p.ldc + c] = (bf16_t)v;
+                for (int j = 0; j < TN; ++j) {
+                    const int c = col0 + wc * (BN / 2) + j * 32 + (lane & 31);
+                    float v = acc[i][j][reg] + bj[j];
+                    if constexpr (EPI & EPI_ROWTAB) v += p.rowtab[(long long)(r % p.rt_mod) * p.rt_ld + c];
+                    if constexpr (EPI & EPI_GELU) v = sizeof(T) == 2 ? gelu_fast(v) : gelu_exact(v);
+                    if constexpr (EPI & EPI_RES) v += p.res[pr * p.ldr + c];
+                    if constexpr ((EPI & EPI_F32OUT) || sizeof(T) == 4)
+                        p.Cf[pr * p.ldc + c] = v;
+                    else
+                        p.Cb[pr * p.ldc + c] = (bf16_t)v;
+                }
             }
         }
     }
 }
 
+// second half of a split-K GEMM: sum the S raw slabs in a fixed order (deterministic) and apply the epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int S, int exact_gelu) {
+    const long long n = (long long)p.M * p.N;
+    for (long long x = blockIdx.x * 256LL + threadIdx.x; x < n; x += (long long)gridDim.x * 256) {
+        const int r = (int)(x / p.N), c = (int)(x % p.N);
+        float v = 0.f;
+        for (int s = 0; s < S; ++s) v += p.ws[(long long)s * n + x];
+        if (p.bias) v += p.bias[c];
+        if (p.rowtab) v += p.rowtab[(long long)(r % p.rt_mod) * p.rt_ld + c];
+        if (p.gelu) v = exact_gelu ? gelu_exact(v) : gelu_fast(v);
+        const long long pr = map_row(p.cmap, r);
+        if (p.res) v += p.res[pr * p.ldr + c];
+        if (p.Cf) p.Cf[pr * p.ldc + c] = v;
+        if (p.Cb) p.Cb[pr * p.ldc + c] = (bf16_t)v;
+    }
+}
+
+template <typename T, int BM, int BN, int EPI>
+static void launch_cfg(const GemmP& p, hipStream_t st) {
+    const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI>), dim3(grid), dim3(256), 0, st, p);
+}
+
+template <typename T, int EPI>
+static void launch_epi(const GemmP& p, hipStream_t st) {
+    // 128x128 tiles only when they still fill the chip twice over; otherwise 64x64 tiles (4x the blocks):
+    // the batch-1 policy pass and the top-k re-score are latency-bound on few rows.
+    const long long big_tiles = (long long)((p.M + 127) / 128) * (p.N / 128);
+    if ((p.N % 128) != 0 || big_tiles < 512) {
+        // few tiles and a long serial K chain per tile (fp32: 4 f32-MFMAs per 16 bytes of K): split K
+        // over blocks into raw slabs, reduce + epilogue in a second small kernel.
+        const long long tiles = (long long)((p.M + 63) / 64) * (p.N / 64);
+        const int nkt = (int)((long long)p.K * sizeof(T) / 128);
+        int S = 1;
+        if (sizeof(T) == 4 && p.ws && tiles < 384) {
+            S = (int)((767 + tiles) / tiles);
+            if (S > nkt / 2) S = nkt / 2;
+            if (S > 16) S = 16;
+            while (S > 1 && (long long)S * p.M * p.N * 4 > p.ws_bytes) --S;
+        }
+        if (S > 1) {
+            hipLaunchKernelGGL((gemm_kernel<T, 64, 64, EPI_SPLITK>), dim3((unsigned)tiles, S), dim3(256), 0, st, p);
+            const long long n = (long long)p.M * p.N;
+            const int g = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, p, S, (int)(sizeof(T) == 4));
+        } else {
+            launch_cfg<T, 64, 64, EPI>(p, st);
+        }
+    } else {
+        launch_cfg<T, 128, 128, EPI>(p, st);
+    }
+}
+
 template <typename T>
 static void launch_t(const GemmP& p, hipStream_t st) {
-    const bool small_n = (p.N % 128) != 0;
-    const bool small_m = p.M <= 512;
-    if (small_n || small_m) {
-        // more, smaller tiles: fills the chip for the batch-1 policy pass and covers N % 128 != 0
-        const int grid = ((p.M + 63) / 64) * (p.N / 64);
-        hipLaunchKernelGGL((gemm_kernel<T, 64, 64>), dim3(grid), dim3(256), 0, st, p);
-    } else {
-        const int grid = ((p.M + 127) / 128) * (p.N / 128);
-        hipLaunchKernelGGL((gemm_kernel<T, 128, 128>), dim3(grid), dim3(256), 0, st, p);
+    const bool f32out = sizeof(T) == 4 || p.Cf != nullptr;
+    const int epi = (p.gelu ? EPI_GELU : 0) | (p.res ? EPI_RES : 0) | (p.rowtab ? EPI_ROWTAB : 0) |
+                    (f32out && sizeof(T) == 2 ? EPI_F32OUT : 0);
+    switch (epi) {
+        case 0: launch_epi<T, 0>(p, st); break;
+        case EPI_F32OUT: launch_epi<T, EPI_F32OUT>(p, st); break;
+        case EPI_GELU: launch_epi<T, EPI_GELU>(p, st); break;
+        case EPI_GELU | EPI_F32OUT: launch_epi<T, EPI_GELU | EPI_F32OUT>(p, st); break;
+        case EPI_RES: launch_epi<T, EPI_RES>(p, st); break;
+        case EPI_RES | EPI_F32OUT: launch_epi<T, EPI_RES | EPI_F32OUT>(p, st); break;
+        case EPI_ROWTAB: launch_epi<T, EPI_ROWTAB>(p, st); break;
+        case EPI_ROWTAB | EPI_F32OUT: launch_epi<T, EPI_ROWTAB | EPI_F32OUT>(p, st); break;
+        default: break;  // no caller combines the remaining flags
     }
 }
 
 void launch_gemm(const GemmP& p, int dtype, hipStream_t st) {
     if (p.M <= 0) return;
+    if (dtype == DT_BF16 && p.variant >= 7 && launch_gemm_ring(p, st)) return;
+    if (dtype == DT_BF16 && (p.variant == 0 || (p.variant >= 3 && p.variant < 7)) && launch_gemm_glds(p, st)) return;
     if (dtype == DT_BF16)
         launch_t<bf16_t>(p, st);
     else

@@ -1,0 +1,223 @@
+// bf16 MFMA GEMM with direct-to-LDS staging (global_load_lds_dwordx4) for the many-row GEMMs of the
+// candidate pass.  Same math and epilogue as gemm.hip; what changes is how tiles reach LDS:
+//   * no VGPR round trip and no ds_write: each wave-instruction drops 8 rows x 128 B (1 KiB) of a tile
+//     straight into LDS, lane l -> bytes [16 l, 16 l + 16) of that KiB;
+//   * LDS rows are therefore unpadded (128 B); bank conflicts are avoided by an XOR swizzle applied on the
+//     SOURCE side: LDS chunk position c of row r holds logical 16-byte chunk c ^ ((r >> 1) & 7), and the
+//     fragment reads apply the same involution.  Rows r, r+1 share a 256-byte bank row (different halves),
+//     rows two apart get different chunk slots => ds_read_b128 of 16 distinct rows is conflict-free;
+//   * two LDS buffers, tile k+1 is in flight while tile k is multiplied, one barrier per k-tile;
+//   * residual rows (out-proj / FFN2 epilogues) are prefetched into registers before the K loop, so the
+//     epilogue does not start with a dependent HBM round trip.
+#include "kernels.h"
+
+namespace m3pc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+enum { EPI_GELU = 1, EPI_RES = 2, EPI_ROWTAB = 4, EPI_F32OUT = 8 };
+
+__device__ __forceinline__ float gelu_fast2(float x) {
+    const float ax = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
+    const float erf_abs = fmaf(-p, e, 1.0f);
+    const float hx = 0.5f * x;
+    return fmaf(fabsf(hx), erf_abs, hx);
+}
+
+__device__ __forceinline__ int map_row2(const RowMap& m, int r) {
+    if (m.rpg == 0) return r;
+    return (r / m.rpg) * m.gstride + (r % m.rpg) + m.off;
+}
+
+typedef const void __attribute__((address_space(1))) * gptr_t;
+typedef void __attribute__((address_space(3))) * lptr_t;
+
+template <int BM, int BN, int EPI, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
+    constexpr int NW = WM * WN;                      // waves per block, WM x WN grid of wave tiles
+    constexpr int WTM = BM / WM, WTN = BN / WN;      // wave tile
+    constexpr int TM = WTM / 32, TN = WTN / 32;      // 32x32 MFMA tiles per wave
+    constexpr int NI_A = BM / 8 / NW, NI_W = BN / 8 / NW;  // 1-KiB wave-instructions per wave per k-tile
+    constexpr int BUF = (BM + BN) * 128;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wr = wid / WN, wc = wid % WN;
+    const int ntn = p.N / BN;
+    const int ntm = (p.M + BM - 1) / BM;
+    const int nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int tm = bid / ntn, tn = bid % ntn;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const long long lda_b = (long long)p.lda * 2, ldw_b = (long long)p.ldw * 2;
+    const int nkt = p.K / 64;
+
+    // staging descriptors: wave-instruction I = wid + 4 i covers tile rows 8 I .. 8 I + 7
+    const char* a_src[NI_A];
+    const char* w_src[NI_W];
+#pragma unroll
+    for (int i = 0; i < NI_A; ++i) {
+        const int r = 8 * (wid + NW * i) + (lane >> 3);
+        const int q = (lane & 7) ^ ((r >> 1) & 7);
+        int gr = row0 + r;
+        if (gr >= p.M) gr = p.M - 1;
+        a_src[i] = (const char*)p.A + (long long)map_row2(p.amap, gr) * lda_b + q * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < NI_W; ++i) {
+        const int r = 8 * (wid + NW * i) + (lane >> 3);
+        const int q = (lane & 7) ^ ((r >> 1) & 7);
+        w_src[i] = (const char*)p.W + (long long)(col0 + r) * ldw_b + q * 16;
+    }
+    const int wave_dst = __builtin_amdgcn_readfirstlane(wid) * 1024;
+
+    auto issue = [&](int kt, int buf) {
+        char* base = smem + buf * BUF + wave_dst;
+        const long long ko = (long long)kt * 128;
+#pragma unroll
+        for (int i = 0; i < NI_A; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + ko), (lptr_t)(base + i * NW * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NI_W; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + ko), (lptr_t)(base + BM * 128 + i * NW * 1024), 16, 0, 0);
+    };
+
+    issue(0, 0);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // residual prefetch (same element order as the epilogue)
+    float rres[(EPI & EPI_RES) ? TM * 16 * TN : 1];
+    if constexpr (EPI & EPI_RES) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                int r = row0 + wr * WTM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (r >= p.M) r = p.M - 1;
+                const long long pr = map_row2(p.cmap, r);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    rres[(i * 16 + reg) * TN + j] = p.res[pr * p.ldr + col0 + wc * WTN + j * 32 + (lane & 31)];
+            }
+    }
+
+    // fragment read offsets: row (lane&31), logical chunk 2s+h at position (2s+h) ^ ((row>>1)&7)
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int sw = (l31 >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) foff[s] = l31 * 128 + (((2 * s + lh) ^ sw) * 16);
+    const int fragA = wr * WTM * 128;
+    const int fragW = BM * 128 + wc * WTN * 128;
+
+    __syncthreads();  // (the compiler drains vmcnt before a barrier while LDS-DMA is outstanding)
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const char* cur = smem + (kt & 1) * BUF;
+        if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4 fa[TM], fw[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4*)(cur + fragA + i * 32 * 128 + foff[s]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fw[j] = *(const u32x4*)(cur + fragW + j * 32 * 128 + foff[s]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fw[j]), acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    float bj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bj[j] = p.bias ? p.bias[col0 + wc * WTN + j * 32 + l31] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int r = row0 + wr * WTM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (r < p.M) {
+                const long long pr = map_row2(p.cmap, r);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int c = col0 + wc * WTN + j * 32 + l31;
+                    float v = acc[i][j][reg] + bj[j];
+                    if constexpr (EPI & EPI_ROWTAB) v += p.rowtab[(long long)(r % p.rt_mod) * p.rt_ld + c];
+                    if constexpr (EPI & EPI_GELU) v = gelu_fast2(v);
+                    if constexpr (EPI & EPI_RES) v += rres[(i * 16 + reg) * TN + j];
+                    if constexpr (EPI & EPI_F32OUT)
+                        p.Cf[pr * p.ldc + c] = v;
+                    else
+                        p.Cb[pr * p.ldc + c] = (bf16_t)v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int EPI, int WM, int WN>
+static void launch_cfg(const GemmP& p, hipStream_t st) {
+    const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
+    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, EPI, WM, WN>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+}
+
+template <int BM, int BN, int WM, int WN>
+static bool launch_tile(const GemmP& p, hipStream_t st) {
+    const bool f32out = p.Cf != nullptr;
+    const int epi = (p.gelu ? EPI_GELU : 0) | (p.res ? EPI_RES : 0) | (p.rowtab ? EPI_ROWTAB : 0) | (f32out ? EPI_F32OUT : 0);
+    switch (epi) {
+        case 0: launch_cfg<BM, BN, 0, WM, WN>(p, st); return true;
+        case EPI_F32OUT: launch_cfg<BM, BN, EPI_F32OUT, WM, WN>(p, st); return true;
+        case EPI_GELU: launch_cfg<BM, BN, EPI_GELU, WM, WN>(p, st); return true;
+        case EPI_GELU | EPI_F32OUT: launch_cfg<BM, BN, EPI_GELU | EPI_F32OUT, WM, WN>(p, st); return true;
+        case EPI_RES | EPI_F32OUT: launch_cfg<BM, BN, EPI_RES | EPI_F32OUT, WM, WN>(p, st); return true;
+        case EPI_ROWTAB | EPI_F32OUT: launch_cfg<BM, BN, EPI_ROWTAB | EPI_F32OUT, WM, WN>(p, st); return true;
+        default: return false;
+    }
+}
+
+// returns false when the shape / epilogue is not covered (caller falls back to gemm.hip's kernel)
+bool launch_gemm_glds(const GemmP& p, hipStream_t st) {
+    if (p.K % 64 != 0 || p.N % 128 != 0) return false;
+    const long long big_tiles = (long long)((p.M + 127) / 128) * (p.N / 128);
+    if (big_tiles < 512) return false;
+    if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || (p.lda % 8) || (p.ldw % 8)) return false;
+    if (p.variant == 4) return launch_tile<256, 128, 2, 2>(p, st);
+    if (p.variant == 5 && p.N % 256 == 0) return launch_tile<256, 256, 2, 4>(p, st);
+    if (p.variant == 6) return launch_tile<256, 128, 4, 2>(p, st);
+    if (p.variant == 3) return launch_tile<128, 128, 2, 2>(p, st);
+    // default selection (measured with tools/gemm_bench.py on the plan step's shapes): wide outputs
+    // (N >= 1024) run fastest on 256x256 tiles with 8 waves -- 4x less L2->LDS traffic per flop; the
+    // N = 512 GEMMs (out-proj, FFN2, heads) would leave the chip half empty with so few 256-wide tiles and
+    // stay on 128x128 tiles.
+    if (p.N % 256 == 0 && p.N >= 1024 && (long long)((p.M + 255) / 256) * (p.N / 256) >= 256)
+        return launch_tile<256, 256, 2, 4>(p, st);
+    return launch_tile<128, 128, 2, 2>(p, st);
+}
+
+}  // namespace m3pc

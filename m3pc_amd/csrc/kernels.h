@@ -41,8 +41,13 @@ struct GemmP {
     bf16_t* Cb;    // bf16 output (optional)
     int ldc;
     RowMap cmap;   // applies to res, Cf, Cb
+    float* ws;     // split-K slab workspace (optional): few-row fp32 GEMMs split K over blocks
+    long long ws_bytes;
+    int variant;   // 0 = default kernel selection; other values pick experimental configurations
 };
 void launch_gemm(const GemmP& p, int dtype, hipStream_t st);
+bool launch_gemm_ring(const GemmP& p, hipStream_t st);  // bf16, many rows: 256x256 tile, 4-slot LDS-DMA ring (gemm_ring.hip)
+bool launch_gemm_glds(const GemmP& p, hipStream_t st);  // bf16, many rows: direct-to-LDS staging (gemm_glds.hip)
 
 // LayerNorm over the last dim (eps 1e-5), one wave per row; optional second LayerNorm applied to
 // the result (decoder.norm followed by an output head's LayerNorm).  d <= 1024, d % 64 == 0.
@@ -82,6 +87,7 @@ struct AttnP {
     float scale;
 };
 void launch_attention(const AttnP& p, int dtype, hipStream_t st);
+void launch_attention_bf16(const AttnP& p, hipStream_t st);
 
 // Encoder token embedding (mtm_model.py:546-557) with the tokenizer affine folded in and the
 // mask-drop gather (mtm_model.py:534-544) applied: X[b, j, :] for the kept tokens only.
@@ -152,6 +158,7 @@ struct SampleP {
     const float* sd;            // (T, A)
     const float* eps;           // mode 0: (n_total, T, A); mode 1: (n_total, h, A)
     int mode, T, A, idx, h, n_begin, n_count;
+    const int* index;           // optional (n_count,): candidate n reads eps row index[n] instead of n_begin+n
     float* cand;                // (n_count, T, A)
     float* sample_actions;      // (n_count, h, A)
 };
@@ -187,19 +194,26 @@ struct ScoreP {
 };
 void launch_score(const ScoreP& p, hipStream_t st);
 
-// softmax / weighted mean / argmax over all candidates (learner.py:318-323)
+// softmax / weighted mean / argmax / multinomial draw over all candidates (learner.py:318-325)
 struct SelectP {
     const float* er;
     const float* a0;
     long long a0_stride;
     int n, A;
     float temperature;
+    const float* expo;     // optional (n,) Exp(1) variates: sample_idx = argmax(p / expo), torch.multinomial's draw
     float* p;
     float* eval_action;
     int* argmax;
-    float* scratch;  // >= 4 + A floats
+    int* sample_idx;
+    float* sample_action;  // (A,) = a0[sample_idx]
 };
 void launch_select(const SelectP& p, hipStream_t st);
+
+// indices of the k largest values (descending; ties -> lower index first), n <= 16384, k <= n
+void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st);
+// dst[index[i]] = src[i]
+void launch_scatter(const float* src, const int* index, int n, float* dst, hipStream_t st);
 
 void launch_tokenize(const void* in, int in_f64, float* out, long long rows, int D, const float* mean,
                      const float* stdv, int normalize, hipStream_t st);

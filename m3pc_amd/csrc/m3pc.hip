@@ -122,6 +122,12 @@ struct m3pc_handle {
     void *Hn = nullptr, *QKV = nullptr, *O = nullptr, *F = nullptr, *Z = nullptr;
     float *cand = nullptr, *loc = nullptr, *sd = nullptr, *rtok = nullptr, *pred[2] = {nullptr, nullptr}, *qv = nullptr;
     float* sel_scratch = nullptr;
+    int* d_topk = nullptr;        // (1024,) candidate ids of the last top-k
+    float* er_top = nullptr;      // (1024,) their fp32 re-scores
+    float* sa_buf = nullptr;      // (max_candidates, T, A) scratch for m3pc_rescore
+    float* splitk_ws = nullptr;   // raw split-K slabs of the few-row fp32 GEMMs
+    long long splitk_ws_bytes = 0;
+    bool policy_valid = false;    // loc/sd/rtok hold the last plan_step's policy pass
     std::map<std::string, std::unique_ptr<Plan>> plans;
     // profiling
     bool prof = false;
@@ -227,7 +233,10 @@ struct GemmTimer {
     }
 };
 
-void gemm(m3pc_handle* h, const GemmP& p, int dt, hipStream_t st) {
+void gemm(m3pc_handle* h, const GemmP& p_in, int dt, hipStream_t st) {
+    GemmP p = p_in;
+    p.ws = h->splitk_ws;
+    p.ws_bytes = h->splitk_ws_bytes;
     GemmTimer t(h, st, 2.0 * p.M * (double)p.N * p.K);
     launch_gemm(p, dt, st);
 }
@@ -968,6 +977,11 @@ int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out) {
     CHK(dmalloc(&h->pred[1], (size_t)D.max_candidates * T * 32));
     CHK(dmalloc(&h->qv, (size_t)D.max_candidates * T));
     CHK(dmalloc(&h->sel_scratch, 64));
+    CHK(dmalloc(&h->d_topk, 1024));
+    CHK(dmalloc(&h->er_top, 1024));
+    CHK(dmalloc(&h->sa_buf, (size_t)D.max_candidates * T * h->A));
+    h->splitk_ws_bytes = 64LL << 20;
+    CHK(dmalloc(&h->splitk_ws, (size_t)(h->splitk_ws_bytes / 4)));
     if (D.critic_hidden > 0) {
         const int Hd = D.critic_hidden, SA = h->S + h->A;
         for (int i = 0; i < 2; ++i) {
@@ -1002,7 +1016,7 @@ int m3pc_destroy(m3pc_handle* h) {
     }
     hipFree(h->mask_tokens);
     void* bufs[] = {h->X, h->Y, h->EncOut, h->G, h->Hn, h->QKV, h->O, h->F, h->Z, h->cand, h->loc, h->sd, h->rtok,
-                    h->pred[0], h->pred[1], h->qv, h->sel_scratch, h->c_om, h->c_os};
+                    h->pred[0], h->pred[1], h->qv, h->sel_scratch, h->d_topk, h->er_top, h->sa_buf, h->splitk_ws, h->c_om, h->c_os};
     for (void* b : bufs)
         if (b) hipFree(b);
     for (int i = 0; i < 2; ++i) {
@@ -1069,6 +1083,7 @@ int m3pc_load_weights(m3pc_handle* h, const m3pc_named_tensor* tensors, int n, v
     }
     HIPCHK(hipMemcpy(h->mask_tokens, mt.data(), mt.size() * sizeof(float), hipMemcpyHostToDevice));
     invalidate_tables(h);
+    h->policy_valid = false;
     h->weights_loaded = true;
     return 0;
 }
@@ -1213,6 +1228,7 @@ int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     CHK(forward_impl(h, pl, in, 1, nullptr, nullptr, nullptr, h->loc, h->sd, DT_F32, st));
     if (loc) HIPCHK(hipMemcpyAsync(loc, h->loc, (size_t)T * h->A * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (std_) HIPCHK(hipMemcpyAsync(std_, h->sd, (size_t)T * h->A * sizeof(float), hipMemcpyDeviceToDevice, st));
+    h->policy_valid = true;
 
     // candidates
     SampleP sp;
@@ -1237,10 +1253,58 @@ int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
                           a->precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32, st);
 }
 
+int m3pc_rescore(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* actions, const float* rewards,
+                 const float* eps, const int* index, int n, float* sample_actions, float* expect_return, void* stream) {
+    if (!h || !a || !states || !actions || !rewards || !eps || !index || !expect_return) return fail(M3PC_EINVAL, "null argument");
+    if (!h->weights_loaded) return fail(M3PC_ESTATE, "weights not loaded");
+    if (!h->policy_valid) return fail(M3PC_ESTATE, "m3pc_rescore needs a preceding m3pc_plan_step");
+    const int T = h->T;
+    if (a->horizon < 1 || a->horizon > T || a->mode < 0 || a->mode > 2) return fail(M3PC_EINVAL, "bad horizon/mode");
+    if (n < 1 || n > h->dm.max_candidates) return fail(M3PC_ENOMEM, "n %d outside [1, max_candidates=%d]", n, h->dm.max_candidates);
+    if (a->mode != M3PC_MODE_RTG && !h->critic_set) return fail(M3PC_ESTATE, "critic weights not set");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->device));
+    float* sa = sample_actions ? sample_actions : h->sa_buf;
+    SampleP sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.hist_actions = actions;
+    sp.loc = h->loc;
+    sp.sd = h->sd;
+    sp.eps = eps;
+    sp.mode = a->mode == M3PC_MODE_NOISE ? 1 : 0;
+    sp.T = T;
+    sp.A = h->A;
+    sp.idx = T - a->horizon;
+    sp.h = a->horizon;
+    sp.n_count = n;
+    sp.index = index;
+    sp.cand = h->cand;
+    sp.sample_actions = sa;
+    launch_sample(sp, st);
+    return candidate_pass(h, a, states, rewards, n, sa, expect_return, nullptr, nullptr, DT_F32, st);
+}
+
+int m3pc_rescore_topk(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* actions,
+                      const float* rewards, const float* eps, float* expect_return, int k, int* topk_index, void* stream) {
+    if (!h || !a || !expect_return) return fail(M3PC_EINVAL, "null argument");
+    if (a->n_total < 1 || a->n_total > 16384) return fail(M3PC_EINVAL, "top-k supports n_total <= 16384");
+    if (k < 1 || k > a->n_total || k > h->dm.max_candidates || k > 1024)
+        return fail(M3PC_EINVAL, "k %d outside [1, min(n_total, max_candidates, 1024)]", k);
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->device));
+    launch_topk(expect_return, a->n_total, k, h->d_topk, st);
+    CHK(m3pc_rescore(h, a, states, actions, rewards, eps, h->d_topk, k, nullptr, h->er_top, stream));
+    launch_scatter(h->er_top, h->d_topk, k, expect_return, st);
+    if (topk_index) HIPCHK(hipMemcpyAsync(topk_index, h->d_topk, (size_t)k * sizeof(int), hipMemcpyDeviceToDevice, st));
+    return check_launch("rescore_topk");
+}
+
 int m3pc_select(m3pc_handle* h, const float* expect_return, const float* a0, long long a0_stride, int n, float temperature,
-                float* p, float* eval_action, int* argmax, void* stream) {
+                const float* expo, float* p, float* eval_action, int* argmax, int* sample_idx, float* sample_action,
+                void* stream) {
     if (!h || !expect_return || n < 1) return fail(M3PC_EINVAL, "bad argument");
-    if (eval_action && !a0) return fail(M3PC_EINVAL, "eval_action needs a0");
+    if ((eval_action || sample_action) && !a0) return fail(M3PC_EINVAL, "eval_action / sample_action need a0");
+    if ((sample_idx || sample_action) && !expo) return fail(M3PC_EINVAL, "the multinomial draw needs expo");
     HIPCHK(hipSetDevice(h->device));
     SelectP s;
     memset(&s, 0, sizeof(s));
@@ -1250,12 +1314,31 @@ int m3pc_select(m3pc_handle* h, const float* expect_return, const float* a0, lon
     s.n = n;
     s.A = h->A;
     s.temperature = temperature;
+    s.expo = expo;
     s.p = p;
     s.eval_action = eval_action;
     s.argmax = argmax;
-    s.scratch = h->sel_scratch;
+    s.sample_idx = sample_idx;
+    s.sample_action = sample_action;
     launch_select(s, (hipStream_t)stream);
     return check_launch("select");
+}
+
+// Not part of the public header: lets tools/gemm_bench.py time the GEMM kernel on the plan step's shapes.
+int m3pc_debug_gemm(int dtype, const void* A, const void* Wt, const float* bias, const float* res, void* C, int M, int N,
+                    int K, int gelu, int f32out, int variant, void* stream) {
+    GemmP p = gemm_basic(A, K, Wt, K, M, N, K, bias);
+    p.gelu = gelu;
+    p.res = res;
+    p.ldr = N;
+    p.variant = variant;
+    if (dtype == DT_BF16 && !f32out)
+        p.Cb = (bf16_t*)C;
+    else
+        p.Cf = (float*)C;
+    p.ldc = N;
+    launch_gemm(p, dtype, (hipStream_t)stream);
+    return check_launch("debug_gemm");
 }
 
 int m3pc_profile_enable(m3pc_handle* h, int enable) {

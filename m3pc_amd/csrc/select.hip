@@ -1,0 +1,143 @@
+// The cross-candidate tail of a plan step (learner.py:318-325) and the top-k used by the fp32 re-score.
+// Everything here is one workgroup: N <= 16384 scores live in registers / LDS, reductions are 64-lane
+// shuffles + one LDS hop.
+#include "kernels.h"
+
+namespace m3pc {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+struct ArgMax {
+    float v;
+    int i;
+};
+__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {  // larger value, ties -> lower index
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ ArgMax block_argmax(ArgMax a, float* sv, int* si) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgMax b{__shfl_xor(a.v, o), __shfl_xor(a.i, o)};
+        a = better(a, b);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        sv[wid] = a.v;
+        si[wid] = a.i;
+    }
+    __syncthreads();
+    ArgMax r{sv[0], si[0]};
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = better(r, ArgMax{sv[w], si[w]});
+    return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* sv) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    v = wsum(v);
+    __syncthreads();
+    if (lane == 0) sv[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sv[w];
+    return t;
+}
+
+// p = exp(T (E - max E)) / sum;  eval = sum p a0 / sum p;  argmax E;  sample = argmax p / expo
+__global__ __launch_bounds__(1024) void select_kernel(SelectP p) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const int tid = threadIdx.x;
+    ArgMax am{-INFINITY, 0x7fffffff};
+    for (int i = tid; i < p.n; i += 1024) am = better(am, ArgMax{p.er[i], i});
+    am = block_argmax(am, sv, si);
+    if (tid == 0 && p.argmax) *p.argmax = am.i;
+    const float mx = am.v;
+    float s = 0.f;
+    for (int i = tid; i < p.n; i += 1024) s += expf(__fmul_rn(__fsub_rn(p.er[i], mx), p.temperature));
+    const float tot = block_sum(s, sv);
+    float ps = 0.f;
+    ArgMax sm{-INFINITY, 0x7fffffff};
+    for (int i = tid; i < p.n; i += 1024) {
+        const float pi = expf(__fmul_rn(__fsub_rn(p.er[i], mx), p.temperature)) / tot;
+        if (p.p) p.p[i] = pi;
+        ps += pi;
+        if (p.expo) sm = better(sm, ArgMax{pi / p.expo[i], i});
+    }
+    const float psum = block_sum(ps, sv);
+    if (p.expo) {
+        sm = block_argmax(sm, sv, si);
+        if (tid == 0 && p.sample_idx) *p.sample_idx = sm.i;
+        if (p.sample_action && tid < p.A) p.sample_action[tid] = p.a0[(long long)sm.i * p.a0_stride + tid];
+    }
+    if (p.eval_action) {
+        for (int a = 0; a < p.A; ++a) {
+            float acc = 0.f;
+            for (int i = tid; i < p.n; i += 1024) {
+                const float pi = expf(__fmul_rn(__fsub_rn(p.er[i], mx), p.temperature)) / tot;
+                acc = fmaf(p.a0[(long long)i * p.a0_stride + a], pi, acc);
+            }
+            const float t = block_sum(acc, sv);
+            if (tid == 0) p.eval_action[a] = t / psum;
+        }
+    }
+}
+void launch_select(const SelectP& p, hipStream_t st) {
+    if (p.n <= 0) return;
+    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, st, p);
+}
+
+// ---------------------------------------------------------------------------------------------- top-k
+// Bitonic sort of 64-bit keys {orderable(value), ~index} in LDS (descending), first k indices out.
+__device__ __forceinline__ unsigned int orderable(float f) {
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__global__ __launch_bounds__(1024) void topk_kernel(const float* v, int n, int npow2, int k, int* idx_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < npow2; i += 1024)
+        keys[i] = i < n ? ((unsigned long long)orderable(v[i]) << 32) | (unsigned int)(~i) : 0ull;
+    __syncthreads();
+    for (int size = 2; size <= npow2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (npow2 >> 1); t += 1024) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a < b) == desc) {
+                    keys[lo] = b;
+                    keys[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < k; i += 1024) idx_out[i] = (int)(~(unsigned int)(keys[i] & 0xffffffffull));
+}
+void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st) {
+    if (n <= 0 || k <= 0) return;
+    int np = 2;
+    while (np < n) np <<= 1;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+        attr = true;
+    }
+    hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), (size_t)np * 8, st, v, n, np, k, idx_out);
+}
+
+__global__ void scatter_kernel(const float* src, const int* index, int n, float* dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[index[i]] = src[i];
+}
+void launch_scatter(const float* src, const int* index, int n, float* dst, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, index, n, dst);
+}
+
+}  // namespace m3pc

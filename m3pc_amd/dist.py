@@ -1,0 +1,53 @@
+"""Candidate sharding across the GPUs of one node.
+
+Candidates are independent through the batched forward and the TD(lambda) scoring; they couple only in
+the final max / softmax / weighted mean / multinomial (learner.py:318-325).  Rank r of G therefore scores
+candidates [r*N/G, (r+1)*N/G) and ONE all-gather (RCCL over xGMI, backend "nccl"; gloo on CPU in the
+tests) of the per-shard scores and first actions reassembles exactly the single-GPU vectors; every rank
+then runs the identical select.  The policy pass and the eps draw are replicated (same seed on every rank),
+which keeps the sampled candidates identical to the 1-GPU run.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced split: the first ``n_total % world`` ranks get one extra candidate."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    q, r = divmod(n_total, world)
+    begin = rank * q + min(rank, r)
+    return begin, q + (1 if rank < r else 0)
+
+
+def world_info(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def gather_candidates(er_shard: torch.Tensor, a0_shard: torch.Tensor, n_total: int, group=None):
+    """All-gather per-shard scores (n_r,) and first actions (n_r, A) into full (N,) / (N, A) tensors in
+    candidate order.  One collective: scores and actions travel in a single packed (n_r, 1+A) buffer,
+    padded to the largest shard so the collective is fixed-size (unequal shards only when N % G != 0)."""
+    rank, world = world_info(group)
+    if world == 1:
+        return er_shard, a0_shard
+    A = a0_shard.shape[1]
+    nmax = -(-n_total // world)
+    pack = torch.zeros((nmax, 1 + A), dtype=er_shard.dtype, device=er_shard.device)
+    n_r = er_shard.shape[0]
+    pack[:n_r, 0] = er_shard
+    pack[:n_r, 1:] = a0_shard
+    out = torch.empty((world, nmax, 1 + A), dtype=pack.dtype, device=pack.device)
+    dist.all_gather_into_tensor(out.view(world * nmax, 1 + A), pack, group=group)
+    ers, a0s = [], []
+    for r in range(world):
+        _, cnt = shard_range(n_total, r, world)
+        ers.append(out[r, :cnt, 0])
+        a0s.append(out[r, :cnt, 1:])
+    return torch.cat(ers), torch.cat(a0s)

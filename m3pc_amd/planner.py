@@ -1,0 +1,256 @@
+"""The plan_guidance plug-in surface of the reference ``Learner`` (research/finetune_omtm/learner.py:
+103-115 mtm_sampling, 142-208 noise_adding_lambda, 211-268 critic_lambda_guiding, 271-327 rtg_guiding,
+329-417 action_sample) driving libm3pc_hip.so.  Same method names, argument meaning, return shapes
+((1,A) sampled action, (A,) eval action) and string dispatch on ``cfg.plan_guidance``.
+
+Two ways in:
+  * ``HipPlanner(cfg, state_dict, tokenizer_manager | stats, q_state_dict, obs_mean, obs_std)``
+  * ``attach(learner)``: build a planner from a live reference ``Learner`` (its ``mtm``, ``tokenizer_manager``,
+    ``iql.qf``, ``cfg``) and rebind the guidance methods + ``action_sample`` on that object; weights are
+    re-synchronised whenever a parameter's ``_version`` changes (fine-tuning updates them between rollouts,
+    finetune.py:306).
+
+Host work per step: assemble the window in NumPy (one packed H2D copy), draw eps / the multinomial index
+with torch's device generator, and -- when candidates are sharded over ranks -- one all-gather.
+"""
+from __future__ import annotations
+
+import types
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import capi, dist as mdist
+from .tokenizers import ContinuousTokenizer, DataStatistics, SquashedNormal, TokenizerManager
+
+KEYS = capi.KEYS
+_MODES = {"rtg_guiding": capi.MODE_RTG, "critic_lambda_guiding": capi.MODE_CRITIC,
+          "noise_adding_lambda": capi.MODE_NOISE}
+
+
+def _cfg_get(cfg, name, default=None):
+    return getattr(cfg, name, default)
+
+
+class HipPlanner:
+    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], tokenizer_manager, q_state_dict=None,
+                 obs_mean=None, obs_std=None, n_embd: int = 512, n_head: int = 4, n_enc_layer: int = 2,
+                 n_dec_layer: int = 1, precision: str = "fp32", rescore_topk: int = 32, device: Optional[int] = None,
+                 group=None, generator: Optional[torch.Generator] = None):
+        """cfg: any object with traj_length, action_samples, horizon, discount, temperature, lmbda,
+        plan_guidance (finetune.py RunConfig fields read at learner.py:276,319,342).
+        tokenizer_manager: a TokenizerManager (this package's) or {key: {"mean","std","min","max"}}.
+        precision: "fp32" (reference-accurate) or "bf16" (bf16 MFMA candidate pass; the top
+        ``rescore_topk`` candidates are re-scored in fp32 so the arg-max does not depend on bf16 rounding)."""
+        self.cfg = cfg
+        self.group = group
+        self.rank, self.world = mdist.world_info(group)
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        S = state_dict["encoder_embed_dict.states.weight"].shape[1]
+        A = state_dict["encoder_embed_dict.actions.weight"].shape[1]
+        T = int(cfg.traj_length)
+        N = int(cfg.action_samples)
+        _, n_local = mdist.shard_range(N, 0, self.world)
+        hidden = 0 if q_state_dict is None else q_state_dict["q1.net.0.weight"].shape[0]
+        self.handle = capi.Handle(S, A, T, n_embd, n_head, n_enc_layer, n_dec_layer,
+                                  max_candidates=max(n_local, rescore_topk, 1), max_batch=1, critic_hidden=hidden,
+                                  device=device)
+        self.device = self.handle.device
+        self.S, self.A, self.T = S, A, T
+        self.precision = {"fp32": capi.PREC_FP32, "bf16": capi.PREC_BF16}[precision]
+        self.rescore_topk = int(rescore_topk) if self.precision == capi.PREC_BF16 else 0
+        self.generator = generator
+        if isinstance(tokenizer_manager, dict):
+            toks = {}
+            for k in KEYS:
+                s = tokenizer_manager[k]
+                toks[k] = ContinuousTokenizer(s["mean"], s["std"], DataStatistics(s["mean"], s["std"], s["min"], s["max"]),
+                                              normalize=(k != "actions"))
+            tokenizer_manager = TokenizerManager(toks)
+        self.tokenizer_manager = tokenizer_manager.bind(self.handle)
+        self.load_state_dict(state_dict)
+        if q_state_dict is not None:
+            self.load_critic(q_state_dict, obs_mean, obs_std)
+        self._host = np.zeros((T, S + A + 1), dtype=np.float32)
+        self.last: Dict[str, torch.Tensor] = {}
+
+    # ---------------------------------------------------------------------------------------- weights
+    def load_state_dict(self, state_dict):
+        self.handle.load_weights(state_dict)
+
+    def load_critic(self, q_state_dict, obs_mean, obs_std):
+        self.handle.set_critic(q_state_dict, obs_mean, obs_std)
+
+    # ---------------------------------------------------------------------------------------- window
+    def assemble_window(self, sequence_history, rtg=None, percentage=1.0):
+        """learner.py:342-385.  Returns (states (T,S), actions (T,A), rewards (T,1) on device, horizon, rtg)."""
+        T = self.T
+        horizon = int(self.cfg.horizon)
+        end_idx = int(sequence_history["path_length"])
+        if end_idx + horizon < T:
+            horizon = T - end_idx
+        hl = T - horizon + 1
+        buf = self._host
+        buf[:] = 0.0
+        lo, hi = end_idx - hl + 1, end_idx + 1
+        buf[:hl, : self.S] = sequence_history["observations"][lo:hi]
+        buf[:hl, self.S : self.S + self.A] = sequence_history["actions"][lo:hi]
+        buf[:hl, self.S + self.A :] = np.asarray(sequence_history["rewards"][lo:hi]).reshape(hl, 1)
+        dev = torch.from_numpy(buf).to(self.device)  # one packed H2D copy
+        states = dev[:, : self.S].contiguous()
+        actions = dev[:, self.S : self.S + self.A].contiguous()
+        rewards = dev[:, self.S + self.A :].contiguous()
+        if rtg is not None:
+            return_to_go = float(rtg)
+        else:
+            st = self.tokenizer_manager.tokenizers["returns"].stats
+            return_to_go = float(np.asarray(st.min + (st.max - st.min) * percentage).reshape(-1)[0])
+        return states, actions, rewards, horizon, return_to_go
+
+    # ---------------------------------------------------------------------------------------- guidance
+    def _eps(self, shape):
+        return torch.randn(shape, device=self.device, dtype=torch.float32, generator=self.generator)
+
+    def _guide(self, mode: int, states, actions, rewards, rtg: float, h: int, lmbda: float, eps=None):
+        cfg = self.cfg
+        N, T, A = int(cfg.action_samples), self.T, self.A
+        if eps is None:
+            # same shapes the reference draws: dist.sample((N,)) over loc (1,T,1,A) (learner.py:285) /
+            # randn((N,h,A)) for the fixed-variance variant (learner.py:157-163); identical on every rank
+            eps = self._eps((N, h, A)) if mode == capi.MODE_NOISE else self._eps((N, 1, T, 1, A))
+        eps = eps.reshape(N, -1, A)
+        begin, count = mdist.shard_range(N, self.rank, self.world)
+        res = self.handle.plan_step(mode, states, actions, rewards, eps, h, rtg, float(lmbda), float(cfg.discount),
+                                    N, begin, count, precision=self.precision)
+        er, a0 = res["expect_return"], res["sample_actions"][:, 0]
+        er, a0 = mdist.gather_candidates(er, a0.contiguous() if self.world > 1 else a0, N, self.group)
+        top = None
+        if self.rescore_topk > 0:
+            # replicated on every rank (identical inputs => identical result): top-k of the gathered scores,
+            # fp32 candidate pass on those k, scores written back in place
+            top = self.handle.rescore_topk(mode, states, actions, rewards, eps, er, min(self.rescore_topk, N), h, rtg,
+                                           float(lmbda), float(cfg.discount))
+        # torch.multinomial(p, 1) == argmax(p / q), q ~ Exp(1) from the same generator (ATen's
+        # multinomial fast path); drawing q here and finishing inside the select kernel gives the same index
+        expo = torch.empty((N,), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
+        p, eval_action, argmax, sample_idx, sample_action = self.handle.select(er, a0, float(cfg.temperature), expo)
+        self.last = dict(expect_return=er, p=p, argmax=argmax, sample_idx=sample_idx, loc=res["loc"], std=res["std"],
+                         sample_actions=res["sample_actions"], eps=eps, topk=top)
+        return sample_action, eval_action
+
+    @staticmethod
+    def _split(trajectory):
+        s, a, r = trajectory["states"][0], trajectory["actions"][0], trajectory["rewards"][0]
+        rtg = trajectory.get("_rtg")
+        if rtg is None:
+            rtg = float(trajectory["returns"].reshape(-1)[0])  # device sync; action_sample passes _rtg
+        return s.float().contiguous(), a.float().contiguous(), r.float().contiguous(), float(rtg)
+
+    @torch.no_grad()
+    def rtg_guiding(self, trajectory: Dict[str, torch.Tensor], h: int, lmbda: float = 0.6):
+        """learner.py:271-327."""
+        s, a, r, rtg = self._split(trajectory)
+        return self._guide(capi.MODE_RTG, s, a, r, rtg, h, lmbda)
+
+    @torch.no_grad()
+    def critic_lambda_guiding(self, trajectory: Dict[str, torch.Tensor], h: int, lmbda: float):
+        """learner.py:211-268."""
+        s, a, r, rtg = self._split(trajectory)
+        return self._guide(capi.MODE_CRITIC, s, a, r, rtg, h, lmbda)
+
+    @torch.no_grad()
+    def noise_adding_lambda(self, trajectory: Dict[str, torch.Tensor], h: int, lmbda: float):
+        """learner.py:142-208."""
+        s, a, r, rtg = self._split(trajectory)
+        return self._guide(capi.MODE_NOISE, s, a, r, rtg, h, lmbda)
+
+    @torch.no_grad()
+    def mtm_sampling(self, trajectory: Dict[str, torch.Tensor], h: int):
+        """learner.py:103-115: one return-conditioned policy pass, no planning."""
+        s, a, r, rtg = self._split(trajectory)
+        T = self.T
+        toks = [self.handle.tokenize(capi.STATES, s[None]), a[None], None,
+                self.handle.tokenize(capi.RETURNS, torch.full((1, T, 1), rtg, dtype=torch.float64, device=self.device))]
+        from .masks import create_rcbc_mask, mask_rows
+        out = self.handle.forward(toks, mask_rows(create_rcbc_mask(T, "cpu", T - h)), want=("actions",))
+        mu, sd = out["actions"]
+        dist_ = SquashedNormal(mu.unsqueeze(2), sd.unsqueeze(2))
+        eps = self._eps(tuple(dist_.loc.shape))
+        sample_action = dist_.sample(eps=eps)[0, T - h]
+        eval_action = dist_.mean[0, T - h]
+        return sample_action, eval_action
+
+    @torch.no_grad()
+    def action_sample(self, sequence_history, percentage=1.0, horizon=4, plan=True, eval=False, rtg=None):
+        """learner.py:329-417 (the ``horizon`` argument is ignored there too: cfg.horizon rules)."""
+        if eval:
+            assert rtg is not None
+        states, actions, rewards, h, return_to_go = self.assemble_window(sequence_history, rtg, percentage)
+        traj = {"states": states[None], "actions": actions[None], "rewards": rewards[None], "_rtg": return_to_go}
+        if plan:
+            guidance = self.cfg.plan_guidance
+            assert guidance in _MODES, guidance
+            if guidance == "rtg_guiding":
+                sample_action, eval_action = self.rtg_guiding(traj, h)  # default lmbda=0.6, learner.py:405-407
+            else:
+                sample_action, eval_action = getattr(self, guidance)(traj, h, lmbda=self.cfg.lmbda)
+        else:
+            sample_action, eval_action = self.mtm_sampling(traj, h)
+        return eval_action if eval else sample_action
+
+
+# ------------------------------------------------------------------------------------------------------
+def _param_version(module) -> int:
+    return sum(int(p._version) for p in module.parameters())
+
+
+def attach(learner, precision: str = "fp32", rescore_topk: int = 32, group=None):
+    """Rebind the plan path of a reference-style ``Learner`` onto the HIP library.
+
+    Reads: learner.cfg, learner.mtm (state_dict + config), learner.tokenizer_manager.tokenizers[k]
+    (._data_mean, ._data_std, .normalize, .stats), learner.iql.qf (state_dict, obs_mean, obs_std).
+    Afterwards learner.action_sample / rtg_guiding / critic_lambda_guiding / noise_adding_lambda /
+    mtm_sampling run on the GPU; everything else on the object is untouched."""
+    mtm = learner.mtm
+    mc = mtm.config
+    toks = {}
+    for k in KEYS:
+        t = learner.tokenizer_manager.tokenizers[k]
+        st = t.stats
+        toks[k] = ContinuousTokenizer(t._data_mean.detach().cpu().numpy(), t._data_std.detach().cpu().numpy(),
+                                      DataStatistics(st.mean, st.std, st.min, st.max), normalize=bool(t.normalize))
+    qf = getattr(getattr(learner, "iql", None), "qf", None)
+    planner = HipPlanner(learner.cfg, mtm.state_dict(), TokenizerManager(toks),
+                         q_state_dict=None if qf is None else qf.state_dict(),
+                         obs_mean=None if qf is None else qf.obs_mean, obs_std=None if qf is None else qf.obs_std,
+                         n_embd=mc.n_embd, n_head=mc.n_head, n_enc_layer=mc.n_enc_layer, n_dec_layer=mc.n_dec_layer,
+                         precision=precision, rescore_topk=rescore_topk, group=group)
+    state = {"mtm": _param_version(mtm), "qf": None if qf is None else _param_version(qf)}
+
+    def _sync():
+        v = _param_version(mtm)
+        if v != state["mtm"]:
+            planner.load_state_dict(mtm.state_dict())
+            state["mtm"] = v
+        if qf is not None:
+            vq = _param_version(qf)
+            if vq != state["qf"]:
+                planner.load_critic(qf.state_dict(), qf.obs_mean, qf.obs_std)
+                state["qf"] = vq
+
+    def _wrap(name):
+        fn = getattr(planner, name)
+
+        def method(self, *a, **kw):
+            _sync()
+            return fn(*a, **kw)
+
+        method.__name__ = name
+        return types.MethodType(method, learner)
+
+    for name in ("action_sample", "rtg_guiding", "critic_lambda_guiding", "noise_adding_lambda", "mtm_sampling"):
+        setattr(learner, name, _wrap(name))
+    learner._hip_planner = planner
+    return planner

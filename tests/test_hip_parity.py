@@ -265,6 +265,37 @@ def test_select_properties():
     assert abs(float(p.sum()) - 1.0) < 1e-5
     _assert_close(p, pr, 1e-5, "p")
     _assert_close(ev, evr, 1e-5, "eval_action")
+    # the multinomial draw: argmax(p / Exp(1)) with the caller's generator == torch.multinomial(p, 1)
+    for seed in (5, 6, 7):
+        gen = torch.Generator(device="cuda").manual_seed(seed)
+        ref_idx = torch.multinomial(p, 1, generator=gen)
+        gen.manual_seed(seed)
+        expo = torch.empty(5000, device="cuda").exponential_(1, generator=gen)
+        _, _, _, si, sa = h.select(er, a0[:, 0], 0.05, expo)
+        assert int(si.item()) == int(ref_idx.item())
+        assert torch.equal(sa[0], a0[int(ref_idx.item()), 0])
+    h.close()
+
+
+def test_rescore_topk_replaces_exactly_the_k_best():
+    """bf16 scores for all candidates, then fp32 re-scores of the top-k written in place: the touched
+    entries equal the fp32 plan_step's scores bit for bit, the others keep their bf16 value."""
+    dims = synth.Dims(11, 3, 16)
+    h, sd, stats, critic = make_handle(dims, max_candidates=256, max_batch=1)
+    cfg = O.PlanCfg(16, 8, 256)
+    win, hh = O.assemble_window(cfg, synth.make_history(dims, 0), 500, 3.0)
+    eps = synth.make_eps(256, dims, 1)[:, 0, :, 0, :].cuda()
+    s, a, r = window_dev(win)
+    f32 = h.plan_step(capi.MODE_RTG, s, a, r, eps, 8, 3.0, 0.6, 0.99, 256)["expect_return"].clone()
+    b16 = h.plan_step(capi.MODE_RTG, s, a, r, eps, 8, 3.0, 0.6, 0.99, 256, precision=capi.PREC_BF16)["expect_return"]
+    before = b16.clone()
+    top = h.rescore_topk(capi.MODE_RTG, s, a, r, eps, b16, 16, 8, 3.0, 0.6, 0.99).long()
+    assert set(top.tolist()) == set(torch.topk(before, 16).indices.tolist())
+    # same fp32 arithmetic; the 16-candidate pass splits K over blocks, so sums associate differently
+    assert float((b16[top] - f32[top]).abs().max()) <= 2e-5 * float(f32.abs().max())
+    rest = torch.ones(256, dtype=torch.bool, device="cuda")
+    rest[top] = False
+    assert torch.equal(b16[rest], before[rest])
     h.close()
 
 
