@@ -6,7 +6,7 @@
 
 One "step" = one complete plan step of rtg_guiding (research/finetune_omtm/learner.py:271-327): draw eps,
 policy pass (batch 1), sample N candidates, batched candidate pass, TD(lambda) scoring, all-gather of the
-shards (N > 1 GPU), fp32 re-score of the bf16 top-32, softmax / weighted mean / argmax, multinomial draw.
+shards (N > 1 GPU), fp32 re-score of the bf16 top-16, softmax / weighted mean / argmax, multinomial draw.
 Inputs (window, weights) are resident in HBM when the timed region starts.
 
 Workload at 1 GPU: BASELINE configs[1] = hopper-medium-v2 shapes (S=11, A=3), rtg_guiding, N=1024
@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--candidates", type=int, default=1024, help="candidates per GPU")
     ap.add_argument("--horizon", type=int, default=16)
     ap.add_argument("--traj-length", type=int, default=32)
-    ap.add_argument("--rescore-topk", type=int, default=32)
+    ap.add_argument("--rescore-topk", type=int, default=16)
     ap.add_argument("--strong", action="store_true", help="keep the global candidate count fixed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -164,14 +164,17 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    launches, gemm_ms, gemm_flops = planner.handle.profile_read(reset=True)
+    prec = capi.PREC_BF16 if args.precision == "bf16" else capi.PREC_FP32
+    launches, gemm_ms, gemm_flops = planner.handle.profile_read(prec, reset=False)
+    all_launches, all_ms, all_flops = planner.handle.profile_read(-1, reset=True)
     planner.handle.profile_enable(False)
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     peak = MFMA_PEAK_TFLOPS[args.precision]
     f_step = alg_flops(n_local, T, H, S, A)
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": None,
-                "kernel": "m3pc::gemm_kernel (all MFMA GEMM launches of a step)",
+                "kernel": f"m3pc::gemm_glds_kernel / gemm_kernel, the {args.precision} MFMA GEMM launches of the candidate pass",
+                "all_gemm_ms_per_step": all_ms / args.steps, "all_gemm_launches_per_step": all_launches / args.steps,
                 "flops_per_launch": gemm_flops / max(launches, 1), "avg_launch_us": 1e3 * gemm_ms / max(launches, 1),
                 "launches_per_step": launches / args.steps, "gemm_ms_per_step": gemm_ms / args.steps,
                 "step_alg_tflop": round(f_step / 1e12, 4),

@@ -179,8 +179,10 @@ int m3pc_select(m3pc_handle* h, const float* expect_return, const float* a0, lon
 /* kernel-level timing of the last plan_step for bench.py / profiling: when enabled the library
  * brackets the dominant kernel class (the MFMA GEMMs) with hipEvents on `stream`. */
 int m3pc_profile_enable(m3pc_handle* h, int enable);
-/* sums since the last reset: gemm launches, gemm milliseconds, gemm flops (2*M*N*K) */
-int m3pc_profile_read(m3pc_handle* h, long long* launches, double* gemm_ms, double* gemm_flops, int reset);
+/* sums since the last reset over the GEMM launches of one arithmetic (precision = M3PC_PREC_*, or -1 for
+ * all): launches, milliseconds between the bracketing events, flops (2*M*N*K) */
+int m3pc_profile_read(m3pc_handle* h, int precision, long long* launches, double* gemm_ms, double* gemm_flops,
+                      int reset);
 
 #ifdef __cplusplus
 }

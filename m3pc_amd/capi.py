@@ -81,7 +81,7 @@ def load_library(path: Optional[str] = None):
         "m3pc_rescore_topk": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, i, vp, vp],
         "m3pc_select": [vp, vp, vp, ll, i, f, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_profile_enable": [vp, i],
-        "m3pc_profile_read": [vp, C.POINTER(ll), C.POINTER(d), C.POINTER(d), i],
+        "m3pc_profile_read": [vp, i, C.POINTER(ll), C.POINTER(d), C.POINTER(d), i],
     }
     for name, args in protos.items():
         fn = getattr(lib, name)
@@ -286,7 +286,7 @@ class Handle:
     def profile_enable(self, on: bool):
         check(self.lib.m3pc_profile_enable(self._h, int(on)))
 
-    def profile_read(self, reset: bool = True):
+    def profile_read(self, precision: int = -1, reset: bool = True):
         n, ms, fl = C.c_longlong(), C.c_double(), C.c_double()
-        check(self.lib.m3pc_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(fl), int(reset)))
+        check(self.lib.m3pc_profile_read(self._h, precision, C.byref(n), C.byref(ms), C.byref(fl), int(reset)))
         return n.value, ms.value, fl.value

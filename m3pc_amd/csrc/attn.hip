@@ -209,7 +209,9 @@ template <typename T, int HDT>
 static void launch_hd(const AttnP& p, hipStream_t st) {
     const int Lk = p.L1 + p.L2;
     const int qgroups = (p.Lq + 127) / 128;
-    const int nw = p.Lq >= 128 ? 4 : (p.Lq + 31) / 32;
+    // always 4 waves: waves past the last query tile still help staging K/V (their MFMAs run on an otherwise
+    // idle SIMD over zero-filled query rows and are never stored)
+    const int nw = 4;
     const int rows = nw * 32 > 64 ? nw * 32 : 64;
     const size_t smem = (size_t)rows * (HDT * 32 + 4) * sizeof(float);
     dim3 grid(p.batch, p.n_head, qgroups), block(nw * 64);

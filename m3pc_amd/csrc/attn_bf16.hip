@@ -191,7 +191,7 @@ template <int HDT>
 static void launch_hd(const AttnP& p, hipStream_t st) {
     const int Lk = p.L1 + p.L2;
     const int qgroups = (p.Lq + 127) / 128;
-    const int nw = p.Lq >= 128 ? 4 : (p.Lq + 31) / 32;
+    const int nw = p.Lq > 64 ? 4 : 2;  // at least 2 waves so staging has 128 lanes
     const int rows = nw * 32 > 64 ? nw * 32 : 64;
     const size_t smem = (size_t)rows * (HDT * 64 + 16);
     dim3 grid(p.batch, p.n_head, qgroups), block(nw * 64);

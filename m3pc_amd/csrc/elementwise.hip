@@ -130,9 +130,90 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
             if (p.Yb) p.Yb[(long long)r * p.d + i * 64 + lane] = (bf16_t)v[i];
         }
 }
+// d % 256 == 0: 16-byte loads (lane owns 4 consecutive columns per 256-column slab), 8-byte bf16 stores
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(LnP p) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.rows) return;
+    const float* x = p.X + (long long)map_row(p.xmap, r) * p.ldx;
+    const int n = p.d >> 8;  // slabs of 256 columns (<= 4)
+    f32x4v v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < n) {
+            v[i] = *(const f32x4v*)(x + i * 256 + lane * 4);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    const float inv_d = 1.0f / (float)p.d;
+    float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < n) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c = v[i][e] - mean;
+                q += c * c;
+            }
+        }
+    float rstd = rsqrtf(wave_sum(q) * inv_d + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < n) {
+            const f32x4v g = *(const f32x4v*)(p.g1 + i * 256 + lane * 4);
+            const f32x4v b = *(const f32x4v*)(p.b1 + i * 256 + lane * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+        }
+    if (p.g2) {
+        s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        mean = wave_sum(s) * inv_d;
+        q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float c = v[i][e] - mean;
+                    q += c * c;
+                }
+            }
+        rstd = rsqrtf(wave_sum(q) * inv_d + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n) {
+                const f32x4v g = *(const f32x4v*)(p.g2 + i * 256 + lane * 4);
+                const f32x4v b = *(const f32x4v*)(p.b2 + i * 256 + lane * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < n) {
+            const long long o = (long long)r * p.d + i * 256 + lane * 4;
+            if (p.Yf) *(f32x4v*)(p.Yf + o) = v[i];
+            if (p.Yb) {
+                bf16x4v w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (bf16_t)v[i][e];
+                *(bf16x4v*)(p.Yb + o) = w;
+            }
+        }
+}
+
 void launch_layernorm(const LnP& p, hipStream_t st) {
     if (p.rows <= 0) return;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, st, p);
+    if (p.d % 256 == 0 && p.ldx % 4 == 0)
+        hipLaunchKernelGGL(layernorm_vec_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL(layernorm_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, st, p);
 }
 
 // ------------------------------------------------------------------------------------------ head out

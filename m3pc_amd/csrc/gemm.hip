@@ -109,32 +109,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    u32x4 ra[A_CH], rw[W_CH];
+    // Register prefetch two k-tiles deep: while tile k is multiplied out of LDS, tiles k+1 and k+2 are
+    // in flight from L2/HBM in two register sets (few-row GEMMs run one block per CU, so nothing else
+    // hides the load latency of their short K chains).
+    const int nloc = kt1 - kt0;
+    u32x4 ra0[A_CH], rw0[W_CH], ra1[A_CH], rw1[W_CH];
+    auto gload = [&](u32x4* ra, u32x4* rw, int kt) {
+        const long long ko = (long long)kt * 128;
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) ra[i] = *(const u32x4*)(a_src[i]);
+        for (int i = 0; i < A_CH; ++i) ra[i] = *(const u32x4*)(a_src[i] + ko);
 #pragma unroll
-    for (int i = 0; i < W_CH; ++i) rw[i] = *(const u32x4*)(w_src[i]);
+        for (int i = 0; i < W_CH; ++i) rw[i] = *(const u32x4*)(w_src[i] + ko);
+    };
+    auto lstore = [&](const u32x4* ra, const u32x4* rw, char* buf) {
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) *(u32x4*)(smem + a_dst[i]) = ra[i];
+        for (int i = 0; i < A_CH; ++i) *(u32x4*)(buf + a_dst[i]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < W_CH; ++i) *(u32x4*)(smem + w_dst[i]) = rw[i];
+        for (int i = 0; i < W_CH; ++i) *(u32x4*)(buf + w_dst[i]) = rw[i];
+    };
+    gload(ra0, rw0, 0);
+    lstore(ra0, rw0, smem);
+    if (nloc > 1) gload(ra0, rw0, 1);
+    if (nloc > 2) gload(ra1, rw1, 2);
     __syncthreads();
 
     const int fragA = (wr * (BM / 2) + (lane & 31)) * LDS_ROW + 16 * (lane >> 5);
     const int fragW = BM * LDS_ROW + (wc * (BN / 2) + (lane & 31)) * LDS_ROW + 16 * (lane >> 5);
 
-    const int nloc = kt1 - kt0;
-    for (int kt = 0; kt < nloc; ++kt) {
-        const char* cur = smem + (kt & 1) * BUF;
-        char* nxt = smem + ((kt + 1) & 1) * BUF;
-        const bool more = kt + 1 < nloc;
-        if (more) {
-            const long long ko = (long long)(kt + 1) * 128;
-#pragma unroll
-            for (int i = 0; i < A_CH; ++i) ra[i] = *(const u32x4*)(a_src[i] + ko);
-#pragma unroll
-            for (int i = 0; i < W_CH; ++i) rw[i] = *(const u32x4*)(w_src[i] + ko);
-        }
+    auto compute = [&](const char* cur) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             u32x4 fa[TM], fw[TN];
@@ -158,13 +160,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                     }
                 }
         }
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < A_CH; ++i) *(u32x4*)(nxt + a_dst[i]) = ra[i];
-#pragma unroll
-            for (int i = 0; i < W_CH; ++i) *(u32x4*)(nxt + w_dst[i]) = rw[i];
-        }
+    };
+    // step kt: multiply tile kt; park tile kt+1 (held in `ra`) in the other LDS buffer; refill `ra` with kt+3
+    auto step = [&](u32x4* ra, u32x4* rw, int kt) {
+        compute(smem + (kt & 1) * BUF);
+        if (kt + 1 < nloc) lstore(ra, rw, smem + ((kt + 1) & 1) * BUF);
         __syncthreads();
+        if (kt + 3 < nloc) gload(ra, rw, kt + 3);
+    };
+    for (int kt = 0; kt < nloc; kt += 2) {
+        step(ra0, rw0, kt);
+        if (kt + 1 < nloc) step(ra1, rw1, kt + 1);
     }
 
     // epilogue.  acc[i][j][reg]: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31 of the 32x32 tile
@@ -244,9 +250,9 @@ static void launch_epi(const GemmP& p, hipStream_t st) {
         const long long tiles = (long long)((p.M + 63) / 64) * (p.N / 64);
         const int nkt = (int)((long long)p.K * sizeof(T) / 128);
         int S = 1;
-        if (sizeof(T) == 4 && p.ws && tiles < 384) {
-            S = (int)((767 + tiles) / tiles);
-            if (S > nkt / 2) S = nkt / 2;
+        if (sizeof(T) == 4 && p.ws && tiles < 768) {
+            S = (int)((1023 + tiles) / tiles);
+            if (S > nkt / 4) S = nkt / 4;
             if (S > 16) S = 16;
             while (S > 1 && (long long)S * p.M * p.N * 4 > p.ws_bytes) --S;
         }

@@ -136,19 +136,115 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
     for (int kt = 0; kt < nkt; ++kt) {
         const char* cur = smem + (kt & 1) * BUF;
         if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+        if constexpr (TM == 4 && TN == 2) {
+            // Hand-scheduled stage (hipcc serialises this loop with lgkmcnt(0) after every few reads): two
+            // fragment register sets; the 6 ds_read_b128 of k-step s+1 are in flight under the 8 MFMAs of
+            // k-step s, waits are counted (lgkmcnt(6) = "all but the newest set").
+            const unsigned lb = (unsigned)(size_t)(lptr_t)smem + (unsigned)((kt & 1) * BUF);
+            const unsigned aA0 = lb + fragA + foff[0], aA1 = lb + fragA + foff[1], aA2 = lb + fragA + foff[2],
+                           aA3 = lb + fragA + foff[3];
+            const unsigned aW0 = lb + fragW + foff[0], aW1 = lb + fragW + foff[1], aW2 = lb + fragW + foff[2],
+                           aW3 = lb + fragW + foff[3];
+            u32x4 t0, t1, t2, t3, t4, t5, u0, u1, u2, u3, u4, u5;
+            asm volatile(
+                "ds_read_b128 %8, %20\n\t"
+                "ds_read_b128 %9, %20 offset:4096\n\t"
+                "ds_read_b128 %10, %20 offset:8192\n\t"
+                "ds_read_b128 %11, %20 offset:12288\n\t"
+                "ds_read_b128 %12, %24\n\t"
+                "ds_read_b128 %13, %24 offset:4096\n\t"
+                "ds_read_b128 %14, %21\n\t"
+                "ds_read_b128 %15, %21 offset:4096\n\t"
+                "ds_read_b128 %16, %21 offset:8192\n\t"
+                "ds_read_b128 %17, %21 offset:12288\n\t"
+                "ds_read_b128 %18, %25\n\t"
+                "ds_read_b128 %19, %25 offset:4096\n\t"
+                "s_waitcnt lgkmcnt(6)\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, %8, %12, %0\n\t"
+                "v_mfma_f32_32x32x16_bf16 %1, %8, %13, %1\n\t"
+                "v_mfma_f32_32x32x16_bf16 %2, %9, %12, %2\n\t"
+                "v_mfma_f32_32x32x16_bf16 %3, %9, %13, %3\n\t"
+                "v_mfma_f32_32x32x16_bf16 %4, %10, %12, %4\n\t"
+                "v_mfma_f32_32x32x16_bf16 %5, %10, %13, %5\n\t"
+                "v_mfma_f32_32x32x16_bf16 %6, %11, %12, %6\n\t"
+                "v_mfma_f32_32x32x16_bf16 %7, %11, %13, %7\n\t"
+                "ds_read_b128 %8, %22\n\t"
+                "ds_read_b128 %9, %22 offset:4096\n\t"
+                "ds_read_b128 %10, %22 offset:8192\n\t"
+                "ds_read_b128 %11, %22 offset:12288\n\t"
+                "ds_read_b128 %12, %26\n\t"
+                "ds_read_b128 %13, %26 offset:4096\n\t"
+                "s_waitcnt lgkmcnt(6)\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, %14, %18, %0\n\t"
+                "v_mfma_f32_32x32x16_bf16 %1, %14, %19, %1\n\t"
+                "v_mfma_f32_32x32x16_bf16 %2, %15, %18, %2\n\t"
+                "v_mfma_f32_32x32x16_bf16 %3, %15, %19, %3\n\t"
+                "v_mfma_f32_32x32x16_bf16 %4, %16, %18, %4\n\t"
+                "v_mfma_f32_32x32x16_bf16 %5, %16, %19, %5\n\t"
+                "v_mfma_f32_32x32x16_bf16 %6, %17, %18, %6\n\t"
+                "v_mfma_f32_32x32x16_bf16 %7, %17, %19, %7\n\t"
+                "ds_read_b128 %14, %23\n\t"
+                "ds_read_b128 %15, %23 offset:4096\n\t"
+                "ds_read_b128 %16, %23 offset:8192\n\t"
+                "ds_read_b128 %17, %23 offset:12288\n\t"
+                "ds_read_b128 %18, %27\n\t"
+                "ds_read_b128 %19, %27 offset:4096\n\t"
+                "s_waitcnt lgkmcnt(6)\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, %8, %12, %0\n\t"
+                "v_mfma_f32_32x32x16_bf16 %1, %8, %13, %1\n\t"
+                "v_mfma_f32_32x32x16_bf16 %2, %9, %12, %2\n\t"
+                "v_mfma_f32_32x32x16_bf16 %3, %9, %13, %3\n\t"
+                "v_mfma_f32_32x32x16_bf16 %4, %10, %12, %4\n\t"
+                "v_mfma_f32_32x32x16_bf16 %5, %10, %13, %5\n\t"
+                "v_mfma_f32_32x32x16_bf16 %6, %11, %12, %6\n\t"
+                "v_mfma_f32_32x32x16_bf16 %7, %11, %13, %7\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, %14, %18, %0\n\t"
+                "v_mfma_f32_32x32x16_bf16 %1, %14, %19, %1\n\t"
+                "v_mfma_f32_32x32x16_bf16 %2, %15, %18, %2\n\t"
+                "v_mfma_f32_32x32x16_bf16 %3, %15, %19, %3\n\t"
+                "v_mfma_f32_32x32x16_bf16 %4, %16, %18, %4\n\t"
+                "v_mfma_f32_32x32x16_bf16 %5, %16, %19, %5\n\t"
+                "v_mfma_f32_32x32x16_bf16 %6, %17, %18, %6\n\t"
+                "v_mfma_f32_32x32x16_bf16 %7, %17, %19, %7\n\t"
+                : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]),
+                  "+v"(acc[3][0]), "+v"(acc[3][1]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5),
+                  "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(u4), "=&v"(u5)
+                : "v"(aA0), "v"(aA1), "v"(aA2), "v"(aA3), "v"(aW0), "v"(aW1), "v"(aW2), "v"(aW3)
+                : "memory");
+            if (kt + 1 == nkt) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA results -> VALU readers
+            __syncthreads();
+            continue;
+        }
+        // software-pipelined fragments: the ds_reads of k-step s+1 are issued before the MFMAs of k-step s,
+        // one read per MFMA slot (sched_group_barrier), so LDS latency hides under the matrix pipe
+        u32x4 fa[2][TM], fw[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = *(const u32x4*)(cur + fragA + i * 32 * 128 + foff[0]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fw[0][j] = *(const u32x4*)(cur + fragW + j * 32 * 128 + foff[0]);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            u32x4 fa[TM], fw[TN];
+            if (s < 3) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4*)(cur + fragA + i * 32 * 128 + foff[s]);
+                for (int i = 0; i < TM; ++i) fa[(s + 1) & 1][i] = *(const u32x4*)(cur + fragA + i * 32 * 128 + foff[s + 1]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fw[j] = *(const u32x4*)(cur + fragW + j * 32 * 128 + foff[s]);
+                for (int j = 0; j < TN; ++j) fw[(s + 1) & 1][j] = *(const u32x4*)(cur + fragW + j * 32 * 128 + foff[s + 1]);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fw[j]), acc[i][j], 0, 0, 0);
+                        __builtin_bit_cast(bf16x8, fa[s & 1][i]), __builtin_bit_cast(bf16x8, fw[s & 1][j]), acc[i][j], 0, 0, 0);
+            if (s < 3) {
+#pragma unroll
+                for (int x = 0; x < TM + TN; ++x) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                }
+                if constexpr (TM * TN > TM + TN) __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+            }
         }
         __syncthreads();
     }

@@ -14,6 +14,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -90,6 +91,7 @@ struct Plan {
 struct EventPair {
     hipEvent_t a, b;
     double flops;
+    int dt;
 };
 
 }  // namespace
@@ -128,6 +130,16 @@ struct m3pc_handle {
     float* splitk_ws = nullptr;   // raw split-K slabs of the few-row fp32 GEMMs
     long long splitk_ws_bytes = 0;
     bool policy_valid = false;    // loc/sd/rtok hold the last plan_step's policy pass
+    // two-stream candidate halves: the workspace pointers above are VIEWS that set_view() re-bases per half
+    struct Base {
+        float *X, *Y, *EncOut, *G, *cand, *pred[2], *qv, *splitk_ws;
+        char *Hn, *QKV, *O, *F, *Z;
+        long long splitk_ws_bytes;
+    } base;
+    bool two_stream = true;
+    bool allow_splitk = true;     // see gemm(): off while sharded candidates are scored
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::map<std::string, std::unique_ptr<Plan>> plans;
     // profiling
     bool prof = false;
@@ -148,6 +160,28 @@ int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(M3PC_EHIP, "kernel launch failed in %s: %s", what, hipGetErrorString(e));
     return 0;
+}
+
+// Re-base the workspace views at candidate c0 (each candidate owns 2T workspace rows).
+void set_view(m3pc_handle* h, int c0, int /*n*/) {
+    const size_t rows = (size_t)c0 * 2 * h->T, d = (size_t)h->d;
+    const m3pc_handle::Base& b = h->base;
+    h->X = b.X + rows * d;
+    h->Y = b.Y + rows * d;
+    h->EncOut = b.EncOut + rows * d;
+    h->G = b.G + rows * d;
+    h->Hn = b.Hn + rows * d * 4;
+    h->QKV = b.QKV + rows * 3 * d * 4;
+    h->O = b.O + rows * d * 4;
+    h->F = b.F + rows * 4 * d * 4;
+    h->Z = b.Z + rows * d * 4;
+    h->cand = b.cand + (size_t)c0 * h->T * h->A;
+    h->pred[0] = b.pred[0] + (size_t)c0 * h->T * 32;
+    h->pred[1] = b.pred[1] + (size_t)c0 * h->T * 32;
+    h->qv = b.qv + (size_t)c0 * h->T;
+    const long long half = b.splitk_ws_bytes / 2;
+    h->splitk_ws = c0 == 0 ? b.splitk_ws : b.splitk_ws + half / 4;
+    h->splitk_ws_bytes = half;
 }
 
 Tensor& W(m3pc_handle* h, const std::string& n) { return h->w.at(n); }
@@ -216,7 +250,7 @@ struct GemmTimer {
     m3pc_handle* h;
     hipStream_t st;
     EventPair* e = nullptr;
-    GemmTimer(m3pc_handle* h_, hipStream_t st_, double flops) : h(h_), st(st_) {
+    GemmTimer(m3pc_handle* h_, hipStream_t st_, double flops, int dt) : h(h_), st(st_) {
         if (!h->prof) return;
         if (h->ev_used == h->ev.size()) {
             EventPair n;
@@ -226,6 +260,7 @@ struct GemmTimer {
         }
         e = &h->ev[h->ev_used++];
         e->flops = flops;
+        e->dt = dt;
         hipEventRecord(e->a, st);
     }
     ~GemmTimer() {
@@ -235,9 +270,11 @@ struct GemmTimer {
 
 void gemm(m3pc_handle* h, const GemmP& p_in, int dt, hipStream_t st) {
     GemmP p = p_in;
-    p.ws = h->splitk_ws;
+    // split-K changes the association of the K sum, so it is only allowed where every rank / shard runs the
+    // same row count (policy pass, generic forward, top-k re-score): sharded candidate scores stay bit-identical
+    p.ws = h->allow_splitk ? h->splitk_ws : nullptr;
     p.ws_bytes = h->splitk_ws_bytes;
-    GemmTimer t(h, st, 2.0 * p.M * (double)p.N * p.K);
+    GemmTimer t(h, st, 2.0 * p.M * (double)p.N * p.K, dt);
     launch_gemm(p, dt, st);
 }
 
@@ -414,7 +451,7 @@ struct TokIn {
 };
 
 // embed + encoder stack + encoder.norm -> EncOut (fp32) [and bf16 copy in Z when dt == bf16 and want_b]
-int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hipStream_t st) {
+int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hipStream_t st, bool bf16_out_only = false) {
     EmbedP e;
     memset(&e, 0, sizeof(e));
     for (int k = 0; k < 4; ++k) {
@@ -443,7 +480,10 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
     ln.d = h->d;
     ln.g1 = W(h, "encoder.norm.weight").f;
     ln.b1 = W(h, "encoder.norm.bias").f;
-    ln.Yf = h->EncOut;
+    if (bf16_out_only)
+        ln.Yb = (bf16_t*)h->Z;  // the candidate pass consumes the encoder output only as a bf16 GEMM operand
+    else
+        ln.Yf = h->EncOut;
     launch_layernorm(ln, st);
     return check_launch("encoder");
 }
@@ -720,14 +760,10 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     in.normalize[M3PC_ACTIONS] = h->tok_norm[M3PC_ACTIONS];
     in.ptr[M3PC_REWARDS] = rewards;
     in.ptr[M3PC_RETURNS] = h->rtok;
-    CHK(run_encoder(h, pl, in, n, dt, st));
+    CHK(run_encoder(h, pl, in, n, dt, st, dt == DT_BF16));
 
     // decoder inputs of the un-masked tokens (kept sets are prefixes 0..kept-1 for the fd mask)
-    const void* enc_op = h->EncOut;
-    if (dt == DT_BF16) {
-        launch_f32_to_bf16(h->EncOut, (bf16_t*)h->Z, (long long)n * Le * d, st);
-        enc_op = h->Z;
-    }
+    const void* enc_op = dt == DT_BF16 ? h->Z : (const void*)h->EncOut;
     for (int k = 0; k < 2; ++k) {
         if (!pl->kept[k]) continue;
         RowMap mm{pl->kept[k], Le, pl->enc_off[k]};
@@ -982,6 +1018,13 @@ int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out) {
     CHK(dmalloc(&h->sa_buf, (size_t)D.max_candidates * T * h->A));
     h->splitk_ws_bytes = 64LL << 20;
     CHK(dmalloc(&h->splitk_ws, (size_t)(h->splitk_ws_bytes / 4)));
+    h->base = m3pc_handle::Base{h->X, h->Y, h->EncOut, h->G, h->cand, {h->pred[0], h->pred[1]}, h->qv, h->splitk_ws,
+                                (char*)h->Hn, (char*)h->QKV, (char*)h->O, (char*)h->F, (char*)h->Z, h->splitk_ws_bytes};
+    set_view(h.get(), 0, D.max_candidates);
+    HIPCHK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    if (const char* e = getenv("M3PC_TWO_STREAM")) h->two_stream = atoi(e) != 0;
     if (D.critic_hidden > 0) {
         const int Hd = D.critic_hidden, SA = h->S + h->A;
         for (int i = 0; i < 2; ++i) {
@@ -1015,8 +1058,12 @@ int m3pc_destroy(m3pc_handle* h) {
         hipFree(h->tok_std[k]);
     }
     hipFree(h->mask_tokens);
-    void* bufs[] = {h->X, h->Y, h->EncOut, h->G, h->Hn, h->QKV, h->O, h->F, h->Z, h->cand, h->loc, h->sd, h->rtok,
-                    h->pred[0], h->pred[1], h->qv, h->sel_scratch, h->d_topk, h->er_top, h->sa_buf, h->splitk_ws, h->c_om, h->c_os};
+    const m3pc_handle::Base& bs = h->base;
+    void* bufs[] = {bs.X, bs.Y, bs.EncOut, bs.G, bs.Hn, bs.QKV, bs.O, bs.F, bs.Z, bs.cand, h->loc, h->sd, h->rtok,
+                    bs.pred[0], bs.pred[1], bs.qv, h->sel_scratch, h->d_topk, h->er_top, h->sa_buf, bs.splitk_ws, h->c_om, h->c_os};
+    if (h->aux) hipStreamDestroy(h->aux);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     for (void* b : bufs)
         if (b) hipFree(b);
     for (int i = 0; i < 2; ++i) {
@@ -1178,6 +1225,7 @@ int m3pc_forward(m3pc_handle* h, int batch, const float* const tokens[4], const 
         in.ptr[k] = tokens[k];
         in.bstride[k] = (long long)h->T * h->feat[k];
     }
+    h->allow_splitk = true;
     return forward_impl(h, pl, in, batch, out_states, out_rewards, out_returns, out_mu, out_std,
                         precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32, (hipStream_t)stream);
 }
@@ -1225,7 +1273,9 @@ int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     in.ptr[M3PC_REWARDS] = rewards;
     in.normalize[M3PC_REWARDS] = h->tok_norm[M3PC_REWARDS];
     in.ptr[M3PC_RETURNS] = h->rtok;
+    h->allow_splitk = true;
     CHK(forward_impl(h, pl, in, 1, nullptr, nullptr, nullptr, h->loc, h->sd, DT_F32, st));
+    h->allow_splitk = false;
     if (loc) HIPCHK(hipMemcpyAsync(loc, h->loc, (size_t)T * h->A * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (std_) HIPCHK(hipMemcpyAsync(std_, h->sd, (size_t)T * h->A * sizeof(float), hipMemcpyDeviceToDevice, st));
     h->policy_valid = true;
@@ -1248,9 +1298,31 @@ int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     sp.sample_actions = sample_actions;
     launch_sample(sp, st);
 
-    // PASS 2 + scoring
-    return candidate_pass(h, a, states, rewards, a->n_count, sample_actions, expect_return, pred_rewards, pred_boot,
-                          a->precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32, st);
+    // PASS 2 + scoring.  Large bf16 batches are cut into two candidate halves that run the same kernel chain
+    // on two HIP streams over disjoint workspace halves: while one half is in an MFMA-bound GEMM the other
+    // is typically in an HBM-bound LayerNorm / attention / epilogue-heavy kernel, so matrix cores and HBM
+    // are both kept busy.  Candidates are independent, results are identical to the one-stream order.
+    const int dt = a->precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32;
+    const int n = a->n_count;
+    if (h->two_stream && dt == DT_BF16 && n >= 512) {
+        const int n0 = ((n / 2 + 127) / 128) * 128, n1 = n - n0;
+        HIPCHK(hipEventRecord(h->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+        int rc = 0;
+        set_view(h, 0, n0);
+        rc = candidate_pass(h, a, states, rewards, n0, sample_actions, expect_return, pred_rewards, pred_boot, dt, st);
+        if (rc == 0) {
+            set_view(h, n0, n1);
+            rc = candidate_pass(h, a, states, rewards, n1, sample_actions + (size_t)n0 * hh * h->A, expect_return + n0,
+                                pred_rewards ? pred_rewards + (size_t)n0 * hh : nullptr,
+                                pred_boot ? pred_boot + (size_t)n0 * hh : nullptr, dt, h->aux);
+        }
+        set_view(h, 0, h->dm.max_candidates);
+        HIPCHK(hipEventRecord(h->ev_join, h->aux));
+        HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
+        return rc;
+    }
+    return candidate_pass(h, a, states, rewards, n, sample_actions, expect_return, pred_rewards, pred_boot, dt, st);
 }
 
 int m3pc_rescore(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* actions, const float* rewards,
@@ -1281,7 +1353,10 @@ int m3pc_rescore(m3pc_handle* h, const m3pc_plan_args* a, const float* states, c
     sp.cand = h->cand;
     sp.sample_actions = sa;
     launch_sample(sp, st);
-    return candidate_pass(h, a, states, rewards, n, sa, expect_return, nullptr, nullptr, DT_F32, st);
+    h->allow_splitk = true;
+    const int rc = candidate_pass(h, a, states, rewards, n, sa, expect_return, nullptr, nullptr, DT_F32, st);
+    h->allow_splitk = false;
+    return rc;
 }
 
 int m3pc_rescore_topk(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* actions,
@@ -1347,18 +1422,21 @@ int m3pc_profile_enable(m3pc_handle* h, int enable) {
     return 0;
 }
 
-int m3pc_profile_read(m3pc_handle* h, long long* launches, double* gemm_ms, double* gemm_flops, int reset) {
+int m3pc_profile_read(m3pc_handle* h, int precision, long long* launches, double* gemm_ms, double* gemm_flops, int reset) {
     if (!h) return fail(M3PC_EINVAL, "null handle");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
     double ms = 0, fl = 0;
+    long long cnt = 0;
     for (size_t i = 0; i < h->ev_used; ++i) {
+        if (precision >= 0 && h->ev[i].dt != (precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32)) continue;
         float t = 0.f;
         HIPCHK(hipEventElapsedTime(&t, h->ev[i].a, h->ev[i].b));
         ms += t;
         fl += h->ev[i].flops;
+        ++cnt;
     }
-    if (launches) *launches = (long long)h->ev_used;
+    if (launches) *launches = cnt;
     if (gemm_ms) *gemm_ms = ms;
     if (gemm_flops) *gemm_flops = fl;
     if (reset) h->ev_used = 0;

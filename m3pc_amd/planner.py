@@ -36,7 +36,7 @@ def _cfg_get(cfg, name, default=None):
 class HipPlanner:
     def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], tokenizer_manager, q_state_dict=None,
                  obs_mean=None, obs_std=None, n_embd: int = 512, n_head: int = 4, n_enc_layer: int = 2,
-                 n_dec_layer: int = 1, precision: str = "fp32", rescore_topk: int = 32, device: Optional[int] = None,
+                 n_dec_layer: int = 1, precision: str = "fp32", rescore_topk: int = 16, device: Optional[int] = None,
                  group=None, generator: Optional[torch.Generator] = None):
         """cfg: any object with traj_length, action_samples, horizon, discount, temperature, lmbda,
         plan_guidance (finetune.py RunConfig fields read at learner.py:276,319,342).
@@ -206,7 +206,7 @@ def _param_version(module) -> int:
     return sum(int(p._version) for p in module.parameters())
 
 
-def attach(learner, precision: str = "fp32", rescore_topk: int = 32, group=None):
+def attach(learner, precision: str = "fp32", rescore_topk: int = 16, group=None):
     """Rebind the plan path of a reference-style ``Learner`` onto the HIP library.
 
     Reads: learner.cfg, learner.mtm (state_dict + config), learner.tokenizer_manager.tokenizers[k]
