@@ -172,7 +172,7 @@ def main():
     peak = MFMA_PEAK_TFLOPS[args.precision]
     f_step = alg_flops(n_local, T, H, S, A)
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None,
+                "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.precision),
                 "kernel": f"m3pc::gemm_glds_kernel / gemm_kernel, the {args.precision} MFMA GEMM launches of the candidate pass",
                 "all_gemm_ms_per_step": all_ms / args.steps, "all_gemm_launches_per_step": all_launches / args.steps,
                 "flops_per_launch": gemm_flops / max(launches, 1), "avg_launch_us": 1e3 * gemm_ms / max(launches, 1),
@@ -198,6 +198,25 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def pmc_traffic(precision):
+    """HBM bytes per launch of the dominant kernel class, from the committed rocprofv3 PMC passes of this same
+    command (profiles/pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950-corrected); PMC counters
+    cannot be read from inside the process, so this is the launch-weighted mean of that profile, or null."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if precision != "bf16" or not os.path.exists(path):
+        return None
+    try:
+        ks = json.load(open(path))["kernels"]
+    except Exception:
+        return None
+    n = b = 0
+    for name, v in ks.items():
+        if "gemm_glds_kernel" in name or "gemm_kernelIDF16b" in name:
+            n += v["launches_profiled"]
+            b += v["launches_profiled"] * v["hbm_bytes_per_launch"]
+    return int(b / n) if n else None
 
 
 def mdist_count(n, rank, world):
