@@ -109,6 +109,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
     // residual prefetch (same element order as the epilogue)
     float rres[(EPI & EPI_RES) ? TM * 16 * TN : 1];
     if constexpr (EPI & EPI_RES) {
+        if (p.cmap.rpg == 0 && row0 + BM <= p.M) {  // scalar row offsets, one per-lane offset (gemm_epilogue.h)
+            const long long rb = (long long)p.M * p.ldr * 4;
+            const __amdgpu_buffer_rsrc_t rrs =
+                __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, rb > 0xfffff000ll ? 0xfffff000u : (unsigned)rb, 0x00020000);
+            const int wu = __builtin_amdgcn_readfirstlane(wid);
+            const int rbase = row0 + (wu / WN) * WTM, cbase = col0 + (wu % WN) * WTN;
+            const int vo_r = (4 * (lane >> 5) * p.ldr + (lane & 31)) * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int so_r = ((rbase + i * 32 + (reg & 3) + 8 * (reg >> 2)) * p.ldr + cbase) * 4;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        rres[(i * 16 + reg) * TN + j] =
+                            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, vo_r + j * 128, so_r, 0));
+                }
+        } else
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -252,6 +270,37 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
     float bj[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) bj[j] = p.bias ? p.bias[col0 + wc * WTN + j * 32 + l31] : 0.f;
+    if (p.cmap.rpg == 0 && row0 + BM <= p.M && !(EPI & EPI_ROWTAB)) {
+        // full tile, identity row map: scalar row offset (buffer soffset) + one per-lane offset (voffset);
+        // see gemm_epilogue.h.  The residual comes from the registers prefetched before the K loop.
+        constexpr int ES = (EPI & EPI_F32OUT) ? 4 : 2;
+        void* cptr = (EPI & EPI_F32OUT) ? (void*)p.Cf : (void*)p.Cb;
+        const long long cb = (long long)p.M * p.ldc * ES;
+        const __amdgpu_buffer_rsrc_t crs =
+            __builtin_amdgcn_make_buffer_rsrc(cptr, 0, cb > 0xfffff000ll ? 0xfffff000u : (unsigned)cb, 0x00020000);
+        const int wu = __builtin_amdgcn_readfirstlane(wid);
+        const int rbase = row0 + (wu / WN) * WTM, cbase = col0 + (wu % WN) * WTN;
+        const int vo_c = (4 * lh * p.ldc + l31) * ES;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int so_c = ((rbase + i * 32 + (reg & 3) + 8 * (reg >> 2)) * p.ldc + cbase) * ES;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float v = acc[i][j][reg] + bj[j];
+                    if constexpr (EPI & EPI_GELU) v = gelu_fast2(v);
+                    if constexpr (EPI & EPI_RES) v += rres[(i * 16 + reg) * TN + j];
+                    if constexpr (EPI & EPI_F32OUT)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, vo_c + j * 128, so_c, 0);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16_t)v), crs, vo_c + j * 64,
+                                                              so_c, 0);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -307,12 +356,9 @@ bool launch_gemm_glds(const GemmP& p, hipStream_t st) {
     if (p.variant == 5 && p.N % 256 == 0) return launch_tile<256, 256, 2, 4>(p, st);
     if (p.variant == 6) return launch_tile<256, 128, 4, 2>(p, st);
     if (p.variant == 3) return launch_tile<128, 128, 2, 2>(p, st);
-    // default selection (measured with tools/gemm_bench.py on the plan step's shapes): wide outputs
-    // (N >= 1024) run fastest on 256x256 tiles with 8 waves -- 4x less L2->LDS traffic per flop; the
-    // N = 512 GEMMs (out-proj, FFN2, heads) would leave the chip half empty with so few 256-wide tiles and
-    // stay on 128x128 tiles.
-    if (p.N % 256 == 0 && p.N >= 1024 && (long long)((p.M + 255) / 256) * (p.N / 256) >= 256)
-        return launch_tile<256, 256, 2, 4>(p, st);
+    // default selection (measured with tools/gemm_bench.py on the plan step's shapes, after the epilogue's
+    // address arithmetic moved to scalar registers): 128x128 tiles at two workgroups per CU win or tie on every
+    // shape -- one workgroup's epilogue (VALU + stores) runs beside the other's MFMAs.
     return launch_tile<128, 128, 2, 2>(p, st);
 }
 

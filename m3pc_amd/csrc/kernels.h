@@ -47,6 +47,7 @@ struct GemmP {
 };
 void launch_gemm(const GemmP& p, int dtype, hipStream_t st);
 bool launch_gemm_ring(const GemmP& p, hipStream_t st);  // bf16, many rows: 256x256 tile, 4-slot LDS-DMA ring (gemm_ring.hip)
+bool launch_gemm_persist(const GemmP& p, hipStream_t st);  // bf16, many rows: persistent 256x256 tiles (gemm_persist.hip)
 bool launch_gemm_glds(const GemmP& p, hipStream_t st);  // bf16, many rows: direct-to-LDS staging (gemm_glds.hip)
 
 // LayerNorm over the last dim (eps 1e-5), one wave per row; optional second LayerNorm applied to

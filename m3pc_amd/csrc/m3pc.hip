@@ -136,7 +136,7 @@ struct m3pc_handle {
         char *Hn, *QKV, *O, *F, *Z;
         long long splitk_ws_bytes;
     } base;
-    bool two_stream = true;
+    bool two_stream = false;      // M3PC_TWO_STREAM=1: measured +2.5 % on C2, off by default to keep per-kernel timings clean
     bool allow_splitk = true;     // see gemm(): off while sharded candidates are scored
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

@@ -182,6 +182,81 @@ class HipPlanner:
         eval_action = dist_.mean[0, T - h]
         return sample_action, eval_action
 
+    # ---------------------------------------------------------------------------------------- zero-shot
+    def assemble_goal_window(self, sequence_history, rtg=None, percentage=1.0):
+        """research/zeroshot_omtm/learner.py:164-223: the history window, with the observation rows of the
+        WHOLE window taken from the buffer (future rows are way-points), shortened near the 1000-step end."""
+        T = self.T
+        horizon = int(self.cfg.horizon)
+        end_idx = int(sequence_history["path_length"])
+        if end_idx + horizon < T:
+            horizon = T - end_idx
+        smart = T
+        if end_idx + horizon > 1000:
+            smart = smart - (end_idx + horizon - 1000)
+        hl = T - horizon + 1
+        buf = self._host
+        buf[:] = 0.0
+        lo = end_idx - hl + 1
+        buf[:hl, self.S : self.S + self.A] = sequence_history["actions"][lo : end_idx + 1]
+        buf[:hl, self.S + self.A :] = np.asarray(sequence_history["rewards"][lo : end_idx + 1]).reshape(hl, 1)
+        buf[:hl, : self.S] = sequence_history["observations"][lo : end_idx + 1]
+        buf[:smart, : self.S] = sequence_history["observations"][lo : lo + T]
+        dev = torch.from_numpy(buf).to(self.device)
+        states = dev[:, : self.S].contiguous()
+        actions = dev[:, self.S : self.S + self.A].contiguous()
+        rewards = dev[:, self.S + self.A :].contiguous()
+        if rtg is not None:
+            return_to_go = float(rtg)
+        else:
+            st = self.tokenizer_manager.tokenizers["returns"].stats
+            return_to_go = float(np.asarray(st.min + (st.max - st.min) * percentage).reshape(-1)[0])
+        return states, actions, rewards, horizon, return_to_go
+
+    def _goal_tokens(self, states, actions, rewards, rtg):
+        T = self.T
+        ret = torch.full((1, T, 1), rtg, dtype=torch.float64, device=self.device)
+        return [self.handle.tokenize(capi.STATES, states[None]), actions[None].contiguous(),
+                self.handle.tokenize(capi.REWARDS, rewards[None]), self.handle.tokenize(capi.RETURNS, ret)]
+
+    def _policy_from(self, toks, masks, h, eval):
+        from .masks import mask_rows
+        mu, sd = self.handle.forward(toks, mask_rows(masks), want=("actions",))["actions"]
+        dist_ = SquashedNormal(mu.unsqueeze(2), sd.unsqueeze(2))
+        if eval:
+            return dist_.mean[0, self.T - h]
+        return dist_.sample(eps=self._eps(tuple(dist_.loc.shape)))[0, self.T - h]
+
+    @torch.no_grad()
+    def action_id_sample(self, sequence_history, percentage=1.0, horizon=4, plan=True, eval=False, rtg=None):
+        """zeroshot learner.py:60-149: one forward under the goal inverse-dynamics mask."""
+        if eval:
+            assert rtg is not None
+        from .masks import create_gid_mask
+        s, a, r, h, rtg_v = self.assemble_goal_window(sequence_history, rtg, percentage)
+        toks = self._goal_tokens(s, a, r, rtg_v)
+        return self._policy_from(toks, create_gid_mask(self.T, "cpu", self.T - h), h, eval)
+
+    @torch.no_grad()
+    def action_piid_sample(self, sequence_history, percentage=1.0, horizon=4, plan=True, eval=False, rtg=None):
+        """zeroshot learner.py:151-261: path inference (pi mask) -> write the inferred states into the
+        window -> inverse dynamics (fid mask) -> action at T-h."""
+        if eval:
+            assert rtg is not None
+        from .masks import create_fid_mask, create_pi_mask, mask_rows
+        T = self.T
+        s, a, r, h, rtg_v = self.assemble_goal_window(sequence_history, rtg, percentage)
+        idx = T - h
+        toks = self._goal_tokens(s, a, r, rtg_v)
+        raw = self.handle.forward(toks, mask_rows(create_pi_mask(T, "cpu", idx)), want=("states",))["states"]
+        inferred = self.handle.detokenize(capi.STATES, raw)  # (1,T,S)
+        s = s.clone()
+        s[idx + 2 : T - 1] = inferred[0, idx + 2 : T - 1]
+        s[: idx + 1] = inferred[0, : idx + 1]
+        toks[0] = self.handle.tokenize(capi.STATES, s[None])
+        self.last = dict(state_inference=inferred, window_states=s)
+        return self._policy_from(toks, create_fid_mask(T, "cpu", idx), h, eval)
+
     @torch.no_grad()
     def action_sample(self, sequence_history, percentage=1.0, horizon=4, plan=True, eval=False, rtg=None):
         """learner.py:329-417 (the ``horizon`` argument is ignored there too: cfg.horizon rules)."""
@@ -250,7 +325,8 @@ def attach(learner, precision: str = "fp32", rescore_topk: int = 16, group=None)
         method.__name__ = name
         return types.MethodType(method, learner)
 
-    for name in ("action_sample", "rtg_guiding", "critic_lambda_guiding", "noise_adding_lambda", "mtm_sampling"):
+    for name in ("action_sample", "rtg_guiding", "critic_lambda_guiding", "noise_adding_lambda", "mtm_sampling",
+                 "action_piid_sample", "action_id_sample"):
         setattr(learner, name, _wrap(name))
     learner._hip_planner = planner
     return planner

@@ -109,6 +109,31 @@ def test_c2_bf16_with_fp32_rescore_keeps_reference_argmax():
     p.handle.close()
 
 
+@pytest.mark.parametrize("pl", [0, 2, 37, 997])
+def test_zeroshot_goal_reaching_matches_reference_golden(pl):
+    """action_piid_sample (two chained forwards) and action_id_sample on windows whose future states are the
+    reference's way-points (G3 fixture captured from research/zeroshot_omtm/learner.py)."""
+    g = np.load(os.path.join(GD, "g3_zeroshot.npz"))
+    dims = synth.Dims(11, 3, 8)
+    cfg = types.SimpleNamespace(traj_length=8, action_samples=1, horizon=4, discount=0.99, temperature=1.0, lmbda=0.6,
+                                plan_guidance="rtg_guiding", index_jump=4)
+    p = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None)
+    hist = synth.make_history(dims, 0)
+    hist["observations"] = g[f"obs_pl{pl}"]
+    hist["path_length"] = pl
+    ev = p.action_piid_sample(hist, percentage=1.0, plan=False, eval=True, rtg=2.5)
+    assert ev.shape == g[f"action_piid_sample_pl{pl}_eval_action"].shape == (1, 3)  # mean[0, T-h] of a (1,T,1,A) dist
+    assert np.abs(ev.cpu().numpy() - g[f"action_piid_sample_pl{pl}_eval_action"]).max() < 2e-5
+    si = g[f"action_piid_sample_pl{pl}_state_inference"]
+    assert np.abs(p.last["state_inference"].cpu().numpy() - si).max() <= 2e-5 * max(1.0, float(np.abs(si).max()))
+    assert np.abs(p.last["window_states"].cpu().numpy() - g[f"action_piid_sample_pl{pl}_win_states_after"][0]).max() <= 1e-4
+    ev2 = p.action_id_sample(hist, percentage=1.0, plan=False, eval=True, rtg=2.5)
+    assert np.abs(ev2.cpu().numpy() - g[f"action_id_sample_pl{pl}_eval_action"]).max() < 2e-5
+    sa = p.action_id_sample(hist, percentage=1.0, plan=False, eval=False, rtg=2.5)
+    assert sa.shape == (1, 3) and float(sa.abs().max()) <= 1.0
+    p.handle.close()
+
+
 def test_omtm_and_tokenizer_mirror_compose_like_the_reference():
     """tokenizer_manager.decode(mtm(tokenizer_manager.encode(traj), mask)) -- the reference's idiom
     (learner.py:108-111) -- on the mirror classes."""
