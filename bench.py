@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--rescore-topk", type=int, default=16)
     ap.add_argument("--strong", action="store_true", help="keep the global candidate count fixed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--env", default="hopper", choices=["hopper", "walker2d", "halfcheetah"],
+                    help="state/action dims of the D4RL family (BASELINE configs 3-4 use walker2d / halfcheetah)")
+    ap.add_argument("--guidance", default="rtg_guiding", choices=["rtg_guiding", "critic_lambda_guiding"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,15 +120,18 @@ def main():
     from m3pc_amd.planner import HipPlanner
     import types
 
-    S, A = synth.ENV_DIMS["hopper"]
+    S, A = synth.ENV_DIMS[args.env]
+    critic_mode = args.guidance == "critic_lambda_guiding"
     T, H = args.traj_length, args.horizon
     n_global = args.candidates if args.strong else args.candidates * world
     dims = synth.Dims(S, A, T)
     cfg = types.SimpleNamespace(traj_length=T, action_samples=n_global, horizon=H, discount=0.99, temperature=0.01,
-                                lmbda=0.6, plan_guidance="rtg_guiding")
+                                lmbda=0.6, plan_guidance=args.guidance)
+    cfg.temperature = 1.0 if critic_mode else 0.01  # config.yaml:79
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1)  # same seed on every rank: identical eps and multinomial draws
-    planner = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None,
+    qsd, om, os_ = synth.make_critic(dims, 0) if critic_mode else (None, None, None)
+    planner = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), qsd, om, os_,
                          precision=args.precision, rescore_topk=args.rescore_topk, device=local_rank, generator=gen)
     hist = synth.make_history(dims, 0)
     hist["path_length"] = 500
@@ -133,7 +139,7 @@ def main():
     assert h == H
 
     def step():
-        return planner._guide(capi.MODE_RTG, states, actions, rewards, rtg, h, 0.6)
+        return planner._guide(capi.MODE_CRITIC if critic_mode else capi.MODE_RTG, states, actions, rewards, rtg, h, 0.6)
 
     def barrier():
         if world > 1:
@@ -170,7 +176,7 @@ def main():
     planner.handle.profile_enable(False)
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     peak = MFMA_PEAK_TFLOPS[args.precision]
-    f_step = alg_flops(n_local, T, H, S, A)
+    f_step = alg_flops(n_local, T, H, S, A, mode="critic" if critic_mode else "rtg")
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.precision),
                 "kernel": f"m3pc::gemm_glds_kernel / gemm_kernel, the {args.precision} MFMA GEMM launches of the candidate pass",
@@ -188,7 +194,7 @@ def main():
                "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
                "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.precision,
                "data": "synthetic",
-               "config": {"workload": f"hopper-medium-v2 shapes (S={S},A={A}) rtg_guiding N={args.candidates}/GPU H={H} "
+               "config": {"workload": f"{args.env}-medium-v2 shapes (S={S},A={A}) {args.guidance} N={args.candidates}/GPU H={H} "
                                       f"T={T} {args.precision} candidate pass + fp32 policy pass + fp32 top-{args.rescore_topk} re-score",
                           "candidates_per_gpu": n_local, "global_candidates": n_global, "horizon": H, "traj_length": T,
                           "parallelism": f"candidate-shard x{world}"},

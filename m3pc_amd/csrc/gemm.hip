@@ -293,7 +293,7 @@ void launch_gemm(const GemmP& p, int dtype, hipStream_t st) {
     // few-row problems on the register-staged kernel below; variants 4-9 are the experimental tilings
     if (dtype == DT_BF16 && p.variant == 9 && launch_gemm_persist(p, st)) return;
     if (dtype == DT_BF16 && p.variant >= 7 && p.variant != 9 && launch_gemm_ring(p, st)) return;
-    if (dtype == DT_BF16 && (p.variant == 0 || (p.variant >= 3 && p.variant < 7)) && launch_gemm_glds(p, st)) return;
+    if (dtype == DT_BF16 && (p.variant == 0 || (p.variant >= 2 && p.variant < 7)) && launch_gemm_glds(p, st)) return;
     if (dtype == DT_BF16)
         launch_t<bf16_t>(p, st);
     else

@@ -41,13 +41,18 @@ __device__ __forceinline__ int map_row2(const RowMap& m, int r) {
 typedef const void __attribute__((address_space(1))) * gptr_t;
 typedef void __attribute__((address_space(3))) * lptr_t;
 
-template <int BM, int BN, int EPI, int WM, int WN>
+// ROWB = bytes of K per LDS row and stage: 128 (64 k, 4 MFMA k-steps per barrier) or 64 (32 k, 2 k-steps, half the
+// LDS => more workgroups per CU, i.e. more tiles in flight against the DMA latency)
+template <int BM, int BN, int EPI, int WM, int WN, int ROWB = 128>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
+    constexpr int RPI = 1024 / ROWB;   // tile rows per 1-KiB DMA instruction
+    constexpr int LPR = ROWB / 16;     // lanes (16-byte chunks) per row
+    constexpr int KS = ROWB / 32;      // MFMA k-steps per stage
     constexpr int NW = WM * WN;                      // waves per block, WM x WN grid of wave tiles
     constexpr int WTM = BM / WM, WTN = BN / WN;      // wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;      // 32x32 MFMA tiles per wave
-    constexpr int NI_A = BM / 8 / NW, NI_W = BN / 8 / NW;  // 1-KiB wave-instructions per wave per k-tile
-    constexpr int BUF = (BM + BN) * 128;
+    constexpr int NI_A = BM / RPI / NW, NI_W = BN / RPI / NW;  // 1-KiB wave-instructions per wave per k-tile
+    constexpr int BUF = (BM + BN) * ROWB;
     __shared__ __attribute__((aligned(1024))) char smem[2 * BUF];
 
     const int tid = threadIdx.x;
@@ -64,36 +69,36 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
     const int tm = bid / ntn, tn = bid % ntn;
     const int row0 = tm * BM, col0 = tn * BN;
     const long long lda_b = (long long)p.lda * 2, ldw_b = (long long)p.ldw * 2;
-    const int nkt = p.K / 64;
+    const int nkt = p.K * 2 / ROWB;
 
     // staging descriptors: wave-instruction I = wid + 4 i covers tile rows 8 I .. 8 I + 7
     const char* a_src[NI_A];
     const char* w_src[NI_W];
 #pragma unroll
     for (int i = 0; i < NI_A; ++i) {
-        const int r = 8 * (wid + NW * i) + (lane >> 3);
-        const int q = (lane & 7) ^ ((r >> 1) & 7);
+        const int r = RPI * (wid + NW * i) + lane / LPR;
+        const int q = (lane % LPR) ^ (ROWB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3));
         int gr = row0 + r;
         if (gr >= p.M) gr = p.M - 1;
         a_src[i] = (const char*)p.A + (long long)map_row2(p.amap, gr) * lda_b + q * 16;
     }
 #pragma unroll
     for (int i = 0; i < NI_W; ++i) {
-        const int r = 8 * (wid + NW * i) + (lane >> 3);
-        const int q = (lane & 7) ^ ((r >> 1) & 7);
+        const int r = RPI * (wid + NW * i) + lane / LPR;
+        const int q = (lane % LPR) ^ (ROWB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3));
         w_src[i] = (const char*)p.W + (long long)(col0 + r) * ldw_b + q * 16;
     }
     const int wave_dst = __builtin_amdgcn_readfirstlane(wid) * 1024;
 
     auto issue = [&](int kt, int buf) {
         char* base = smem + buf * BUF + wave_dst;
-        const long long ko = (long long)kt * 128;
+        const long long ko = (long long)kt * ROWB;
 #pragma unroll
         for (int i = 0; i < NI_A; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + ko), (lptr_t)(base + i * NW * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < NI_W; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + ko), (lptr_t)(base + BM * 128 + i * NW * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + ko), (lptr_t)(base + BM * ROWB + i * NW * 1024), 16, 0, 0);
     };
 
     issue(0, 0);
@@ -142,19 +147,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
 
     // fragment read offsets: row (lane&31), logical chunk 2s+h at position (2s+h) ^ ((row>>1)&7)
     const int l31 = lane & 31, lh = lane >> 5;
-    const int sw = (l31 >> 1) & 7;
+    const int sw = ROWB == 128 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
     int foff[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) foff[s] = l31 * 128 + (((2 * s + lh) ^ sw) * 16);
-    const int fragA = wr * WTM * 128;
-    const int fragW = BM * 128 + wc * WTN * 128;
+    for (int s = 0; s < 4; ++s) foff[s] = l31 * ROWB + (((2 * s + lh) ^ sw) * 16);
+    const int fragA = wr * WTM * ROWB;
+    const int fragW = BM * ROWB + wc * WTN * ROWB;
 
     __syncthreads();  // (the compiler drains vmcnt before a barrier while LDS-DMA is outstanding)
 
     for (int kt = 0; kt < nkt; ++kt) {
         const char* cur = smem + (kt & 1) * BUF;
         if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
-        if constexpr (TM == 4 && TN == 2) {
+        if constexpr (TM == 4 && TN == 2 && ROWB == 128) {
             // Hand-scheduled stage (hipcc serialises this loop with lgkmcnt(0) after every few reads): two
             // fragment register sets; the 6 ds_read_b128 of k-step s+1 are in flight under the 8 MFMAs of
             // k-step s, waits are counted (lgkmcnt(6) = "all but the newest set").
@@ -238,16 +243,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
         // one read per MFMA slot (sched_group_barrier), so LDS latency hides under the matrix pipe
         u32x4 fa[2][TM], fw[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[0][i] = *(const u32x4*)(cur + fragA + i * 32 * 128 + foff[0]);
+        for (int i = 0; i < TM; ++i) fa[0][i] = *(const u32x4*)(cur + fragA + i * 32 * ROWB + foff[0]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fw[0][j] = *(const u32x4*)(cur + fragW + j * 32 * 128 + foff[0]);
+        for (int j = 0; j < TN; ++j) fw[0][j] = *(const u32x4*)(cur + fragW + j * 32 * ROWB + foff[0]);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s < 3) {
+        for (int s = 0; s < KS; ++s) {
+            if (s < KS - 1) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[(s + 1) & 1][i] = *(const u32x4*)(cur + fragA + i * 32 * 128 + foff[s + 1]);
+                for (int i = 0; i < TM; ++i) fa[(s + 1) & 1][i] = *(const u32x4*)(cur + fragA + i * 32 * ROWB + foff[s + 1]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fw[(s + 1) & 1][j] = *(const u32x4*)(cur + fragW + j * 32 * 128 + foff[s + 1]);
+                for (int j = 0; j < TN; ++j) fw[(s + 1) & 1][j] = *(const u32x4*)(cur + fragW + j * 32 * ROWB + foff[s + 1]);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8, fa[s & 1][i]), __builtin_bit_cast(bf16x8, fw[s & 1][j]), acc[i][j], 0, 0, 0);
-            if (s < 3) {
+            if (s < KS - 1) {
 #pragma unroll
                 for (int x = 0; x < TM + TN; ++x) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
@@ -325,23 +330,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
     }
 }
 
-template <int BM, int BN, int EPI, int WM, int WN>
+template <int BM, int BN, int EPI, int WM, int WN, int ROWB = 128>
 static void launch_cfg(const GemmP& p, hipStream_t st) {
     const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
-    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, EPI, WM, WN>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, EPI, WM, WN, ROWB>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int ROWB = 128>
 static bool launch_tile(const GemmP& p, hipStream_t st) {
     const bool f32out = p.Cf != nullptr;
     const int epi = (p.gelu ? EPI_GELU : 0) | (p.res ? EPI_RES : 0) | (p.rowtab ? EPI_ROWTAB : 0) | (f32out ? EPI_F32OUT : 0);
     switch (epi) {
-        case 0: launch_cfg<BM, BN, 0, WM, WN>(p, st); return true;
-        case EPI_F32OUT: launch_cfg<BM, BN, EPI_F32OUT, WM, WN>(p, st); return true;
-        case EPI_GELU: launch_cfg<BM, BN, EPI_GELU, WM, WN>(p, st); return true;
-        case EPI_GELU | EPI_F32OUT: launch_cfg<BM, BN, EPI_GELU | EPI_F32OUT, WM, WN>(p, st); return true;
-        case EPI_RES | EPI_F32OUT: launch_cfg<BM, BN, EPI_RES | EPI_F32OUT, WM, WN>(p, st); return true;
-        case EPI_ROWTAB | EPI_F32OUT: launch_cfg<BM, BN, EPI_ROWTAB | EPI_F32OUT, WM, WN>(p, st); return true;
+        case 0: launch_cfg<BM, BN, 0, WM, WN, ROWB>(p, st); return true;
+        case EPI_F32OUT: launch_cfg<BM, BN, EPI_F32OUT, WM, WN, ROWB>(p, st); return true;
+        case EPI_GELU: launch_cfg<BM, BN, EPI_GELU, WM, WN, ROWB>(p, st); return true;
+        case EPI_GELU | EPI_F32OUT: launch_cfg<BM, BN, EPI_GELU | EPI_F32OUT, WM, WN, ROWB>(p, st); return true;
+        case EPI_RES | EPI_F32OUT: launch_cfg<BM, BN, EPI_RES | EPI_F32OUT, WM, WN, ROWB>(p, st); return true;
+        case EPI_ROWTAB | EPI_F32OUT: launch_cfg<BM, BN, EPI_ROWTAB | EPI_F32OUT, WM, WN, ROWB>(p, st); return true;
         default: return false;
     }
 }
@@ -356,6 +361,7 @@ bool launch_gemm_glds(const GemmP& p, hipStream_t st) {
     if (p.variant == 5 && p.N % 256 == 0) return launch_tile<256, 256, 2, 4>(p, st);
     if (p.variant == 6) return launch_tile<256, 128, 4, 2>(p, st);
     if (p.variant == 3) return launch_tile<128, 128, 2, 2>(p, st);
+    if (p.variant == 2) return launch_tile<128, 128, 2, 2, 64>(p, st);
     // default selection (measured with tools/gemm_bench.py on the plan step's shapes, after the epilogue's
     // address arithmetic moved to scalar registers): 128x128 tiles at two workgroups per CU win or tie on every
     // shape -- one workgroup's epilogue (VALU + stores) runs beside the other's MFMAs.

@@ -14,6 +14,7 @@
 // loop: it would drain the LDS-DMA queue.
 // LDS rows are 64 B; chunk position c of row r holds logical chunk c ^ ((r >> 2) & 3) (swizzle applied on the
 // global SOURCE address, the DMA writes linearly), which makes the 16-row ds_read_b128 groups conflict-free.
+#include "gemm_epilogue.h"
 #include "kernels.h"
 
 namespace m3pc {
@@ -92,7 +93,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmP p) {
     const int wave_dst = __builtin_amdgcn_readfirstlane(wid) * 1024;
 
     const bool dbg_noload = p.variant == 11 || p.variant == 12;   // timing experiments (tools/gemm_bench.py)
-    const bool dbg_nostore = p.variant == 10 || p.variant == 12;
     auto issue = [&](int st) {
         if (dbg_noload) return;
         char* base = smem + (st & 3) * STAGE + wave_dst;
@@ -161,32 +161,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmP p) {
     RING_WAIT_BARRIER(0);
     compute(nst - 1);
 
-    // epilogue.  acc[i][j][reg]: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31 of the 32x32 tile
-    float bj[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bj[j] = p.bias ? p.bias[col0 + wc * 64 + j * 32 + l31] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int r = row0 + wr * WTM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-            if (r < p.M) {
-                const long long pr = map_row3(p.cmap, r);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int c = col0 + wc * 64 + j * 32 + l31;
-                    float v = acc[i][j][reg] + bj[j];
-                    if constexpr (EPI & EPI_ROWTAB) v += p.rowtab[(long long)(r % p.rt_mod) * p.rt_ld + c];
-                    if constexpr (EPI & EPI_GELU) v = gelu_fast3(v);
-                    if constexpr (EPI & EPI_RES) v += p.res[pr * p.ldr + c];
-                    if (dbg_nostore && v != 1234.5678f) continue;
-                    if constexpr (EPI & EPI_F32OUT)
-                        p.Cf[pr * p.ldc + c] = v;
-                    else
-                        p.Cb[pr * p.ldc + c] = (bf16_t)v;
-                }
-            }
-        }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    {
+        const int wu = __builtin_amdgcn_readfirstlane(wid);
+        gemm_epilogue<EPI, TM, TN>(p, acc, row0 + (wu / WN) * WTM, col0 + (wu % WN) * 64, row0, BM, lane);
     }
 }
 
