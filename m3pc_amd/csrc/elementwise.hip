@@ -40,10 +40,53 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedP p) {
     const float* WT = p.WT[key];
     const float* E = p.E[key] + (long long)t * p.d;
     float* out = p.X + row * p.d;
-    for (int c = threadIdx.x; c < p.d; c += blockDim.x) {
-        float acc = 0.f;
-        for (int f = 0; f < D; ++f) acc = fmaf(xs[f], WT[f * p.d + c], acc);
-        out[c] = acc + E[c];
+    float vals[4];  // d <= 1024, blockDim = min(d, 256): at most 4 columns per thread (static indices)
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x + i * blockDim.x;
+        vals[i] = 0.f;
+        if (c < p.d) {
+            float acc = 0.f;
+            for (int f = 0; f < D; ++f) acc = fmaf(xs[f], WT[f * p.d + c], acc);
+            acc += E[c];
+            out[c] = acc;
+            vals[i] = acc;
+            s += acc;
+        }
+    }
+    if (!p.ln_g) return;
+    // fused LayerNorm of the row (norm1 of the first encoder layer): block-wide mean / variance
+    __shared__ float red[8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    s = wave_sum(s);
+    if (lane == 0) red[wid] = s;
+    __syncthreads();
+    float tot = 0.f;
+    for (int w = 0; w < nwv; ++w) tot += red[w];
+    const float mean = tot / (float)p.d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (threadIdx.x + i * blockDim.x < p.d) {
+            const float c = vals[i] - mean;
+            q += c * c;
+        }
+    q = wave_sum(q);
+    __syncthreads();
+    if (lane == 0) red[wid] = q;
+    __syncthreads();
+    tot = 0.f;
+    for (int w = 0; w < nwv; ++w) tot += red[w];
+    const float rstd = rsqrtf(tot / (float)p.d + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x + i * blockDim.x;
+        if (c < p.d) {
+            const float y = (vals[i] - mean) * rstd * p.ln_g[c] + p.ln_b[c];
+            if (p.Hf) p.Hf[row * p.d + c] = y;
+            if (p.Hb) p.Hb[row * p.d + c] = (bf16_t)y;
+        }
     }
 }
 void launch_embed(const EmbedP& p, hipStream_t st) {

@@ -104,6 +104,10 @@ struct EmbedP {
     const int2* tokmap;      // (L,) {key, t} of every kept token, encoder order
     int batch, L, d, T;
     float* X;                // (batch, L, d)
+    const float* ln_g;       // optional: also emit LayerNorm(X row) (the first block's norm1) ...
+    const float* ln_b;
+    float* Hf;               // ... as fp32 and/or
+    bf16_t* Hb;              // ... bf16 rows (batch*L, d)
 };
 void launch_embed(const EmbedP& p, hipStream_t st);
 

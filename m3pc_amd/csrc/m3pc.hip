@@ -371,7 +371,7 @@ void invalidate_tables(m3pc_handle* h) {
 
 // ---------------------------------------------------------------------------------- transformer block
 // One pre-LN layer (mtm_model.py:379-409) over `batch` sequences of L rows, in place on X (fp32).
-int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L, int dt, hipStream_t st) {
+int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L, int dt, hipStream_t st, bool ln1_done = false) {
     const int d = h->d, ff = h->ff;
     const int rows = batch * L;
     const int es = (int)dtype_size(dt);
@@ -388,7 +388,7 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
         ln.Yb = (bf16_t*)h->Hn;
     else
         ln.Yf = (float*)h->Hn;
-    launch_layernorm(ln, st);
+    if (!ln1_done) launch_layernorm(ln, st);  // the embedding kernel already wrote norm1(X) of the first layer
     {
         GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".self_attn.in_proj_weight", dt), d, rows, 3 * d, d,
                              W(h, pfx + ".self_attn.in_proj_bias").f);
@@ -470,8 +470,15 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
     e.d = h->d;
     e.T = h->T;
     e.X = h->X;
+    e.ln_g = W(h, "encoder.layers.0.norm1.weight").f;  // first layer's norm1 fused into the embedding
+    e.ln_b = W(h, "encoder.layers.0.norm1.bias").f;
+    if (dt == DT_BF16)
+        e.Hb = (bf16_t*)h->Hn;
+    else
+        e.Hf = (float*)h->Hn;
     launch_embed(e, st);
-    for (int i = 0; i < h->dm.n_enc_layer; ++i) CHK(run_block(h, "encoder.layers." + std::to_string(i), h->X, batch, pl->Le, dt, st));
+    for (int i = 0; i < h->dm.n_enc_layer; ++i)
+        CHK(run_block(h, "encoder.layers." + std::to_string(i), h->X, batch, pl->Le, dt, st, i == 0));
     LnP ln;
     memset(&ln, 0, sizeof(ln));
     ln.X = h->X;

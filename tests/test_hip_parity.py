@@ -235,6 +235,36 @@ def test_c2_bf16_screen_quality():
     h.close()
 
 
+# ------------------------------------------------------------------------------------ edge shapes vs the oracle
+@pytest.mark.parametrize("T,H,N,mode", [(8, 4, 625, "rtg"), (8, 4, 625, "critic"), (8, 1, 37, "rtg"), (8, 8, 130, "critic"),
+                                        (16, 5, 1, "rtg"), (8, 4, 64, "noise")])
+def test_odd_shapes_match_oracle(T, H, N, mode):
+    """The reference's shipped planning config (N=625, H=4, T=8, finetune_omtm/config.yaml:5,77-78) and ragged
+    cases: horizon 1, horizon == T (no history), a single candidate, candidate counts that are not tile
+    multiples.  fp32 path against the oracle on identical eps."""
+    dims = synth.Dims(11, 3, T)
+    h, sd, stats, critic = make_handle(dims, max_candidates=N, max_batch=1)
+    cfg = O.PlanCfg(T, H, N, 0.99, 1.0 if mode != "rtg" else 0.01, 0.6)
+    win, hh = O.assemble_window(cfg, synth.make_history(dims, 3), 300, 2.0)
+    assert hh == H
+    if mode == "noise":
+        eps = torch.randn((N, H, 3), generator=torch.Generator().manual_seed(5))
+        dev_eps = eps.cuda()
+    else:
+        eps = synth.make_eps(N, dims, 9)
+        dev_eps = eps[:, 0, :, 0, :].cuda()
+    ref = O.guiding(sd, stats, cfg, win, H, 0.6, eps, mode, critic=critic)
+    s, a, r = window_dev(win)
+    res = h.plan_step(MODES[mode], s, a, r, dev_eps, H, 2.0, 0.6, 0.99, N)
+    _assert_close(res["sample_actions"], ref["sample_actions"], 2e-5, "sample_actions")
+    scale = max(float(ref["expect_return"].abs().max()), 1.0)
+    assert float((res["expect_return"].cpu() - ref["expect_return"]).abs().max()) <= 5e-5 * scale
+    p, ev, am = h.select(res["expect_return"], res["sample_actions"][:, 0], cfg.temperature)
+    assert int(am.item()) == ref["argmax"]
+    _assert_close(ev, ref["eval_action"], 1e-4, "eval_action")
+    h.close()
+
+
 # ------------------------------------------------------------------------------------ properties at full size
 def test_sharding_is_exact():
     """Scoring candidates in shards gives bit-identical scores to one call (candidates are independent)."""
