@@ -292,8 +292,8 @@ void launch_gemm(const GemmP& p, int dtype, hipStream_t st) {
     // default (variant 0): many-row bf16 problems on the LDS-DMA kernel (gemm_glds.hip, 128x128 tiles),
     // few-row problems on the register-staged kernel below; variants 4-9 are the experimental tilings
     if (dtype == DT_BF16 && p.variant == 9 && launch_gemm_persist(p, st)) return;
-    if (dtype == DT_BF16 && p.variant >= 7 && p.variant != 9 && launch_gemm_ring(p, st)) return;
-    if (dtype == DT_BF16 && (p.variant == 0 || (p.variant >= 2 && p.variant < 7)) && launch_gemm_glds(p, st)) return;
+    if (dtype == DT_BF16 && p.variant >= 7 && p.variant != 9 && p.variant < 20 && launch_gemm_ring(p, st)) return;
+    if (dtype == DT_BF16 && (p.variant == 0 || (p.variant >= 2 && p.variant < 7) || (p.variant >= 20 && p.variant <= 23)) && launch_gemm_glds(p, st)) return;
     if (dtype == DT_BF16)
         launch_t<bf16_t>(p, st);
     else

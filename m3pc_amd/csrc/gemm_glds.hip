@@ -43,8 +43,10 @@ typedef void __attribute__((address_space(3))) * lptr_t;
 
 // ROWB = bytes of K per LDS row and stage: 128 (64 k, 4 MFMA k-steps per barrier) or 64 (32 k, 2 k-steps, half the
 // LDS => more workgroups per CU, i.e. more tiles in flight against the DMA latency)
-template <int BM, int BN, int EPI, int WM, int WN, int ROWB = 128>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
+//
+// One output tile.  `bid` is the tile's index among the `ntm` x (N / BN) tiles that cover rows [row_begin, ...).
+template <int BM, int BN, int EPI, int WM, int WN, int ROWB>
+__device__ __forceinline__ void gemm_glds_tile(const GemmP& p, char* smem, int bid, const int ntm, const int row_begin) {
     constexpr int RPI = 1024 / ROWB;   // tile rows per 1-KiB DMA instruction
     constexpr int LPR = ROWB / 16;     // lanes (16-byte chunks) per row
     constexpr int KS = ROWB / 32;      // MFMA k-steps per stage
@@ -53,21 +55,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
     constexpr int TM = WTM / 32, TN = WTN / 32;      // 32x32 MFMA tiles per wave
     constexpr int NI_A = BM / RPI / NW, NI_W = BN / RPI / NW;  // 1-KiB wave-instructions per wave per k-tile
     constexpr int BUF = (BM + BN) * ROWB;
-    __shared__ __attribute__((aligned(1024))) char smem[2 * BUF];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int wr = wid / WN, wc = wid % WN;
     const int ntn = p.N / BN;
-    const int ntm = (p.M + BM - 1) / BM;
     const int nwg = ntm * ntn;
-    int bid = blockIdx.x;
     {
         const int q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
     const int tm = bid / ntn, tn = bid % ntn;
-    const int row0 = tm * BM, col0 = tn * BN;
+    const int row0 = row_begin + tm * BM, col0 = tn * BN;
     const long long lda_b = (long long)p.lda * 2, ldw_b = (long long)p.ldw * 2;
     const int nkt = p.K * 2 / ROWB;
 
@@ -90,7 +89,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
     }
     const int wave_dst = __builtin_amdgcn_readfirstlane(wid) * 1024;
 
+    const bool dbg_noload = p.variant == 20 || p.variant == 22;   // timing experiments (tools/gemm_bench.py)
+    const bool dbg_nostore = p.variant == 21 || p.variant == 22;
     auto issue = [&](int kt, int buf) {
+        if (dbg_noload) return;
         char* base = smem + buf * BUF + wave_dst;
         const long long ko = (long long)kt * ROWB;
 #pragma unroll
@@ -239,6 +241,61 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
             __syncthreads();
             continue;
         }
+        if constexpr (TM == 2 && TN == 2 && ROWB == 128) {
+            // Same idea for the 64x64 wave tile: hipcc's schedule of this loop puts an lgkmcnt(0) in front of almost
+            // every MFMA pair (8 exposed LDS round trips per stage); here the 4 reads of k-step s+1 fly under the 4
+            // MFMAs of k-step s and the waits are counted.
+            const unsigned lb = (unsigned)(size_t)(lptr_t)smem + (unsigned)((kt & 1) * BUF);
+            const unsigned aA0 = lb + fragA + foff[0], aA1 = lb + fragA + foff[1], aA2 = lb + fragA + foff[2],
+                           aA3 = lb + fragA + foff[3];
+            const unsigned aW0 = lb + fragW + foff[0], aW1 = lb + fragW + foff[1], aW2 = lb + fragW + foff[2],
+                           aW3 = lb + fragW + foff[3];
+            u32x4 t0, t1, t2, t3, u0, u1, u2, u3;
+            asm volatile(
+                "ds_read_b128 %4, %12\n\t"
+                "ds_read_b128 %6, %16\n\t"
+                "ds_read_b128 %5, %12 offset:4096\n\t"
+                "ds_read_b128 %7, %16 offset:4096\n\t"
+                "ds_read_b128 %8, %13\n\t"
+                "ds_read_b128 %10, %17\n\t"
+                "ds_read_b128 %9, %13 offset:4096\n\t"
+                "ds_read_b128 %11, %17 offset:4096\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, %4, %6, %0\n\t"
+                "v_mfma_f32_32x32x16_bf16 %1, %4, %7, %1\n\t"
+                "v_mfma_f32_32x32x16_bf16 %2, %5, %6, %2\n\t"
+                "v_mfma_f32_32x32x16_bf16 %3, %5, %7, %3\n\t"
+                "ds_read_b128 %4, %14\n\t"
+                "ds_read_b128 %6, %18\n\t"
+                "ds_read_b128 %5, %14 offset:4096\n\t"
+                "ds_read_b128 %7, %18 offset:4096\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, %8, %10, %0\n\t"
+                "v_mfma_f32_32x32x16_bf16 %1, %8, %11, %1\n\t"
+                "v_mfma_f32_32x32x16_bf16 %2, %9, %10, %2\n\t"
+                "v_mfma_f32_32x32x16_bf16 %3, %9, %11, %3\n\t"
+                "ds_read_b128 %8, %15\n\t"
+                "ds_read_b128 %10, %19\n\t"
+                "ds_read_b128 %9, %15 offset:4096\n\t"
+                "ds_read_b128 %11, %19 offset:4096\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, %4, %6, %0\n\t"
+                "v_mfma_f32_32x32x16_bf16 %1, %4, %7, %1\n\t"
+                "v_mfma_f32_32x32x16_bf16 %2, %5, %6, %2\n\t"
+                "v_mfma_f32_32x32x16_bf16 %3, %5, %7, %3\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, %8, %10, %0\n\t"
+                "v_mfma_f32_32x32x16_bf16 %1, %8, %11, %1\n\t"
+                "v_mfma_f32_32x32x16_bf16 %2, %9, %10, %2\n\t"
+                "v_mfma_f32_32x32x16_bf16 %3, %9, %11, %3\n\t"
+                : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "=&v"(t0), "=&v"(t1), "=&v"(t2),
+                  "=&v"(t3), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)
+                : "v"(aA0), "v"(aA1), "v"(aA2), "v"(aA3), "v"(aW0), "v"(aW1), "v"(aW2), "v"(aW3)
+                : "memory");
+            if (kt + 1 == nkt) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA results -> VALU readers
+            __syncthreads();
+            continue;
+        }
         // software-pipelined fragments: the ds_reads of k-step s+1 are issued before the MFMAs of k-step s,
         // one read per MFMA slot (sched_group_barrier), so LDS latency hides under the matrix pipe
         u32x4 fa[2][TM], fw[2][TN];
@@ -275,6 +332,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
     float bj[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) bj[j] = p.bias ? p.bias[col0 + wc * WTN + j * 32 + l31] : 0.f;
+    if (dbg_nostore) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+        if (t == 12345.678f) p.Cf[0] = t;
+        return;
+    }
     if (p.cmap.rpg == 0 && row0 + BM <= p.M && !(EPI & EPI_ROWTAB)) {
         // full tile, identity row map: scalar row offset (buffer soffset) + one per-lane offset (voffset);
         // see gemm_epilogue.h.  The residual comes from the registers prefetched before the K loop.
@@ -330,10 +398,39 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
     }
 }
 
+// Row peeling (PEEL): the chip holds 512 resident 128x128 workgroups, and a grid of e.g. 1568 tiles runs as 3.06
+// "rounds", i.e. costs 4.  With p.peel = P (a multiple of BM chosen by the launcher so that the tiles of rows
+// [0, P) fill whole rounds) the rows [P, M) are covered by 64x64 tiles whose workgroups come FIRST in the grid: they
+// are dispatched at t = 0 beside the first big tiles, take a quarter of a big tile's time, and the grid ends after
+// ~3.1 rounds.  Every output element still accumulates its k-steps in the same order, so results do not depend on
+// the tile shape.
+template <int BM, int BN, int EPI, int WM, int WN, int ROWB, bool PEEL>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_glds_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * (BM + BN) * ROWB];
+    if constexpr (PEEL) {
+        const int ntm_tail = (p.M - p.peel + 63) / 64;
+        const int n_tail = ntm_tail * (p.N / 64);
+        if ((int)blockIdx.x < n_tail) {
+            gemm_glds_tile<64, 64, EPI, 2, 2, ROWB>(p, smem, blockIdx.x, ntm_tail, p.peel);
+            return;
+        }
+        gemm_glds_tile<BM, BN, EPI, WM, WN, ROWB>(p, smem, blockIdx.x - n_tail, p.peel / BM, 0);
+    } else {
+        gemm_glds_tile<BM, BN, EPI, WM, WN, ROWB>(p, smem, blockIdx.x, (p.M + BM - 1) / BM, 0);
+    }
+}
+
 template <int BM, int BN, int EPI, int WM, int WN, int ROWB = 128>
 static void launch_cfg(const GemmP& p, hipStream_t st) {
+    if (p.peel > 0) {
+        if constexpr (BM == 128 && BN == 128 && WM == 2 && WN == 2) {
+            const int grid = (p.peel / BM) * (p.N / BN) + ((p.M - p.peel + 63) / 64) * (p.N / 64);
+            hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, EPI, WM, WN, ROWB, true>), dim3(grid), dim3(256), 0, st, p);
+            return;
+        }
+    }
     const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
-    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, EPI, WM, WN, ROWB>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, EPI, WM, WN, ROWB, false>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
 }
 
 template <int BM, int BN, int WM, int WN, int ROWB = 128>
@@ -362,10 +459,24 @@ bool launch_gemm_glds(const GemmP& p, hipStream_t st) {
     if (p.variant == 6) return launch_tile<256, 128, 4, 2>(p, st);
     if (p.variant == 3) return launch_tile<128, 128, 2, 2>(p, st);
     if (p.variant == 2) return launch_tile<128, 128, 2, 2, 64>(p, st);
+    if (p.variant >= 20 && p.variant <= 22) return launch_tile<128, 128, 2, 2>(p, st);
     // default selection (measured with tools/gemm_bench.py on the plan step's shapes, after the epilogue's
     // address arithmetic moved to scalar registers): 128x128 tiles at two workgroups per CU win or tie on every
     // shape -- one workgroup's epilogue (VALU + stores) runs beside the other's MFMAs.
-    return launch_tile<128, 128, 2, 2>(p, st);
+    GemmP q = p;
+    q.peel = 0;
+    if (p.variant != 23) {
+        const int slots = 512;  // 256 CUs x 2 resident workgroups (64 KiB of LDS each)
+        const int ntm = (p.M + 127) / 128, ntn = p.N / 128;
+        int g = slots, b = ntn;
+        while (b) { const int t = g % b; g = b; b = t; }
+        const int step = slots / g;                 // row tiles per whole number of rounds
+        const int ntm_main = (ntm / step) * step;
+        const long long rem = ((long long)ntm * ntn) % slots;
+        // peel when the last round would be less than half full and the peeled rows are few
+        if (ntm_main > 0 && rem != 0 && rem * 2 < slots && p.M - ntm_main * 128 <= 4096) q.peel = ntm_main * 128;
+    }
+    return launch_tile<128, 128, 2, 2>(q, st);
 }
 
 }  // namespace m3pc

@@ -46,16 +46,27 @@ __device__ __forceinline__ int map_row3(const RowMap& m, int r) {
 }
 
 #define RING_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory")
+template <int N>
+__device__ __forceinline__ void ring_wait_barrier() {
+    static_assert(N == 0 || N == 3 || N == 4 || N == 6 || N == 8, "add the immediate");
+    if constexpr (N == 0) RING_WAIT_BARRIER(0);
+    if constexpr (N == 3) RING_WAIT_BARRIER(3);
+    if constexpr (N == 4) RING_WAIT_BARRIER(4);
+    if constexpr (N == 6) RING_WAIT_BARRIER(6);
+    if constexpr (N == 8) RING_WAIT_BARRIER(8);
+}
 
-template <int BN, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmP p) {
+// NSLOT = 4: three stages in flight, one block per CU.  NSLOT = 3 (BN = 128 only): two stages in flight, 72 KiB of
+// LDS and <= 128 VGPRs so that two blocks share a CU and one block's epilogue overlaps the other's main loop.
+template <int BN, int EPI, int NSLOT>
+__global__ __launch_bounds__(512, NSLOT == 3 ? 4 : 2) void gemm_ring_kernel(GemmP p) {
     constexpr int BM = 256;
     constexpr int WN = BN / 64, WM = 8 / WN;     // wave grid: 2x4 for BN=256, 4x2 for BN=128
     constexpr int WTM = BM / WM, TM = WTM / 32;  // wave tile WTM x 64
     constexpr int TN = 2;
     constexpr int STAGE = (BM + BN) * 64;        // bytes per ring slot
     constexpr int NI_A = BM / 16 / 8, NI_W = BN / 16 / 8;  // 1-KiB DMA instructions (16 rows) per wave per stage
-    __shared__ __attribute__((aligned(1024))) char smem[4 * STAGE];
+    __shared__ __attribute__((aligned(1024))) char smem[NSLOT * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmP p) {
     const bool dbg_noload = p.variant == 11 || p.variant == 12;   // timing experiments (tools/gemm_bench.py)
     auto issue = [&](int st) {
         if (dbg_noload) return;
-        char* base = smem + (st & 3) * STAGE + wave_dst;
+        char* base = smem + (st % NSLOT) * STAGE + wave_dst;
         const long long ko = (long long)st * 64;
 #pragma unroll
         for (int i = 0; i < NI_A; ++i)
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmP p) {
     const int fragW = BM * 64 + wc * 64 * 64;
 
     auto compute = [&](int st) {
-        const char* cur = smem + (st & 3) * STAGE;
+        const char* cur = smem + (st % NSLOT) * STAGE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int fo = s == 0 ? f0 : f1;
@@ -139,26 +150,22 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmP p) {
     };
 
     // nst >= 4 is guaranteed by the launcher (K >= 128)
-    issue(0);
-    issue(1);
-    issue(2);
     constexpr int PER = NI_A + NI_W;  // DMA instructions per wave per stage
-    static_assert(PER == 4 || PER == 3, "vmcnt immediates below assume 3 or 4 DMA instructions per stage");
-    for (int st = 0; st < nst - 2; ++st) {
-        if constexpr (PER == 4)
-            RING_WAIT_BARRIER(8);
-        else
-            RING_WAIT_BARRIER(6);
-        if (st + 3 < nst) issue(st + 3);
+    constexpr int F = NSLOT - 1;      // stages in flight
+    static_assert(PER == 4 || PER == 3, "vmcnt immediates assume 3 or 4 DMA instructions per stage");
+#pragma unroll
+    for (int s = 0; s < F; ++s) issue(s);
+    for (int st = 0; st < nst - (F - 1); ++st) {
+        ring_wait_barrier<(F - 1) * PER>();
+        if (st + F < nst) issue(st + F);
         compute(st);
     }
-    // tail: stages nst-2 and nst-1 (nothing left to issue)
-    if constexpr (PER == 4)
-        RING_WAIT_BARRIER(4);
-    else
-        RING_WAIT_BARRIER(3);
-    compute(nst - 2);
-    RING_WAIT_BARRIER(0);
+    // tail: the last F-1 stages (nothing left to issue)
+    if constexpr (F == 3) {
+        ring_wait_barrier<PER>();
+        compute(nst - 2);
+    }
+    ring_wait_barrier<0>();
     compute(nst - 1);
 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -168,23 +175,23 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmP p) {
     }
 }
 
-template <int BN, int EPI>
+template <int BN, int EPI, int NSLOT>
 static void launch_cfg(const GemmP& p, hipStream_t st) {
     const int grid = ((p.M + 255) / 256) * (p.N / BN);
-    hipLaunchKernelGGL((gemm_ring_kernel<BN, EPI>), dim3(grid), dim3(512), 0, st, p);
+    hipLaunchKernelGGL((gemm_ring_kernel<BN, EPI, NSLOT>), dim3(grid), dim3(512), 0, st, p);
 }
 
-template <int BN>
+template <int BN, int NSLOT>
 static bool launch_bn(const GemmP& p, hipStream_t st) {
     const bool f32out = p.Cf != nullptr;
     const int epi = (p.gelu ? EPI_GELU : 0) | (p.res ? EPI_RES : 0) | (p.rowtab ? EPI_ROWTAB : 0) | (f32out ? EPI_F32OUT : 0);
     switch (epi) {
-        case 0: launch_cfg<BN, 0>(p, st); return true;
-        case EPI_F32OUT: launch_cfg<BN, EPI_F32OUT>(p, st); return true;
-        case EPI_GELU: launch_cfg<BN, EPI_GELU>(p, st); return true;
-        case EPI_GELU | EPI_F32OUT: launch_cfg<BN, EPI_GELU | EPI_F32OUT>(p, st); return true;
-        case EPI_RES | EPI_F32OUT: launch_cfg<BN, EPI_RES | EPI_F32OUT>(p, st); return true;
-        case EPI_ROWTAB | EPI_F32OUT: launch_cfg<BN, EPI_ROWTAB | EPI_F32OUT>(p, st); return true;
+        case 0: launch_cfg<BN, 0, NSLOT>(p, st); return true;
+        case EPI_F32OUT: launch_cfg<BN, EPI_F32OUT, NSLOT>(p, st); return true;
+        case EPI_GELU: launch_cfg<BN, EPI_GELU, NSLOT>(p, st); return true;
+        case EPI_GELU | EPI_F32OUT: launch_cfg<BN, EPI_GELU | EPI_F32OUT, NSLOT>(p, st); return true;
+        case EPI_RES | EPI_F32OUT: launch_cfg<BN, EPI_RES | EPI_F32OUT, NSLOT>(p, st); return true;
+        case EPI_ROWTAB | EPI_F32OUT: launch_cfg<BN, EPI_ROWTAB | EPI_F32OUT, NSLOT>(p, st); return true;
         default: return false;
     }
 }
@@ -195,8 +202,9 @@ bool launch_gemm_ring(const GemmP& p, hipStream_t st) {
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || (p.lda % 8) || (p.ldw % 8)) return false;
     const long long rows256 = (p.M + 255) / 256;
     if (rows256 * (p.N / 128) < 256) return false;  // too few tiles to fill the chip
-    if (p.variant == 8 || p.N % 256 != 0) return launch_bn<128>(p, st);  // variants 10-12: timing experiments
-    return launch_bn<256>(p, st);
+    if (p.variant == 13) return launch_bn<128, 3>(p, st);
+    if (p.variant == 8 || p.N % 256 != 0) return launch_bn<128, 4>(p, st);  // variants 10-12: timing experiments
+    return launch_bn<256, 4>(p, st);
 }
 
 }  // namespace m3pc

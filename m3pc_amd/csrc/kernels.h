@@ -44,6 +44,7 @@ struct GemmP {
     float* ws;     // split-K slab workspace (optional): few-row fp32 GEMMs split K over blocks
     long long ws_bytes;
     int variant;   // 0 = default kernel selection; other values pick experimental configurations
+    int peel;      // set by launch_gemm_glds: rows >= peel are covered by small tiles (0 = off); callers leave it 0
 };
 void launch_gemm(const GemmP& p, int dtype, hipStream_t st);
 bool launch_gemm_ring(const GemmP& p, hipStream_t st);  // bf16, many rows: 256x256 tile, 4-slot LDS-DMA ring (gemm_ring.hip)

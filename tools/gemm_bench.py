@@ -60,13 +60,14 @@ def main():
             tot[v] += us
             out = Cout.float()
             if ref is None:
-                x = A[:256].float() @ W.float().T + bias
+                sel = torch.cat([torch.arange(256), torch.arange(M - 1280, M)]).to(dev)  # head + peeled tail rows
+                x = A[sel].float() @ W.float().T + bias
                 if gelu:
                     x = torch.nn.functional.gelu(x)
                 if res:
-                    x = x + R[:256]
+                    x = x + R[sel]
                 ref = x
-            err = float((out[:256] - ref).abs().max())
+            err = float((out[sel] - ref).abs().max())
             line += f" | v{v}: {us:7.1f}us {2.0 * M * N * K / us / 1e6:7.1f} TF/s err {err:.2e}"
         print(line, flush=True)
     print("total us per variant:", {v: round(t, 1) for v, t in tot.items()})
