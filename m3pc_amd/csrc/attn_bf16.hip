@@ -42,10 +42,16 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
     // ---- Q: stage nw*32 rows, keep this wave's B fragments in registers
+    // query slots: [0, Lq) from Q (per batch element), [Lq1p, Lq1p + Lq2) from the shared segment Q2
+    const int Lq1p = (p.Lq + 31) & ~31;
+    const bf16_t* Q2b = p.Q2 ? (const bf16_t*)p.Q2 + head * HD : nullptr;
     for (int c = tid; c < nw * 32 * CPR; c += nthr) {
-        const int r = c / CPR, kc = c % CPR;
+        const int r = c / CPR, kc = c % CPR, qi = q0 + r;
         u32x4 v = zero4;
-        if (q0 + r < p.Lq) v = *(const u32x4*)(Qb + (long long)(q0 + r) * p.ldq + kc * 8);
+        if (qi < p.Lq)
+            v = *(const u32x4*)(Qb + (long long)qi * p.ldq + kc * 8);
+        else if (Q2b && qi >= Lq1p && qi - Lq1p < p.Lq2)
+            v = *(const u32x4*)(Q2b + (long long)(qi - Lq1p) * p.ldq2 + kc * 8);
         *(u32x4*)(lds + r * ROWB + kc * 16) = v;
     }
     __syncthreads();
@@ -175,9 +181,14 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int i = q0 + wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (i < p.Lq) {
+        int orow = -1;
+        if (i < p.Lq)
+            orow = p.orow1 + i;
+        else if (Q2b && i >= Lq1p && i - Lq1p < p.Lq2)
+            orow = p.orow2 + i - Lq1p;
+        if (orow >= 0) {
 #pragma unroll
-            for (int d = 0; d < HDT; ++d) Ob[(long long)i * p.ldo + d * 32 + l31] = (bf16_t)oacc[d][e];
+            for (int d = 0; d < HDT; ++d) Ob[(long long)orow * p.ldo + d * 32 + l31] = (bf16_t)oacc[d][e];
         }
     }
 }
@@ -190,8 +201,9 @@ static void launch_nch(const AttnP& p, dim3 grid, dim3 block, size_t smem, hipSt
 template <int HDT>
 static void launch_hd(const AttnP& p, hipStream_t st) {
     const int Lk = p.L1 + p.L2;
-    const int qgroups = (p.Lq + 127) / 128;
-    const int nw = p.Lq > 64 ? 4 : 2;  // at least 2 waves so staging has 128 lanes
+    const int slots = p.Q2 ? ((p.Lq + 31) & ~31) + p.Lq2 : p.Lq;  // query slots (see AttnP::Q2)
+    const int qgroups = (slots + 127) / 128;
+    const int nw = slots > 64 ? 4 : 2;  // at least 2 waves so staging has 128 lanes
     const int rows = nw * 32 > 64 ? nw * 32 : 64;
     const size_t smem = (size_t)rows * (HDT * 64 + 16);
     dim3 grid(p.batch, p.n_head, qgroups), block(nw * 64);

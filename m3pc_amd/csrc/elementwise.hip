@@ -89,9 +89,129 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedP p) {
         }
     }
 }
+// Wave-per-row variant (d % 256 == 0): one wave owns token j for a chunk of CB batch elements; lane l holds the
+// NV = d/256 float4 column groups (i*64 + l)*4.  The row is built, normalised (LayerNorm = two 64-lane butterflies,
+// no LDS, no barrier) and stored with 16-byte accesses.  Tokens j < n_indep do not depend on the batch index: the
+// row is computed for the first element of the chunk and only re-stored for the others, which turns the kernel
+// into a pure HBM writer (the candidate pass shares 33 of its 49 tokens between candidates).
+template <int NV>
+__global__ __launch_bounds__(256) void embed_rows_kernel(EmbedP p, int CB, int nchunk) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= p.L * nchunk) return;
+    const int j = w / nchunk, ch = w % nchunk;
+    const int2 kt = p.tokmap[j];
+    const int key = kt.x, t = kt.y;
+    const int D = p.feat[key], d = p.d;
+    const float* WT = p.WT[key];
+    const float* E = p.E[key] + (long long)t * d;
+    const bool indep = j < p.n_indep;
+    const int b0 = ch * CB, b1 = b0 + CB < p.batch ? b0 + CB : p.batch;
+    const int n_own = p.L - p.n_sh;
+    float4 ev[NV], gv[NV], bv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        ev[i] = *(const float4*)(E + c);
+        if (p.ln_g) {
+            gv[i] = *(const float4*)(p.ln_g + c);
+            bv[i] = *(const float4*)(p.ln_b + c);
+        }
+    }
+    float4 x[NV], y[NV];
+    for (int b = b0; b < b1; ++b) {
+        if (b == b0 || !indep) {
+            const float* xin = p.tok[key] + (long long)b * p.bstride[key] + (long long)t * D;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int f = 0; f < D; ++f) {
+                float xf = xin[f];
+                if (p.normalize[key]) xf = (xf - p.mean[key][f]) / p.stdv[key][f];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const float4 wv = *(const float4*)(WT + (long long)f * d + (i * 64 + lane) * 4);
+                    x[i].x = fmaf(xf, wv.x, x[i].x);
+                    x[i].y = fmaf(xf, wv.y, x[i].y);
+                    x[i].z = fmaf(xf, wv.z, x[i].z);
+                    x[i].w = fmaf(xf, wv.w, x[i].w);
+                }
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                x[i].x += ev[i].x;
+                x[i].y += ev[i].y;
+                x[i].z += ev[i].z;
+                x[i].w += ev[i].w;
+                s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+            }
+            if (p.ln_g) {
+                const float mean = wave_sum(s) / (float)d;
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const float c0 = x[i].x - mean, c1 = x[i].y - mean, c2 = x[i].z - mean, c3 = x[i].w - mean;
+                    q += (c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3);
+                }
+                const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    y[i].x = (x[i].x - mean) * rstd * gv[i].x + bv[i].x;
+                    y[i].y = (x[i].y - mean) * rstd * gv[i].y + bv[i].y;
+                    y[i].z = (x[i].z - mean) * rstd * gv[i].z + bv[i].z;
+                    y[i].w = (x[i].w - mean) * rstd * gv[i].w + bv[i].w;
+                }
+            }
+        }
+        const long long row = (long long)b * p.L + j;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *(float4*)(p.X + row * d + (i * 64 + lane) * 4) = x[i];
+        if (!p.ln_g) continue;
+        if (p.Hf) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) *(float4*)(p.Hf + row * d + (i * 64 + lane) * 4) = y[i];
+        }
+        if (p.Hb) {
+            bf16_t* dst;
+            if (p.n_sh == 0)
+                dst = p.Hb + row * d;
+            else if (j >= p.n_sh)
+                dst = p.Hb + ((long long)b * n_own + (j - p.n_sh)) * d;
+            else if (b == 0)
+                dst = p.Hb_sh + (long long)j * d;
+            else
+                continue;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+                bf16x4_t o;
+                o[0] = (bf16_t)y[i].x;
+                o[1] = (bf16_t)y[i].y;
+                o[2] = (bf16_t)y[i].z;
+                o[3] = (bf16_t)y[i].w;
+                *(bf16x4_t*)(dst + (i * 64 + lane) * 4) = o;
+            }
+        }
+    }
+}
+
 void launch_embed(const EmbedP& p, hipStream_t st) {
     const long long rows = (long long)p.batch * p.L;
     if (rows <= 0) return;
+    if (p.d % 256 == 0 && p.d <= 1024) {
+        int CB = p.batch / 64;
+        CB = CB < 1 ? 1 : (CB > 16 ? 16 : CB);
+        const int nchunk = (p.batch + CB - 1) / CB;
+        const int waves = p.L * nchunk;
+        const dim3 grid((waves + 3) / 4), block(256);
+        switch (p.d / 256) {
+            case 1: hipLaunchKernelGGL(embed_rows_kernel<1>, grid, block, 0, st, p, CB, nchunk); break;
+            case 2: hipLaunchKernelGGL(embed_rows_kernel<2>, grid, block, 0, st, p, CB, nchunk); break;
+            case 3: hipLaunchKernelGGL(embed_rows_kernel<3>, grid, block, 0, st, p, CB, nchunk); break;
+            default: hipLaunchKernelGGL(embed_rows_kernel<4>, grid, block, 0, st, p, CB, nchunk); break;
+        }
+        return;
+    }
     hipLaunchKernelGGL(embed_kernel, dim3((unsigned)rows), dim3(p.d < 256 ? p.d : 256), 0, st, p);
 }
 

@@ -87,6 +87,11 @@ struct AttnP {
     int ldo;
     int batch, n_head, hd, Lq;
     float scale;
+    // optional second query segment shared by the batch (bf16 kernel only): query slots [0, Lq) come from Q,
+    // slots [ceil32(Lq), ceil32(Lq) + Lq2) from Q2; outputs go to rows orow1 + i / orow2 + i of O[b]
+    const void* Q2;
+    int ldq2, Lq2;
+    int orow1, orow2;
 };
 void launch_attention(const AttnP& p, int dtype, hipStream_t st);
 void launch_attention_bf16(const AttnP& p, hipStream_t st);
@@ -109,6 +114,9 @@ struct EmbedP {
     const float* ln_b;
     float* Hf;               // ... as fp32 and/or
     bf16_t* Hb;              // ... bf16 rows (batch*L, d)
+    int n_indep;             // the first n_indep tokens do not depend on the batch index (computed once per wave)
+    int n_sh;                // > 0: LayerNorm rows of tokens j < n_sh go once to Hb_sh[j], those of tokens j >= n_sh
+    bf16_t* Hb_sh;           //      compactly to Hb[b * (L - n_sh) + j - n_sh]  (first-layer pruning, see run_block)
 };
 void launch_embed(const EmbedP& p, hipStream_t st);
 

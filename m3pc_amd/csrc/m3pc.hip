@@ -371,7 +371,8 @@ void invalidate_tables(m3pc_handle* h) {
 
 // ---------------------------------------------------------------------------------- transformer block
 // One pre-LN layer (mtm_model.py:379-409) over `batch` sequences of L rows, in place on X (fp32).
-int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L, int dt, hipStream_t st, bool ln1_done = false) {
+int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L, int dt, hipStream_t st, bool ln1_done = false,
+              int n_sh = 0) {
     const int d = h->d, ff = h->ff;
     const int rows = batch * L;
     const int es = (int)dtype_size(dt);
@@ -389,6 +390,58 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
     else
         ln.Yf = (float*)h->Hn;
     if (!ln1_done) launch_layernorm(ln, st);  // the embedding kernel already wrote norm1(X) of the first layer
+    if (n_sh > 0) {
+        // First layer of a candidate pass: the first n_sh tokens are the same for every candidate (history), so
+        // their norm1 rows and Q|K|V projections exist once (n_sh rows behind the compact per-candidate rows in
+        // Hn / QKV, written by the embedding kernel) and only the L - n_sh candidate-specific rows go through the
+        // big GEMM.  Attention still produces all L output rows per candidate: queries and keys are read from the
+        // two segments (own rows first, then the shared ones; softmax is order-independent up to rounding).
+        const int n_own = L - n_sh;
+        const size_t es2 = dtype_size(dt);
+        char* hn_sh = (char*)h->Hn + (size_t)batch * n_own * d * es2;
+        char* qkv_sh = (char*)h->QKV + (size_t)batch * n_own * 3 * d * es2;
+        {
+            GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".self_attn.in_proj_weight", dt), d, batch * n_own, 3 * d, d,
+                                 W(h, pfx + ".self_attn.in_proj_bias").f);
+            gemm_out(p, dt, h->QKV, 3 * d);
+            gemm(h, p, dt, st);
+        }
+        {
+            GemmP p = gemm_basic(hn_sh, d, Wop(h, pfx + ".self_attn.in_proj_weight", dt), d, n_sh, 3 * d, d,
+                                 W(h, pfx + ".self_attn.in_proj_bias").f);
+            gemm_out(p, dt, qkv_sh, 3 * d);
+            gemm(h, p, dt, st);
+        }
+        AttnP a;
+        memset(&a, 0, sizeof(a));
+        const char* q = (const char*)h->QKV;
+        a.Q = q;
+        a.q_bstride = (long long)n_own * 3 * d;
+        a.ldq = 3 * d;
+        a.Lq = n_own;
+        a.orow1 = n_sh;
+        a.Q2 = qkv_sh;
+        a.ldq2 = 3 * d;
+        a.Lq2 = n_sh;
+        a.orow2 = 0;
+        a.K1 = q + (size_t)d * es2;
+        a.V1 = q + (size_t)2 * d * es2;
+        a.kv1_bstride = (long long)n_own * 3 * d;
+        a.ldkv1 = 3 * d;
+        a.L1 = n_own;
+        a.K2 = qkv_sh + (size_t)d * es2;
+        a.V2 = qkv_sh + (size_t)2 * d * es2;
+        a.ldkv2 = 3 * d;
+        a.L2 = n_sh;
+        a.O = h->O;
+        a.o_bstride = (long long)L * d;
+        a.ldo = d;
+        a.batch = batch;
+        a.n_head = h->nh;
+        a.hd = h->hd;
+        a.scale = 1.0f / sqrtf((float)h->hd);
+        launch_attention(a, dt, st);
+    } else {
     {
         GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".self_attn.in_proj_weight", dt), d, rows, 3 * d, d,
                              W(h, pfx + ".self_attn.in_proj_bias").f);
@@ -416,6 +469,7 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
         a.Lq = L;
         a.scale = 1.0f / sqrtf((float)h->hd);
         launch_attention(a, dt, st);
+    }
     }
     {
         GemmP p = gemm_basic(h->O, d, Wop(h, pfx + ".self_attn.out_proj.weight", dt), d, rows, d, d,
@@ -451,9 +505,18 @@ struct TokIn {
 };
 
 // embed + encoder stack + encoder.norm -> EncOut (fp32) [and bf16 copy in Z when dt == bf16 and want_b]
-int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hipStream_t st, bool bf16_out_only = false) {
+// n_indep: number of leading encoder tokens that are identical for every batch element (candidate pass: history)
+int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hipStream_t st, bool bf16_out_only = false,
+                int n_indep = 0) {
+    // first-layer pruning (run_block): whole 32-query tiles of shared tokens, bf16 candidate passes only
+    int n_sh = 0;
+    if (dt == DT_BF16 && batch >= 64 && h->d % 256 == 0 && h->d <= 1024 && n_indep >= 32 && !getenv("M3PC_NO_PRUNE1"))
+        n_sh = (n_indep / 32) * 32;
     EmbedP e;
     memset(&e, 0, sizeof(e));
+    e.n_indep = n_indep;
+    e.n_sh = n_sh;
+    e.Hb_sh = n_sh ? (bf16_t*)((char*)h->Hn + (size_t)batch * (pl->Le - n_sh) * h->d * 2) : nullptr;
     for (int k = 0; k < 4; ++k) {
         e.tok[k] = in.ptr[k];
         e.bstride[k] = in.bstride[k];
@@ -478,7 +541,7 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
         e.Hf = (float*)h->Hn;
     launch_embed(e, st);
     for (int i = 0; i < h->dm.n_enc_layer; ++i)
-        CHK(run_block(h, "encoder.layers." + std::to_string(i), h->X, batch, pl->Le, dt, st, i == 0));
+        CHK(run_block(h, "encoder.layers." + std::to_string(i), h->X, batch, pl->Le, dt, st, i == 0, i == 0 ? n_sh : 0));
     LnP ln;
     memset(&ln, 0, sizeof(ln));
     ln.X = h->X;
@@ -767,7 +830,8 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     in.normalize[M3PC_ACTIONS] = h->tok_norm[M3PC_ACTIONS];
     in.ptr[M3PC_REWARDS] = rewards;
     in.ptr[M3PC_RETURNS] = h->rtok;
-    CHK(run_encoder(h, pl, in, n, dt, st, dt == DT_BF16));
+    // encoder order is states 0..idx, actions 0..T-1: everything before actions[idx] is history, shared by all candidates
+    CHK(run_encoder(h, pl, in, n, dt, st, dt == DT_BF16, (idx + 1) + idx));
 
     // decoder inputs of the un-masked tokens (kept sets are prefixes 0..kept-1 for the fd mask)
     const void* enc_op = dt == DT_BF16 ? h->Z : (const void*)h->EncOut;
