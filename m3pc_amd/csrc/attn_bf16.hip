@@ -124,7 +124,24 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
                 l += v;
             }
     l += __shfl_xor(l, 32);
-    const float inv = 1.0f / l;
+    float inv = 1.0f / l;
+    float* fbuf = (float*)(lds + 64 * ROWB);  // per-query weight of the pre-reduced key block (behind the K/V image)
+    if (p.pre_m) {
+        // merge with the pre-reduced (batch-independent) key block: m_t = max(m, m_pre),
+        // l_t = l e^{m - m_t} + l_pre e^{m_pre - m_t};  P gets e^{m - m_t} / l_t, the block's pre_O gets e^{m_pre - m_t} / l_t
+        const int qi = q0 + wid * 32 + l31;
+        float mp = -INFINITY, lp = 0.f;
+        if (qi < p.Lq) {
+            mp = p.pre_m[head * p.Lq + qi];
+            lp = p.pre_l[head * p.Lq + qi];
+        }
+        const float mt = fmaxf(m, mp);
+        const float a = __builtin_amdgcn_exp2f((m - mt) * 1.44269504088896340736f);
+        const float bs = __builtin_amdgcn_exp2f((mp - mt) * 1.44269504088896340736f);
+        const float lt = l * a + lp * bs;
+        inv = a / lt;
+        if (lh == 0) fbuf[wid * 32 + l31] = bs / lt;
+    }
 
     // ---- O = P V
     f32x16 oacc[HDT];
@@ -187,6 +204,12 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
         else if (Q2b && i >= Lq1p && i - Lq1p < p.Lq2)
             orow = p.orow2 + i - Lq1p;
         if (orow >= 0) {
+            if (p.pre_m) {
+                const float f = fbuf[i - q0];
+                const float* po = p.pre_O + ((long long)head * p.Lq + i) * HD;
+#pragma unroll
+                for (int d = 0; d < HDT; ++d) oacc[d][e] = fmaf(f, po[d * 32 + l31], oacc[d][e]);
+            }
 #pragma unroll
             for (int d = 0; d < HDT; ++d) Ob[(long long)orow * p.ldo + d * 32 + l31] = (bf16_t)oacc[d][e];
         }
@@ -205,7 +228,7 @@ static void launch_hd(const AttnP& p, hipStream_t st) {
     const int qgroups = (slots + 127) / 128;
     const int nw = slots > 64 ? 4 : 2;  // at least 2 waves so staging has 128 lanes
     const int rows = nw * 32 > 64 ? nw * 32 : 64;
-    const size_t smem = (size_t)rows * (HDT * 64 + 16);
+    const size_t smem = (size_t)rows * (HDT * 64 + 16) + 512;  // + per-query weights of the pre-reduced block
     dim3 grid(p.batch, p.n_head, qgroups), block(nw * 64);
     if (Lk <= 64)
         launch_nch<HDT, 1>(p, grid, block, smem, st);
@@ -213,6 +236,43 @@ static void launch_hd(const AttnP& p, hipStream_t st) {
         launch_nch<HDT, 2>(p, grid, block, smem, st);
     else
         launch_nch<HDT, 4>(p, grid, block, smem, st);
+}
+
+// one wave per (head, query): scores against the L2 shared keys, their max / exp-sum and the exp-weighted V sum.
+// Runs once per (weights, mask, mode) when the decoder tables are built, so it is written for clarity, not speed.
+__global__ __launch_bounds__(64) void attn_prestats_kernel(AttnP p, float* pre_m, float* pre_l, float* pre_O) {
+    const int head = blockIdx.x, qi = blockIdx.y, lane = threadIdx.x;
+    const int HD = p.hd;
+    __shared__ float sc[256];
+    const bf16_t* q = (const bf16_t*)p.Q + (long long)qi * p.ldq + head * HD;
+    const bf16_t* K = (const bf16_t*)p.K2 + head * HD;
+    const bf16_t* V = (const bf16_t*)p.V2 + head * HD;
+    float m = -INFINITY;
+    for (int j = 0; j < p.L2; ++j) {
+        float s = 0.f;
+        for (int c = lane; c < HD; c += 64) s = fmaf((float)q[c], (float)K[(long long)j * p.ldkv2 + c], s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        s *= p.scale;
+        if (lane == 0) sc[j] = s;
+        m = fmaxf(m, s);
+    }
+    __syncthreads();
+    float l = 0.f;
+    for (int j = 0; j < p.L2; ++j) l += __builtin_amdgcn_exp2f((sc[j] - m) * 1.44269504088896340736f);
+    for (int c = lane; c < HD; c += 64) {
+        float o = 0.f;
+        for (int j = 0; j < p.L2; ++j)
+            o = fmaf(__builtin_amdgcn_exp2f((sc[j] - m) * 1.44269504088896340736f), (float)V[(long long)j * p.ldkv2 + c], o);
+        pre_O[((long long)head * p.Lq + qi) * HD + c] = o;
+    }
+    if (lane == 0) {
+        pre_m[head * p.Lq + qi] = m;
+        pre_l[head * p.Lq + qi] = l;
+    }
+}
+void launch_attention_prestats(const AttnP& p, float* pre_m, float* pre_l, float* pre_O, hipStream_t st) {
+    hipLaunchKernelGGL(attn_prestats_kernel, dim3(p.n_head, p.Lq), dim3(64), 0, st, p, pre_m, pre_l, pre_O);
 }
 
 void launch_attention_bf16(const AttnP& p, hipStream_t st) {

@@ -92,7 +92,17 @@ struct AttnP {
     const void* Q2;
     int ldq2, Lq2;
     int orow1, orow2;
+    // optional pre-reduced key block (bf16 kernel, batch-shared queries only): for every (head, query) the running
+    // max pre_m, the sum pre_l = sum_j exp(s_j - pre_m) and pre_O = sum_j exp(s_j - pre_m) V_j over a set of keys
+    // that is the same for the whole batch (launch_attention_prestats).  The kernel merges it with the softmax
+    // over its own keys exactly as two blocks of a streaming softmax are merged.
+    const float* pre_m;  // (n_head, Lq)
+    const float* pre_l;  // (n_head, Lq)
+    const float* pre_O;  // (n_head, Lq, hd)
 };
+// pre_m / pre_l / pre_O of queries Q (Lq rows) against keys K2/V2 (L2 rows); uses Q, ldq, K2, V2, ldkv2, L2, Lq,
+// n_head, hd, scale of `p` (bf16 operands) and writes the three arrays
+void launch_attention_prestats(const AttnP& p, float* pre_m, float* pre_l, float* pre_O, hipStream_t st);
 void launch_attention(const AttnP& p, int dtype, hipStream_t st);
 void launch_attention_bf16(const AttnP& p, hipStream_t st);
 

@@ -64,6 +64,8 @@ struct SharedTables {  // candidate-independent decoder quantities of one plan, 
     void* QKVm = nullptr;    // (Lm, 3d) q|k|v of masked tokens (operand dtype)
     void* QKVq = nullptr;    // (nq, 3d) rows of the scored tokens (valid when they are all masked)
     float* Yq = nullptr;     // (nq, d)  decoder inputs of the scored tokens
+    // softmax block of the (shared) queries against the masked tokens' keys, pre-reduced (AttnP::pre_m/l/O); bf16 only
+    float *pre_m = nullptr, *pre_l = nullptr, *pre_O = nullptr;
 };
 
 struct Plan {
@@ -360,6 +362,9 @@ void free_tables(SharedTables& t) {
     if (t.QKVm) hipFree(t.QKVm);
     if (t.QKVq) hipFree(t.QKVq);
     if (t.Yq) hipFree(t.Yq);
+    if (t.pre_m) hipFree(t.pre_m);
+    if (t.pre_l) hipFree(t.pre_l);
+    if (t.pre_O) hipFree(t.pre_O);
     t = SharedTables();
 }
 
@@ -794,6 +799,27 @@ int build_tables(m3pc_handle* h, Plan* pl, int qi, int dt, hipStream_t st) {
     g.out = tb.Yq;
     g.outb = nullptr;
     launch_gather_rows(g, st);
+    if (dt == DT_BF16 && q.all_masked && pl->Lm > 0 && pl->Lm <= 256 && !getenv("M3PC_NO_PRESTATS")) {
+        // queries and masked-token keys are both candidate-independent: reduce that block of the softmax once
+        if (!tb.pre_m) {
+            CHK(dmalloc(&tb.pre_m, (size_t)h->nh * q.nq));
+            CHK(dmalloc(&tb.pre_l, (size_t)h->nh * q.nq));
+            CHK(dmalloc(&tb.pre_O, (size_t)h->nh * q.nq * h->hd));
+        }
+        AttnP at;
+        memset(&at, 0, sizeof(at));
+        at.Q = tb.QKVq;
+        at.ldq = 3 * d;
+        at.Lq = q.nq;
+        at.K2 = (const char*)tb.QKVm + (size_t)d * es;
+        at.V2 = (const char*)tb.QKVm + (size_t)2 * d * es;
+        at.ldkv2 = 3 * d;
+        at.L2 = pl->Lm;
+        at.n_head = h->nh;
+        at.hd = h->hd;
+        at.scale = 1.0f / sqrtf((float)h->hd);
+        launch_attention_prestats(at, tb.pre_m, tb.pre_l, tb.pre_O, st);
+    }
     HIPCHK(hipStreamSynchronize(st));
     hipFree(d_rs);
     tb.valid = true;
@@ -918,6 +944,15 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         at.hd = h->hd;
         at.Lq = nq;
         at.scale = 1.0f / sqrtf((float)h->hd);
+        if (dt == DT_BF16 && q.all_masked && tb.pre_m) {
+            // the masked tokens' keys meet the same (shared) queries for every candidate: that block of the softmax
+            // was reduced when the tables were built, only the candidate's own Le keys are visited here
+            at.K2 = at.V2 = nullptr;
+            at.L2 = 0;
+            at.pre_m = tb.pre_m;
+            at.pre_l = tb.pre_l;
+            at.pre_O = tb.pre_O;
+        }
         launch_attention(at, dt, st);
     }
     float* Y1 = h->EncOut;  // (n*nq, d) decoder residual of the scored tokens (EncOut is dead: Z/Y hold its uses)
