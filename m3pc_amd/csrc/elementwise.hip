@@ -418,21 +418,36 @@ __global__ __launch_bounds__(256) void actor_head_kernel(ActorP p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i)
         if (i < n) v[i] = x[i * 64 + lane];
-    for (int f = 0; f < p.A; ++f) {
-        float s1 = 0.f, s2 = 0.f;
+    // four features at a time: their 2 x 4 dot products and butterflies are independent chains, so the weight
+    // loads and the shuffles of one feature hide behind the others (this kernel is pure latency)
+    for (int f0 = 0; f0 < p.A; f0 += 4) {
+        float s1[4], s2[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (i < n) {
-                s1 = fmaf(v[i], p.Wmu[(long long)f * p.d + i * 64 + lane], s1);
-                s2 = fmaf(v[i], p.Wls[(long long)f * p.d + i * 64 + lane], s2);
+        for (int k = 0; k < 4; ++k) {
+            const int f = f0 + k < p.A ? f0 + k : p.A - 1;
+            s1[k] = 0.f;
+            s2[k] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i < n) {
+                    s1[k] = fmaf(v[i], p.Wmu[(long long)f * p.d + i * 64 + lane], s1[k]);
+                    s2[k] = fmaf(v[i], p.Wls[(long long)f * p.d + i * 64 + lane], s2[k]);
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s1[k] = wave_sum(s1[k]);
+            s2[k] = wave_sum(s2[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int f = f0 + k;
+            if (f < p.A && lane == 0) {
+                p.mu[(long long)r * p.A + f] = s1[k] + p.bmu[f];
+                float ls = tanhf(s2[k] + p.bls[f]);
+                ls = -5.0f + 0.5f * (2.0f - (-5.0f)) * (ls + 1.0f);
+                p.sd[(long long)r * p.A + f] = expf(ls);
             }
-        s1 = wave_sum(s1) + p.bmu[f];
-        s2 = wave_sum(s2) + p.bls[f];
-        if (lane == 0) {
-            p.mu[(long long)r * p.A + f] = s1;
-            float ls = tanhf(s2);
-            ls = -5.0f + 0.5f * (2.0f - (-5.0f)) * (ls + 1.0f);
-            p.sd[(long long)r * p.A + f] = expf(ls);
         }
     }
 }
@@ -554,15 +569,14 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreP p) {
     const float one_minus = (float)(1.0 - p.lmbda);
     float er = 0.f;
     double lam_t = 1.0;  // python float lmbda**t
+    // The reference restarts the discounted reward sum at every t; summed left to right it is a prefix of the
+    // next t's sum and disc is the same repeated product, so one running (pre, disc) pair reproduces every t bit
+    // for bit in O(h) instead of O(h^2).
+    float disc = p.gamma, pre = 0.f;
     for (int t = 0; t < p.h; ++t) {
-        float disc = p.gamma, s = 0.f;
-        for (int i = 0; i < t; ++i) {
-            s = __fadd_rn(s, __fmul_rn(rw[i], disc));
-            disc = __fmul_rn(disc, p.gamma);
-        }
         const float b = __fmul_rn(bt[t], p.boot_scale);
         if (p.boot_out) p.boot_out[(long long)n * p.h + t] = b;
-        s = __fadd_rn(s, __fmul_rn(b, disc));
+        const float s = __fadd_rn(pre, __fmul_rn(b, disc));
         float w;
         if (t < p.h - 1)
             w = __fmul_rn(__fmul_rn(s, one_minus), (float)lam_t);
@@ -570,6 +584,8 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreP p) {
             w = __fmul_rn(s, (float)lam_t);
         er = __fadd_rn(er, w);
         lam_t *= p.lmbda;
+        pre = __fadd_rn(pre, __fmul_rn(rw[t], disc));
+        disc = __fmul_rn(disc, p.gamma);
     }
     p.expect_return[n] = er;
 }

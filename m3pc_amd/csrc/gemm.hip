@@ -233,6 +233,68 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int S, int 
     }
 }
 
+// Same reduction, one wave per output row, followed by the LayerNorm that consumes the row (GemmP::ln_*): saves the
+// separate LayerNorm launch of the few-row fp32 passes.  Column layout and summation order are those of
+// layernorm_vec_kernel (elementwise.hip), so fused and unfused paths give identical bits.
+typedef float f32x4r __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float wave_sum_r(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(GemmP p, int S, int exact_gelu) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.M) return;
+    const long long mn = (long long)p.M * p.N;
+    const int n = p.N >> 8;  // slabs of 256 columns (<= 4)
+    f32x4r v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < n) {
+            const int c = i * 256 + lane * 4;
+            f32x4r a = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < S; ++k) a += *(const f32x4r*)(p.ws + k * mn + (long long)r * p.N + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = a[e];
+                if (p.bias) x += p.bias[c + e];
+                if (p.rowtab) x += p.rowtab[(long long)(r % p.rt_mod) * p.rt_ld + c + e];
+                if (p.gelu) x = exact_gelu ? gelu_exact(x) : gelu_fast(x);
+                if (p.res) x += p.res[(long long)r * p.ldr + c + e];
+                a[e] = x;
+            }
+            *(f32x4r*)(p.Cf + (long long)r * p.ldc + c) = a;
+            v[i] = a;
+            s += (a[0] + a[1]) + (a[2] + a[3]);
+        }
+    const float inv_d = 1.0f / (float)p.N;
+    const float mean = wave_sum_r(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < n) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c = v[i][e] - mean;
+                q += c * c;
+            }
+        }
+    const float rstd = rsqrtf(wave_sum_r(q) * inv_d + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < n) {
+            const int c = i * 256 + lane * 4;
+            const f32x4r g = *(const f32x4r*)(p.ln_g + c);
+            const f32x4r b = *(const f32x4r*)(p.ln_b + c);
+            f32x4r y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            *(f32x4r*)(p.ln_out + (long long)r * p.N + c) = y;
+        }
+}
+
 template <typename T, int BM, int BN, int EPI>
 static void launch_cfg(const GemmP& p, hipStream_t st) {
     const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
@@ -240,7 +302,7 @@ static void launch_cfg(const GemmP& p, hipStream_t st) {
 }
 
 template <typename T, int EPI>
-static void launch_epi(const GemmP& p, hipStream_t st) {
+static int launch_epi(const GemmP& p, hipStream_t st) {
     // 128x128 tiles only when they still fill the chip twice over; otherwise 64x64 tiles (4x the blocks):
     // the batch-1 policy pass and the top-k re-score are latency-bound on few rows.
     const long long big_tiles = (long long)((p.M + 127) / 128) * (p.N / 128);
@@ -250,7 +312,10 @@ static void launch_epi(const GemmP& p, hipStream_t st) {
         const long long tiles = (long long)((p.M + 63) / 64) * (p.N / 64);
         const int nkt = (int)((long long)p.K * sizeof(T) / 128);
         int S = 1;
-        if (sizeof(T) == 4 && p.ws && tiles < 768) {
+        // measured (tools/gemm_bench_f32.py): with >= 200 tiles and a 16-k-tile chain (K = 512) one pass beats
+        // split + reduce (top-16 re-score: QKV 23.9 vs 31.3 us, FFN1 27.8 vs 38.5 us); K = 2048 chains and the
+        // batch-1 policy pass (2-32 tiles) still want the split
+        if (sizeof(T) == 4 && p.ws && tiles < 768 && (tiles < 200 || nkt > 16)) {
             S = (int)((1023 + tiles) / tiles);
             if (S > nkt / 4) S = nkt / 4;
             if (S > 16) S = 16;
@@ -258,6 +323,11 @@ static void launch_epi(const GemmP& p, hipStream_t st) {
         }
         if (S > 1) {
             hipLaunchKernelGGL((gemm_kernel<T, 64, 64, EPI_SPLITK>), dim3((unsigned)tiles, S), dim3(256), 0, st, p);
+            if (p.ln_g && p.ln_out && p.Cf && !p.Cb && p.cmap.rpg == 0 && p.N % 256 == 0 && p.N <= 1024 && p.ldc % 4 == 0 &&
+                (!p.res || p.ldr % 4 == 0)) {
+                hipLaunchKernelGGL(splitk_reduce_ln_kernel, dim3((p.M + 3) / 4), dim3(256), 0, st, p, S, (int)(sizeof(T) == 4));
+                return 1;
+            }
             const long long n = (long long)p.M * p.N;
             const int g = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, p, S, (int)(sizeof(T) == 4));
@@ -267,37 +337,39 @@ static void launch_epi(const GemmP& p, hipStream_t st) {
     } else {
         launch_cfg<T, 128, 128, EPI>(p, st);
     }
+    return 0;
 }
 
 template <typename T>
-static void launch_t(const GemmP& p, hipStream_t st) {
+static int launch_t(const GemmP& p, hipStream_t st) {
     const bool f32out = sizeof(T) == 4 || p.Cf != nullptr;
     const int epi = (p.gelu ? EPI_GELU : 0) | (p.res ? EPI_RES : 0) | (p.rowtab ? EPI_ROWTAB : 0) |
                     (f32out && sizeof(T) == 2 ? EPI_F32OUT : 0);
     switch (epi) {
-        case 0: launch_epi<T, 0>(p, st); break;
-        case EPI_F32OUT: launch_epi<T, EPI_F32OUT>(p, st); break;
-        case EPI_GELU: launch_epi<T, EPI_GELU>(p, st); break;
-        case EPI_GELU | EPI_F32OUT: launch_epi<T, EPI_GELU | EPI_F32OUT>(p, st); break;
-        case EPI_RES: launch_epi<T, EPI_RES>(p, st); break;
-        case EPI_RES | EPI_F32OUT: launch_epi<T, EPI_RES | EPI_F32OUT>(p, st); break;
-        case EPI_ROWTAB: launch_epi<T, EPI_ROWTAB>(p, st); break;
-        case EPI_ROWTAB | EPI_F32OUT: launch_epi<T, EPI_ROWTAB | EPI_F32OUT>(p, st); break;
-        default: break;  // no caller combines the remaining flags
+        case 0: return launch_epi<T, 0>(p, st);
+        case EPI_F32OUT: return launch_epi<T, EPI_F32OUT>(p, st);
+        case EPI_GELU: return launch_epi<T, EPI_GELU>(p, st);
+        case EPI_GELU | EPI_F32OUT: return launch_epi<T, EPI_GELU | EPI_F32OUT>(p, st);
+        case EPI_RES: return launch_epi<T, EPI_RES>(p, st);
+        case EPI_RES | EPI_F32OUT: return launch_epi<T, EPI_RES | EPI_F32OUT>(p, st);
+        case EPI_ROWTAB: return launch_epi<T, EPI_ROWTAB>(p, st);
+        case EPI_ROWTAB | EPI_F32OUT: return launch_epi<T, EPI_ROWTAB | EPI_F32OUT>(p, st);
+        default: return 0;  // no caller combines the remaining flags
     }
 }
 
-void launch_gemm(const GemmP& p, int dtype, hipStream_t st) {
-    if (p.M <= 0) return;
+// returns 1 when the LayerNorm described by p.ln_* was applied as part of the launch (see GemmP), else 0
+int launch_gemm(const GemmP& p, int dtype, hipStream_t st) {
+    if (p.M <= 0) return 0;
     // default (variant 0): many-row bf16 problems on the LDS-DMA kernel (gemm_glds.hip, 128x128 tiles),
     // few-row problems on the register-staged kernel below; variants 4-9 are the experimental tilings
-    if (dtype == DT_BF16 && p.variant == 9 && launch_gemm_persist(p, st)) return;
-    if (dtype == DT_BF16 && p.variant >= 7 && p.variant != 9 && p.variant < 20 && launch_gemm_ring(p, st)) return;
-    if (dtype == DT_BF16 && (p.variant == 0 || (p.variant >= 2 && p.variant < 7) || (p.variant >= 20 && p.variant <= 23)) && launch_gemm_glds(p, st)) return;
-    if (dtype == DT_BF16)
-        launch_t<bf16_t>(p, st);
-    else
-        launch_t<float>(p, st);
+    if (dtype == DT_BF16 && p.variant == 9 && launch_gemm_persist(p, st)) return 0;
+    if (dtype == DT_BF16 && p.variant >= 7 && p.variant != 9 && p.variant < 20 && launch_gemm_ring(p, st)) return 0;
+    if (dtype == DT_BF16 && (p.variant == 0 || (p.variant >= 2 && p.variant < 7) || (p.variant >= 20 && p.variant <= 23)) &&
+        launch_gemm_glds(p, st))
+        return 0;
+    if (dtype == DT_BF16) return launch_t<bf16_t>(p, st);
+    return launch_t<float>(p, st);
 }
 
 }  // namespace m3pc

@@ -45,8 +45,14 @@ struct GemmP {
     long long ws_bytes;
     int variant;   // 0 = default kernel selection; other values pick experimental configurations
     int peel;      // set by launch_gemm_glds: rows >= peel are covered by small tiles (0 = off); callers leave it 0
+    // optional: the LayerNorm that consumes C (fp32, N % 256 == 0, identity cmap).  When the launcher takes the
+    // split-K route its row-wise reduce also writes ln_out = LayerNorm(C row) and launch_gemm returns 1; otherwise
+    // it returns 0 and the caller launches the LayerNorm itself.
+    const float* ln_g;
+    const float* ln_b;
+    float* ln_out;
 };
-void launch_gemm(const GemmP& p, int dtype, hipStream_t st);
+int launch_gemm(const GemmP& p, int dtype, hipStream_t st);
 bool launch_gemm_ring(const GemmP& p, hipStream_t st);  // bf16, many rows: 256x256 tile, 4-slot LDS-DMA ring (gemm_ring.hip)
 bool launch_gemm_persist(const GemmP& p, hipStream_t st);  // bf16, many rows: persistent 256x256 tiles (gemm_persist.hip)
 bool launch_gemm_glds(const GemmP& p, hipStream_t st);  // bf16, many rows: direct-to-LDS staging (gemm_glds.hip)

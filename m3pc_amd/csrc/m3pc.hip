@@ -270,14 +270,15 @@ struct GemmTimer {
     }
 };
 
-void gemm(m3pc_handle* h, const GemmP& p_in, int dt, hipStream_t st) {
+// returns 1 when the LayerNorm named by p_in.ln_* was fused into the launch (GemmP::ln_g)
+int gemm(m3pc_handle* h, const GemmP& p_in, int dt, hipStream_t st) {
     GemmP p = p_in;
     // split-K changes the association of the K sum, so it is only allowed where every rank / shard runs the
     // same row count (policy pass, generic forward, top-k re-score): sharded candidate scores stay bit-identical
     p.ws = h->allow_splitk ? h->splitk_ws : nullptr;
     p.ws_bytes = h->splitk_ws_bytes;
     GemmTimer t(h, st, 2.0 * p.M * (double)p.N * p.K, dt);
-    launch_gemm(p, dt, st);
+    return launch_gemm(p, dt, st);
 }
 
 GemmP gemm_basic(const void* A, int lda, const void* Wp, int ldw, int M, int N, int K, const float* bias) {
@@ -376,8 +377,10 @@ void invalidate_tables(m3pc_handle* h) {
 
 // ---------------------------------------------------------------------------------- transformer block
 // One pre-LN layer (mtm_model.py:379-409) over `batch` sequences of L rows, in place on X (fp32).
+// next_ln: the LayerNorm that follows this block on X (next block's norm1 or the stack's final norm); when the
+// FFN2 GEMM can apply it in its split-K reduce, *next_ln_done is set and the caller skips that launch.
 int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L, int dt, hipStream_t st, bool ln1_done = false,
-              int n_sh = 0) {
+              int n_sh = 0, const LnP* next_ln = nullptr, bool* next_ln_done = nullptr) {
     const int d = h->d, ff = h->ff;
     const int rows = batch * L;
     const int es = (int)dtype_size(dt);
@@ -482,11 +485,15 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
         p.res = X;
         p.ldr = d;
         gemm_out(p, DT_F32, X, d);
-        gemm(h, p, dt, st);
+        ln.g1 = W(h, pfx + ".norm2.weight").f;
+        ln.b1 = W(h, pfx + ".norm2.bias").f;
+        if (dt == DT_F32) {  // few-row fp32 passes: norm2 rides on the split-K reduce when there is one
+            p.ln_g = ln.g1;
+            p.ln_b = ln.b1;
+            p.ln_out = ln.Yf;
+        }
+        if (!gemm(h, p, dt, st)) launch_layernorm(ln, st);
     }
-    ln.g1 = W(h, pfx + ".norm2.weight").f;
-    ln.b1 = W(h, pfx + ".norm2.bias").f;
-    launch_layernorm(ln, st);
     {
         GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".linear1.weight", dt), d, rows, ff, d, W(h, pfx + ".linear1.bias").f);
         p.gelu = 1;
@@ -498,7 +505,14 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
         p.res = X;
         p.ldr = d;
         gemm_out(p, DT_F32, X, d);
-        gemm(h, p, dt, st);
+        if (dt == DT_F32 && next_ln && next_ln->Yf && !next_ln->Yb && !next_ln->g2 && next_ln->X == X && next_ln->xmap.rpg == 0 &&
+            next_ln->rows == rows) {
+            p.ln_g = next_ln->g1;
+            p.ln_b = next_ln->b1;
+            p.ln_out = next_ln->Yf;
+        }
+        const int done = gemm(h, p, dt, st);
+        if (next_ln_done) *next_ln_done = done != 0;
     }
     return check_launch(pfx.c_str());
 }
@@ -545,8 +559,6 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
     else
         e.Hf = (float*)h->Hn;
     launch_embed(e, st);
-    for (int i = 0; i < h->dm.n_enc_layer; ++i)
-        CHK(run_block(h, "encoder.layers." + std::to_string(i), h->X, batch, pl->Le, dt, st, i == 0, i == 0 ? n_sh : 0));
     LnP ln;
     memset(&ln, 0, sizeof(ln));
     ln.X = h->X;
@@ -559,7 +571,21 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
         ln.Yb = (bf16_t*)h->Z;  // the candidate pass consumes the encoder output only as a bf16 GEMM operand
     else
         ln.Yf = h->EncOut;
-    launch_layernorm(ln, st);
+    bool ln_done = true;  // norm1 of layer 0 comes from the embedding kernel
+    const int nl = h->dm.n_enc_layer;
+    for (int i = 0; i < nl; ++i) {
+        LnP nxt = ln;  // what follows layer i on X: norm1 of layer i+1 (-> Hn) or encoder.norm (-> EncOut / Z)
+        if (i + 1 < nl) {
+            nxt.g1 = W(h, "encoder.layers." + std::to_string(i + 1) + ".norm1.weight").f;
+            nxt.b1 = W(h, "encoder.layers." + std::to_string(i + 1) + ".norm1.bias").f;
+            nxt.Yb = nullptr;
+            nxt.Yf = dt == DT_F32 ? (float*)h->Hn : nullptr;
+        }
+        const bool l1 = ln_done;
+        ln_done = false;
+        CHK(run_block(h, "encoder.layers." + std::to_string(i), h->X, batch, pl->Le, dt, st, l1, i == 0 ? n_sh : 0, &nxt, &ln_done));
+    }
+    if (!ln_done) launch_layernorm(ln, st);
     return check_launch("encoder");
 }
 
@@ -1518,6 +1544,12 @@ int m3pc_debug_gemm(int dtype, const void* A, const void* Wt, const float* bias,
     else
         p.Cf = (float*)C;
     p.ldc = N;
+    if (dtype == DT_F32 && variant != 1) {  // split-K workspace as the handle provides it (variant 1: none)
+        static float* ws = nullptr;
+        if (!ws) HIPCHK(hipMalloc((void**)&ws, 64 << 20));
+        p.ws = ws;
+        p.ws_bytes = 64 << 20;
+    }
     launch_gemm(p, dtype, (hipStream_t)stream);
     return check_launch("debug_gemm");
 }
