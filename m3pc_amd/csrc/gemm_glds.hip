@@ -45,7 +45,17 @@ typedef void __attribute__((address_space(3))) * lptr_t;
 // LDS => more workgroups per CU, i.e. more tiles in flight against the DMA latency)
 //
 // One output tile.  `bid` is the tile's index among the `ntm` x (N / BN) tiles that cover rows [row_begin, ...).
-template <int BM, int BN, int EPI, int WM, int WN, int ROWB>
+// NSLOT = 2: double buffer, one stage in flight, __syncthreads per stage.  NSLOT = 3 (with ROWB = 64): ring of three
+// 32-deep stages, two in flight, counted s_waitcnt vmcnt + raw s_barrier (a __syncthreads would drain the DMA queue),
+// 48 KiB of LDS per 128x128 workgroup => three workgroups per CU.
+template <int N>
+__device__ __forceinline__ void glds_wait_barrier() {
+    static_assert(N == 0 || N == 2 || N == 4, "add the immediate");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+}
+template <int BM, int BN, int EPI, int WM, int WN, int ROWB, int NSLOT = 2>
 __device__ __forceinline__ void gemm_glds_tile(const GemmP& p, char* smem, int bid, const int ntm, const int row_begin) {
     constexpr int RPI = 1024 / ROWB;   // tile rows per 1-KiB DMA instruction
     constexpr int LPR = ROWB / 16;     // lanes (16-byte chunks) per row
@@ -90,7 +100,7 @@ __device__ __forceinline__ void gemm_glds_tile(const GemmP& p, char* smem, int b
     const int wave_dst = __builtin_amdgcn_readfirstlane(wid) * 1024;
 
     const bool dbg_noload = p.variant == 20 || p.variant == 22;   // timing experiments (tools/gemm_bench.py)
-    const bool dbg_nostore = p.variant == 21 || p.variant == 22;
+    const bool dbg_nostore = p.variant == 21 || p.variant == 22 || p.variant == 24 || p.variant == 25;
     auto issue = [&](int kt, int buf) {
         if (dbg_noload) return;
         char* base = smem + buf * BUF + wave_dst;
@@ -156,11 +166,47 @@ __device__ __forceinline__ void gemm_glds_tile(const GemmP& p, char* smem, int b
     const int fragA = wr * WTM * ROWB;
     const int fragW = BM * ROWB + wc * WTN * ROWB;
 
+    if constexpr (NSLOT == 3) {
+        constexpr int PER = NI_A + NI_W;  // DMA wave-instructions per stage
+        // VMEM order so far: stage 0, (residual prefetch), now stage 1: "all but the newest PER" = stage kt landed
+        if (nkt > 1) issue(1, 1);
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt + 1 < nkt)
+                glds_wait_barrier<PER>();
+            else
+                glds_wait_barrier<0>();
+            // every wave has finished reading slot (kt-1)%3 = (kt+2)%3 before it passed this barrier
+            if (kt + 2 < nkt) issue(kt + 2, (kt + 2) % 3);
+            const char* cur = smem + (kt % 3) * BUF;
+            u32x4 fa[KS][TM], fw[KS][TN];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[s][i] = *(const u32x4*)(cur + fragA + i * 32 * ROWB + foff[s]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fw[s][j] = *(const u32x4*)(cur + fragW + j * 32 * ROWB + foff[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, fa[s][i]), __builtin_bit_cast(bf16x8, fw[s][j]), acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    }
+
     __syncthreads();  // (the compiler drains vmcnt before a barrier while LDS-DMA is outstanding)
 
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = NSLOT == 3 ? nkt : 0; kt < nkt; ++kt) {
         const char* cur = smem + (kt & 1) * BUF;
         if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+        if (p.variant == 24 || p.variant == 25) {  // timing experiment: DMA stream + barriers only, no LDS reads / MFMA
+            __syncthreads();
+            continue;
+        }
         if constexpr (TM == 4 && TN == 2 && ROWB == 128) {
             // Hand-scheduled stage (hipcc serialises this loop with lgkmcnt(0) after every few reads): two
             // fragment register sets; the 6 ds_read_b128 of k-step s+1 are in flight under the 8 MFMAs of
@@ -420,6 +466,55 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_glds_kernel(GemmP p) {
     }
 }
 
+// 128x128 tile on the three-slot ring (NSLOT = 3): 48 KiB of LDS and <= 168 VGPRs => three workgroups per CU
+template <int EPI>
+__global__ __launch_bounds__(256, 3) void gemm_glds_ring3_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(1024))) char smem[3 * (128 + 128) * 64];
+    if (p.peel > 0) {  // rows >= peel on 64x64 tiles whose workgroups come first in the grid (see gemm_glds_kernel)
+        const int ntm_tail = (p.M - p.peel + 63) / 64;
+        const int n_tail = ntm_tail * (p.N / 64);
+        if ((int)blockIdx.x < n_tail) {
+            gemm_glds_tile<64, 64, EPI, 2, 2, 64, 3>(p, smem, blockIdx.x, ntm_tail, p.peel);
+            return;
+        }
+        gemm_glds_tile<128, 128, EPI, 2, 2, 64, 3>(p, smem, blockIdx.x - n_tail, p.peel / 128, 0);
+        return;
+    }
+    gemm_glds_tile<128, 128, EPI, 2, 2, 64, 3>(p, smem, blockIdx.x, (p.M + 127) / 128, 0);
+}
+static bool launch_ring3(const GemmP& p, hipStream_t st) {
+    const bool f32out = p.Cf != nullptr;
+    const int epi = (p.gelu ? EPI_GELU : 0) | (p.res ? EPI_RES : 0) | (p.rowtab ? EPI_ROWTAB : 0) | (f32out ? EPI_F32OUT : 0);
+    const int tiles = p.peel > 0 ? (p.peel / 128) * (p.N / 128) + ((p.M - p.peel + 63) / 64) * (p.N / 64)
+                                 : ((p.M + 127) / 128) * (p.N / 128);
+    const dim3 grid(tiles), block(256);
+    switch (epi) {
+        case 0: hipLaunchKernelGGL(gemm_glds_ring3_kernel<0>, grid, block, 0, st, p); return true;
+        case EPI_F32OUT: hipLaunchKernelGGL(gemm_glds_ring3_kernel<EPI_F32OUT>, grid, block, 0, st, p); return true;
+        case EPI_GELU: hipLaunchKernelGGL(gemm_glds_ring3_kernel<EPI_GELU>, grid, block, 0, st, p); return true;
+        case EPI_GELU | EPI_F32OUT: hipLaunchKernelGGL(gemm_glds_ring3_kernel<EPI_GELU | EPI_F32OUT>, grid, block, 0, st, p); return true;
+        case EPI_RES | EPI_F32OUT: hipLaunchKernelGGL(gemm_glds_ring3_kernel<EPI_RES | EPI_F32OUT>, grid, block, 0, st, p); return true;
+        case EPI_ROWTAB | EPI_F32OUT: hipLaunchKernelGGL(gemm_glds_ring3_kernel<EPI_ROWTAB | EPI_F32OUT>, grid, block, 0, st, p); return true;
+        default: return false;
+    }
+}
+// p.peel for `slots` resident 128x128 workgroups: the largest row count whose tiles fill whole rounds, when the
+// remaining partial round would be less than half full and the peeled rows are few (else 0)
+static int peel_rows(const GemmP& p, int slots) {
+    const int ntm = (p.M + 127) / 128, ntn = p.N / 128;
+    int g = slots, b = ntn;
+    while (b) {
+        const int t = g % b;
+        g = b;
+        b = t;
+    }
+    const int step = slots / g;  // row tiles per whole number of rounds
+    const int ntm_main = (ntm / step) * step;
+    const long long rem = ((long long)ntm * ntn) % slots;
+    if (ntm_main > 0 && rem != 0 && rem * 2 < slots && p.M - ntm_main * 128 <= 4096) return ntm_main * 128;
+    return 0;
+}
+
 template <int BM, int BN, int EPI, int WM, int WN, int ROWB = 128>
 static void launch_cfg(const GemmP& p, hipStream_t st) {
     if (p.peel > 0) {
@@ -459,23 +554,21 @@ bool launch_gemm_glds(const GemmP& p, hipStream_t st) {
     if (p.variant == 6) return launch_tile<256, 128, 4, 2>(p, st);
     if (p.variant == 3) return launch_tile<128, 128, 2, 2>(p, st);
     if (p.variant == 2) return launch_tile<128, 128, 2, 2, 64>(p, st);
-    if (p.variant >= 20 && p.variant <= 22) return launch_tile<128, 128, 2, 2>(p, st);
-    // default selection (measured with tools/gemm_bench.py on the plan step's shapes, after the epilogue's
-    // address arithmetic moved to scalar registers): 128x128 tiles at two workgroups per CU win or tie on every
-    // shape -- one workgroup's epilogue (VALU + stores) runs beside the other's MFMAs.
+    if ((p.variant >= 20 && p.variant <= 22) || p.variant == 24) return launch_tile<128, 128, 2, 2>(p, st);
+    if (p.variant == 25 && p.N % 256 == 0) return launch_tile<256, 256, 2, 4>(p, st);
     GemmP q = p;
     q.peel = 0;
-    if (p.variant != 23) {
-        const int slots = 512;  // 256 CUs x 2 resident workgroups (64 KiB of LDS each)
-        const int ntm = (p.M + 127) / 128, ntn = p.N / 128;
-        int g = slots, b = ntn;
-        while (b) { const int t = g % b; g = b; b = t; }
-        const int step = slots / g;                 // row tiles per whole number of rounds
-        const int ntm_main = (ntm / step) * step;
-        const long long rem = ((long long)ntm * ntn) % slots;
-        // peel when the last round would be less than half full and the peeled rows are few
-        if (ntm_main > 0 && rem != 0 && rem * 2 < slots && p.M - ntm_main * 128 <= 4096) q.peel = ntm_main * 128;
+    if (p.variant == 26) return launch_ring3(q, st);  // ring, no peeling
+    if (p.variant == 23 || p.variant == 27) {         // double buffer, two workgroups per CU (23: no peeling)
+        if (p.variant == 27) q.peel = peel_rows(p, 512);
+        return launch_tile<128, 128, 2, 2>(q, st);
     }
+    // default selection (measured with tools/gemm_bench.py on the plan step's shapes): 128x128 tiles on the
+    // three-slot ring, three workgroups per CU -- two 16-KiB stages in flight per workgroup against the DMA latency,
+    // and one workgroup's epilogue (VALU + stores) runs beside the others' MFMAs.  -9 % over the double buffer.
+    q.peel = peel_rows(p, 768);
+    if (launch_ring3(q, st)) return true;
+    q.peel = peel_rows(p, 512);
     return launch_tile<128, 128, 2, 2>(q, st);
 }
 

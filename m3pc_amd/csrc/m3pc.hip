@@ -277,6 +277,8 @@ int gemm(m3pc_handle* h, const GemmP& p_in, int dt, hipStream_t st) {
     // same row count (policy pass, generic forward, top-k re-score): sharded candidate scores stay bit-identical
     p.ws = h->allow_splitk ? h->splitk_ws : nullptr;
     p.ws_bytes = h->splitk_ws_bytes;
+    static const int env_variant = getenv("M3PC_GEMM_VARIANT") ? atoi(getenv("M3PC_GEMM_VARIANT")) : 0;  // A/B runs
+    if (env_variant) p.variant = env_variant;
     GemmTimer t(h, st, 2.0 * p.M * (double)p.N * p.K, dt);
     return launch_gemm(p, dt, st);
 }
@@ -994,13 +996,17 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
             p.ldr = d;
         }
         gemm_out(p, DT_F32, Y1, d);
-        gemm(h, p, dt, st);
+        ln.X = Y1;
+        ln.rows = n * nq;
+        ln.g1 = W(h, pfx + ".norm2.weight").f;
+        ln.b1 = W(h, pfx + ".norm2.bias").f;
+        if (dt == DT_F32) {  // re-score: norm2 rides on the split-K reduce when there is one
+            p.ln_g = ln.g1;
+            p.ln_b = ln.b1;
+            p.ln_out = ln.Yf;
+        }
+        if (!gemm(h, p, dt, st)) launch_layernorm(ln, st);
     }
-    ln.X = Y1;
-    ln.rows = n * nq;
-    ln.g1 = W(h, pfx + ".norm2.weight").f;
-    ln.b1 = W(h, pfx + ".norm2.bias").f;
-    launch_layernorm(ln, st);
     {
         GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".linear1.weight", dt), d, n * nq, h->ff, d, W(h, pfx + ".linear1.bias").f);
         p.gelu = 1;
