@@ -99,8 +99,9 @@ __device__ __forceinline__ void gemm_glds_tile(const GemmP& p, char* smem, int b
     }
     const int wave_dst = __builtin_amdgcn_readfirstlane(wid) * 1024;
 
-    const bool dbg_noload = p.variant == 20 || p.variant == 22;   // timing experiments (tools/gemm_bench.py)
-    const bool dbg_nostore = p.variant == 21 || p.variant == 22 || p.variant == 24 || p.variant == 25;
+    // timing experiments (tools/gemm_bench.py): 20-22 / 24-25 on the double buffer, 28-30 on the ring
+    const bool dbg_noload = p.variant == 20 || p.variant == 22 || p.variant == 28 || p.variant == 30;
+    const bool dbg_nostore = p.variant == 21 || p.variant == 22 || p.variant == 24 || p.variant == 25 || p.variant == 29 || p.variant == 30;
     auto issue = [&](int kt, int buf) {
         if (dbg_noload) return;
         char* base = smem + buf * BUF + wave_dst;
@@ -558,7 +559,7 @@ bool launch_gemm_glds(const GemmP& p, hipStream_t st) {
     if (p.variant == 25 && p.N % 256 == 0) return launch_tile<256, 256, 2, 4>(p, st);
     GemmP q = p;
     q.peel = 0;
-    if (p.variant == 26) return launch_ring3(q, st);  // ring, no peeling
+    if (p.variant == 26 || (p.variant >= 28 && p.variant <= 30)) return launch_ring3(q, st);  // ring, no peeling
     if (p.variant == 23 || p.variant == 27) {         // double buffer, two workgroups per CU (23: no peeling)
         if (p.variant == 27) q.peel = peel_rows(p, 512);
         return launch_tile<128, 128, 2, 2>(q, st);
