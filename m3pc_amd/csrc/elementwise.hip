@@ -459,6 +459,12 @@ void launch_actor_head(const ActorP& p, hipStream_t st) {
 // ------------------------------------------------------------------------------------------ sampling
 __global__ __launch_bounds__(256) void sample_kernel(SampleP p) {
     const long long tot = (long long)p.n_count * p.T * p.A;
+    if (blockIdx.x == 0) {
+        for (int x = threadIdx.x; x < p.T * p.A; x += blockDim.x) {
+            if (p.loc_out) p.loc_out[x] = p.loc[x];
+            if (p.sd_out) p.sd_out[x] = p.sd[x];
+        }
+    }
     for (long long x = blockIdx.x * (long long)blockDim.x + threadIdx.x; x < tot; x += (long long)gridDim.x * blockDim.x) {
         const int a = (int)(x % p.A);
         const int t = (int)((x / p.A) % p.T);

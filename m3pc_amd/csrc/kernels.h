@@ -191,6 +191,8 @@ struct SampleP {
     const int* index;           // optional (n_count,): candidate n reads eps row index[n] instead of n_begin+n
     float* cand;                // (n_count, T, A)
     float* sample_actions;      // (n_count, h, A)
+    float* loc_out;             // optional (T, A) copies of loc / sd for the caller (saves two D2D copy launches)
+    float* sd_out;
 };
 void launch_sample(const SampleP& p, hipStream_t st);
 
@@ -243,7 +245,7 @@ void launch_select(const SelectP& p, hipStream_t st);
 // indices of the k largest values (descending; ties -> lower index first), n <= 16384, k <= n
 void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st);
 // dst[index[i]] = src[i]
-void launch_scatter(const float* src, const int* index, int n, float* dst, hipStream_t st);
+void launch_scatter(const float* src, const int* index, int n, float* dst, int* index_copy, hipStream_t st);  // + index_copy[i] = index[i]
 
 void launch_tokenize(const void* in, int in_f64, float* out, long long rows, int D, const float* mean,
                      const float* stdv, int normalize, hipStream_t st);

@@ -1414,8 +1414,6 @@ int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     h->allow_splitk = true;
     CHK(forward_impl(h, pl, in, 1, nullptr, nullptr, nullptr, h->loc, h->sd, DT_F32, st));
     h->allow_splitk = false;
-    if (loc) HIPCHK(hipMemcpyAsync(loc, h->loc, (size_t)T * h->A * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (std_) HIPCHK(hipMemcpyAsync(std_, h->sd, (size_t)T * h->A * sizeof(float), hipMemcpyDeviceToDevice, st));
     h->policy_valid = true;
 
     // candidates
@@ -1434,6 +1432,8 @@ int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     sp.n_count = a->n_count;
     sp.cand = h->cand;
     sp.sample_actions = sample_actions;
+    sp.loc_out = loc;  // the caller's copies of the policy head ride on this launch
+    sp.sd_out = std_;
     launch_sample(sp, st);
 
     // PASS 2 + scoring.  Large bf16 batches are cut into two candidate halves that run the same kernel chain
@@ -1507,8 +1507,7 @@ int m3pc_rescore_topk(m3pc_handle* h, const m3pc_plan_args* a, const float* stat
     HIPCHK(hipSetDevice(h->device));
     launch_topk(expect_return, a->n_total, k, h->d_topk, st);
     CHK(m3pc_rescore(h, a, states, actions, rewards, eps, h->d_topk, k, nullptr, h->er_top, stream));
-    launch_scatter(h->er_top, h->d_topk, k, expect_return, st);
-    if (topk_index) HIPCHK(hipMemcpyAsync(topk_index, h->d_topk, (size_t)k * sizeof(int), hipMemcpyDeviceToDevice, st));
+    launch_scatter(h->er_top, h->d_topk, k, expect_return, topk_index, st);
     return check_launch("rescore_topk");
 }
 

@@ -131,13 +131,16 @@ void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st) {
     hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), (size_t)np * 8, st, v, n, np, k, idx_out);
 }
 
-__global__ void scatter_kernel(const float* src, const int* index, int n, float* dst) {
+__global__ void scatter_kernel(const float* src, const int* index, int n, float* dst, int* index_copy) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[index[i]] = src[i];
+    if (i < n) {
+        dst[index[i]] = src[i];
+        if (index_copy) index_copy[i] = index[i];
+    }
 }
-void launch_scatter(const float* src, const int* index, int n, float* dst, hipStream_t st) {
+void launch_scatter(const float* src, const int* index, int n, float* dst, int* index_copy, hipStream_t st) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, index, n, dst);
+    hipLaunchKernelGGL(scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, index, n, dst, index_copy);
 }
 
 }  // namespace m3pc
