@@ -164,6 +164,17 @@ def main():
     # roofline of the dominant kernel class (the MFMA GEMM): a second, instrumented pass of the same K
     # steps with hipEvents around every GEMM launch on the launch stream (events perturb the step time,
     # so they are kept out of the timed region above).
+    # per-step latency distribution: one event pair per step on the launch stream, outside the timed region
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 200))]
+    for e0, e1 in pairs:
+        e0.record()
+        step()
+        e1.record()
+    torch.cuda.synchronize()
+    lat = sorted(e0.elapsed_time(e1) for e0, e1 in pairs)
+    latency = {"p50": round(lat[len(lat) // 2], 4), "p99": round(lat[min(len(lat) - 1, int(0.99 * len(lat)))], 4),
+               "min": round(lat[0], 4), "steps": len(lat)}
+
     n_local = mdist_count(n_global, rank, world)
     planner.handle.profile_enable(True)
     planner.handle.profile_read(reset=True)
@@ -199,7 +210,7 @@ def main():
                                       f"T={T} {args.precision} candidate pass + fp32 policy pass + fp32 top-{args.rescore_topk} re-score",
                           "candidates_per_gpu": n_local, "global_candidates": n_global, "horizon": H, "traj_length": T,
                           "parallelism": f"candidate-shard x{world}"},
-               "roofline": roofline}
+               "latency_ms": latency, "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, dict(horizon=H, action_samples=args.candidates), hist, 3.0)
         print(json.dumps(out), flush=True)

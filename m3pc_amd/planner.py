@@ -37,7 +37,7 @@ class HipPlanner:
     def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], tokenizer_manager, q_state_dict=None,
                  obs_mean=None, obs_std=None, n_embd: int = 512, n_head: int = 4, n_enc_layer: int = 2,
                  n_dec_layer: int = 1, precision: str = "fp32", rescore_topk: int = 16, device: Optional[int] = None,
-                 group=None, generator: Optional[torch.Generator] = None):
+                 group=None, generator: Optional[torch.Generator] = None, max_batch: int = 1):
         """cfg: any object with traj_length, action_samples, horizon, discount, temperature, lmbda,
         plan_guidance (finetune.py RunConfig fields read at learner.py:276,319,342).
         tokenizer_manager: a TokenizerManager (this package's) or {key: {"mean","std","min","max"}}.
@@ -55,7 +55,8 @@ class HipPlanner:
         _, n_local = mdist.shard_range(N, 0, self.world)
         hidden = 0 if q_state_dict is None else q_state_dict["q1.net.0.weight"].shape[0]
         self.handle = capi.Handle(S, A, T, n_embd, n_head, n_enc_layer, n_dec_layer,
-                                  max_candidates=max(n_local, rescore_topk, 1), max_batch=1, critic_hidden=hidden,
+                                  max_candidates=max(n_local, rescore_topk, 1), max_batch=max(int(max_batch), 1),
+                                  critic_hidden=hidden,
                                   device=device)
         self.device = self.handle.device
         self.S, self.A, self.T = S, A, T
@@ -256,6 +257,43 @@ class HipPlanner:
         toks[0] = self.handle.tokenize(capi.STATES, s[None])
         self.last = dict(state_inference=inferred, window_states=s)
         return self._policy_from(toks, create_fid_mask(T, "cpu", idx), h, eval)
+
+    @torch.no_grad()
+    def action_piid_sample_batch(self, sequence_histories, percentage=1.0, eval=True, rtg=None):
+        """E independent goal-reaching windows per launch (BASELINE config 5 / SURVEY §8 f1): the reference plans one
+        env per call (zeroshot learner.py:151-261, unseen.py rollout loop); here the windows that share a horizon go
+        through the pi and fid forwards as ONE batch of the same kernels.  Per window the arithmetic is that of
+        ``action_piid_sample``.  Returns (E, A).  The planner must have been built with ``max_batch >= E``."""
+        if eval:
+            assert rtg is not None
+        from .masks import create_fid_mask, create_pi_mask, mask_rows
+        T, E = self.T, len(sequence_histories)
+        wins = [self.assemble_goal_window(hst, rtg, percentage) for hst in sequence_histories]
+        out = torch.empty((E, self.A), dtype=torch.float32, device=self.device)
+        infer = [None] * E
+        for h in sorted({w[3] for w in wins}):
+            ids = [i for i, w in enumerate(wins) if w[3] == h]
+            idx = T - h
+            s = torch.stack([wins[i][0] for i in ids])
+            a = torch.stack([wins[i][1] for i in ids]).contiguous()
+            r = torch.stack([wins[i][2] for i in ids])
+            ret = torch.tensor([wins[i][4] for i in ids], dtype=torch.float64, device=self.device)[:, None, None].expand(-1, T, 1)
+            toks = [self.handle.tokenize(capi.STATES, s), a, self.handle.tokenize(capi.REWARDS, r),
+                    self.handle.tokenize(capi.RETURNS, ret.contiguous())]
+            raw = self.handle.forward(toks, mask_rows(create_pi_mask(T, "cpu", idx)), want=("states",))["states"]
+            inferred = self.handle.detokenize(capi.STATES, raw)  # (B,T,S)
+            s = s.clone()
+            s[:, idx + 2 : T - 1] = inferred[:, idx + 2 : T - 1]
+            s[:, : idx + 1] = inferred[:, : idx + 1]
+            toks[0] = self.handle.tokenize(capi.STATES, s)
+            mu, sd = self.handle.forward(toks, mask_rows(create_fid_mask(T, "cpu", idx)), want=("actions",))["actions"]
+            dist_ = SquashedNormal(mu.unsqueeze(2), sd.unsqueeze(2))
+            act = dist_.mean if eval else dist_.sample(eps=self._eps(tuple(dist_.loc.shape)))
+            out[torch.tensor(ids, device=self.device)] = act[:, idx, 0]
+            for j, i in enumerate(ids):
+                infer[i] = inferred[j]
+        self.last = dict(state_inference=infer)
+        return out
 
     @torch.no_grad()
     def action_sample(self, sequence_history, percentage=1.0, horizon=4, plan=True, eval=False, rtg=None):

@@ -134,6 +134,33 @@ def test_zeroshot_goal_reaching_matches_reference_golden(pl):
     p.handle.close()
 
 
+def test_zeroshot_batched_windows_match_reference_goldens():
+    """BASELINE config 5 shape of the path: E goal-reaching windows per launch (here the four G3 windows, which
+    have two different horizons) -- each row must equal the reference's single-window result."""
+    g = np.load(os.path.join(GD, "g3_zeroshot.npz"))
+    dims = synth.Dims(11, 3, 8)
+    cfg = types.SimpleNamespace(traj_length=8, action_samples=1, horizon=4, discount=0.99, temperature=1.0, lmbda=0.6,
+                                plan_guidance="rtg_guiding", index_jump=4)
+    p = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None, max_batch=8)
+    pls = [0, 2, 37, 997, 37, 2]
+    hists = []
+    for pl in pls:
+        hist = synth.make_history(dims, 0)
+        hist["observations"] = g[f"obs_pl{pl}"]
+        hist["path_length"] = pl
+        hists.append(hist)
+    assert len({int(g[f"action_piid_sample_pl{pl}_horizon"]) for pl in pls}) > 1  # mixed horizons in one call
+    ev = p.action_piid_sample_batch(hists, percentage=1.0, eval=True, rtg=2.5)
+    assert ev.shape == (len(pls), 3)
+    for i, pl in enumerate(pls):
+        assert np.abs(ev[i].cpu().numpy() - g[f"action_piid_sample_pl{pl}_eval_action"][0]).max() < 2e-5
+        si = g[f"action_piid_sample_pl{pl}_state_inference"][0]
+        assert np.abs(p.last["state_inference"][i].cpu().numpy() - si).max() <= 2e-5 * max(1.0, float(np.abs(si).max()))
+    sa = p.action_piid_sample_batch(hists, percentage=1.0, eval=False, rtg=2.5)
+    assert sa.shape == (len(pls), 3) and float(sa.abs().max()) <= 1.0
+    p.handle.close()
+
+
 def test_omtm_and_tokenizer_mirror_compose_like_the_reference():
     """tokenizer_manager.decode(mtm(tokenizer_manager.encode(traj), mask)) -- the reference's idiom
     (learner.py:108-111) -- on the mirror classes."""
