@@ -19,6 +19,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 enum { EPI_GELU = 1, EPI_RES = 2, EPI_ROWTAB = 4, EPI_F32OUT = 8 };
 
+__device__ long long g_clock_probe[2];  // {shader clocks, 100-MHz wall ticks} of one workgroup (debug variants only)
+void read_clock_probe(long long out[2]) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_probe), 2 * sizeof(long long)); }
+
 __device__ __forceinline__ float gelu_fast2(float x) {
     const float ax = fabsf(x) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
@@ -50,10 +53,11 @@ typedef void __attribute__((address_space(3))) * lptr_t;
 // 48 KiB of LDS per 128x128 workgroup => three workgroups per CU.
 template <int N>
 __device__ __forceinline__ void glds_wait_barrier() {
-    static_assert(N == 0 || N == 2 || N == 4, "add the immediate");
+    static_assert(N == 0 || N == 2 || N == 4 || N == 6, "add the immediate");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
     if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
 }
 template <int BM, int BN, int EPI, int WM, int WN, int ROWB, int NSLOT = 2>
 __device__ __forceinline__ void gemm_glds_tile(const GemmP& p, char* smem, int bid, const int ntm, const int row_begin) {
@@ -481,8 +485,38 @@ __global__ __launch_bounds__(256, 3) void gemm_glds_ring3_kernel(GemmP p) {
         gemm_glds_tile<128, 128, EPI, 2, 2, 64, 3>(p, smem, blockIdx.x - n_tail, p.peel / 128, 0);
         return;
     }
+    // clock probe (variants 26/28-30, tools/gemm_bench.py --clock): shader-clock and 100-MHz wall counters around
+    // one mid-grid workgroup give the SIMD clock this kernel actually ran at
+    const bool probe = p.variant >= 26 && p.variant <= 30 && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+    long long c0 = 0, w0 = 0;
+    if (probe) {
+        c0 = clock64();
+        w0 = wall_clock64();
+    }
     gemm_glds_tile<128, 128, EPI, 2, 2, 64, 3>(p, smem, blockIdx.x, (p.M + 127) / 128, 0);
+    if (probe) {
+        g_clock_probe[0] = clock64() - c0;
+        g_clock_probe[1] = wall_clock64() - w0;
+    }
 }
+// experimental (variant 31): 256x128 tile, 4 waves with 128x64 wave tiles, same ring => 72 KiB, two workgroups per
+// CU, 0.75x the L2->LDS bytes per flop of the 128x128 tile.  Epilogues without a residual only.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_glds_ring3w_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(1024))) char smem[3 * (256 + 128) * 64];
+    gemm_glds_tile<256, 128, EPI, 2, 2, 64, 3>(p, smem, blockIdx.x, (p.M + 255) / 256, 0);
+}
+static bool launch_ring3w(const GemmP& p, hipStream_t st) {
+    const bool f32out = p.Cf != nullptr;
+    const int epi = (p.gelu ? EPI_GELU : 0) | (p.res ? EPI_RES : 0) | (p.rowtab ? EPI_ROWTAB : 0) | (f32out ? EPI_F32OUT : 0);
+    const dim3 grid(((p.M + 255) / 256) * (p.N / 128)), block(256);
+    switch (epi) {
+        case 0: hipLaunchKernelGGL(gemm_glds_ring3w_kernel<0>, grid, block, 0, st, p); return true;
+        case EPI_GELU: hipLaunchKernelGGL(gemm_glds_ring3w_kernel<EPI_GELU>, grid, block, 0, st, p); return true;
+        default: return false;
+    }
+}
+
 static bool launch_ring3(const GemmP& p, hipStream_t st) {
     const bool f32out = p.Cf != nullptr;
     const int epi = (p.gelu ? EPI_GELU : 0) | (p.res ? EPI_RES : 0) | (p.rowtab ? EPI_ROWTAB : 0) | (f32out ? EPI_F32OUT : 0);
@@ -560,6 +594,7 @@ bool launch_gemm_glds(const GemmP& p, hipStream_t st) {
     GemmP q = p;
     q.peel = 0;
     if (p.variant == 26 || (p.variant >= 28 && p.variant <= 30)) return launch_ring3(q, st);  // ring, no peeling
+    if (p.variant == 31) return launch_ring3w(q, st) || launch_ring3(q, st);
     if (p.variant == 23 || p.variant == 27) {         // double buffer, two workgroups per CU (23: no peeling)
         if (p.variant == 27) q.peel = peel_rows(p, 512);
         return launch_tile<128, 128, 2, 2>(q, st);

@@ -1539,7 +1539,8 @@ int m3pc_select(m3pc_handle* h, const float* expect_return, const float* a0, lon
 // Not part of the public header: lets tools/gemm_bench.py time the GEMM kernel on the plan step's shapes.
 int m3pc_debug_gemm(int dtype, const void* A, const void* Wt, const float* bias, const float* res, void* C, int M, int N,
                     int K, int gelu, int f32out, int variant, void* stream) {
-    GemmP p = gemm_basic(A, K, Wt, K, M, N, K, bias);
+    static const int ldpad = getenv("M3PC_DEBUG_LDPAD") ? atoi(getenv("M3PC_DEBUG_LDPAD")) : 0;  // operand row padding (elements)
+    GemmP p = gemm_basic(A, K + ldpad, Wt, K + ldpad, M, N, K, bias);
     p.gelu = gelu;
     p.res = res;
     p.ldr = N;
@@ -1557,6 +1558,13 @@ int m3pc_debug_gemm(int dtype, const void* A, const void* Wt, const float* bias,
     }
     launch_gemm(p, dtype, (hipStream_t)stream);
     return check_launch("debug_gemm");
+}
+
+// Not part of the public header (tools/gemm_bench.py): clock counters of the last probed GEMM workgroup.
+int m3pc_debug_clock(long long* out2) {
+    HIPCHK(hipDeviceSynchronize());
+    read_clock_probe(out2);
+    return 0;
 }
 
 int m3pc_profile_enable(m3pc_handle* h, int enable) {

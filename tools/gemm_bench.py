@@ -35,8 +35,12 @@ def main():
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     tot = {v: 0.0 for v in variants}
     for name, M, N, K, gelu, res, f32out in SHAPES:
-        A = torch.randn(M, K, device=dev).to(torch.bfloat16)
-        W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+        pad = int(os.environ.get("M3PC_DEBUG_LDPAD", "0"))  # operand row stride = K + pad elements (the library reads the same env)
+        Ap = torch.zeros(M, K + pad, device=dev, dtype=torch.bfloat16)
+        Wp = torch.zeros(N, K + pad, device=dev, dtype=torch.bfloat16)
+        Ap[:, :K] = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        Wp[:, :K] = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+        A, W = Ap[:, :K], Wp[:, :K]  # strided views: data_ptr() is the padded buffer's base
         bias = torch.randn(N, device=dev)
         R = torch.randn(M, N, device=dev) if res else None
         Cout = torch.empty(M, N, device=dev, dtype=torch.float32 if f32out else torch.bfloat16)
@@ -69,6 +73,11 @@ def main():
                 ref = x
             err = float((out[sel] - ref).abs().max())
             line += f" | v{v}: {us:7.1f}us {2.0 * M * N * K / us / 1e6:7.1f} TF/s err {err:.2e}"
+            if 26 <= v <= 30:  # ring debug variants carry a clock probe: shader clocks / 100-MHz ticks of one workgroup
+                buf = (C.c_longlong * 2)()
+                lib.m3pc_debug_clock(buf)
+                if buf[1] > 0:
+                    line += f" clk {100.0 * buf[0] / buf[1]:.0f}MHz wg {buf[1] / 100.0:.1f}us"
         print(line, flush=True)
     print("total us per variant:", {v: round(t, 1) for v, t in tot.items()})
 
