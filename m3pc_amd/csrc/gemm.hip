@@ -365,7 +365,7 @@ int launch_gemm(const GemmP& p, int dtype, hipStream_t st) {
     // few-row problems on the register-staged kernel below; variants 4-9 are the experimental tilings
     if (dtype == DT_BF16 && p.variant == 9 && launch_gemm_persist(p, st)) return 0;
     if (dtype == DT_BF16 && p.variant >= 7 && p.variant != 9 && p.variant < 20 && launch_gemm_ring(p, st)) return 0;
-    if (dtype == DT_BF16 && (p.variant == 0 || (p.variant >= 2 && p.variant < 7) || (p.variant >= 20 && p.variant <= 31)) &&
+    if (dtype == DT_BF16 && (p.variant == 0 || (p.variant >= 2 && p.variant < 7) || (p.variant >= 20 && p.variant <= 32)) &&
         launch_gemm_glds(p, st))
         return 0;
     if (dtype == DT_BF16) return launch_t<bf16_t>(p, st);

@@ -106,9 +106,37 @@ __device__ __forceinline__ void gemm_glds_tile(const GemmP& p, char* smem, int b
     // timing experiments (tools/gemm_bench.py): 20-22 / 24-25 on the double buffer, 28-30 on the ring
     const bool dbg_noload = p.variant == 20 || p.variant == 22 || p.variant == 28 || p.variant == 30;
     const bool dbg_nostore = p.variant == 21 || p.variant == 22 || p.variant == 24 || p.variant == 25 || p.variant == 29 || p.variant == 30;
+    // Ring kernels issue the DMA as buffer loads: one SGPR resource per operand, a 32-bit per-lane offset fixed for
+    // the tile and the k offset as the scalar offset -- no 64-bit address VALU per piece and half the address
+    // traffic of the flat form (the piece's issue cost is what the K loop pays for).
+    const long long a_bytes = (long long)(p.amap.rpg ? ((p.M + p.amap.rpg - 1) / p.amap.rpg) * (long long)p.amap.gstride + p.amap.off + p.amap.rpg
+                                                      : p.M) * lda_b;
+    const long long w_bytes = (long long)p.N * ldw_b;
+    const bool use_buf = NSLOT == 3 && p.variant != 32 && a_bytes < 0xfffff000ll && w_bytes < 0xfffff000ll;
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, use_buf ? (unsigned)a_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, use_buf ? (unsigned)w_bytes : 0u, 0x00020000);
+    int a_vo[NI_A], w_vo[NI_W];
+    if (use_buf) {
+#pragma unroll
+        for (int i = 0; i < NI_A; ++i) a_vo[i] = (int)(a_src[i] - (const char*)p.A);
+#pragma unroll
+        for (int i = 0; i < NI_W; ++i) w_vo[i] = (int)(w_src[i] - (const char*)p.W);
+    }
     auto issue = [&](int kt, int buf) {
         if (dbg_noload) return;
         char* base = smem + buf * BUF + wave_dst;
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc does not know this builtin)
+        if (use_buf) {
+            const int ko = kt * ROWB;
+#pragma unroll
+            for (int i = 0; i < NI_A; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lptr_t)(base + i * NW * 1024), 16, a_vo[i], ko, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NI_W; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lptr_t)(base + BM * ROWB + i * NW * 1024), 16, w_vo[i], ko, 0, 0);
+            return;
+        }
+#endif
         const long long ko = (long long)kt * ROWB;
 #pragma unroll
         for (int i = 0; i < NI_A; ++i)
@@ -593,7 +621,7 @@ bool launch_gemm_glds(const GemmP& p, hipStream_t st) {
     if (p.variant == 25 && p.N % 256 == 0) return launch_tile<256, 256, 2, 4>(p, st);
     GemmP q = p;
     q.peel = 0;
-    if (p.variant == 26 || (p.variant >= 28 && p.variant <= 30)) return launch_ring3(q, st);  // ring, no peeling
+    if (p.variant == 26 || (p.variant >= 28 && p.variant <= 30) || p.variant == 32) return launch_ring3(q, st);  // ring, no peeling (32: flat-address DMA)
     if (p.variant == 31) return launch_ring3w(q, st) || launch_ring3(q, st);
     if (p.variant == 23 || p.variant == 27) {         // double buffer, two workgroups per CU (23: no peeling)
         if (p.variant == 27) q.peel = peel_rows(p, 512);
