@@ -255,7 +255,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(GemmP p, int S, i
         if (i < n) {
             const int c = i * 256 + lane * 4;
             f32x4r a = {0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < S; ++k) a += *(const f32x4r*)(p.ws + k * mn + (long long)r * p.N + c);
+            const float* src = p.ws + (long long)r * p.N + c;
+            int k = 0;
+            for (; k + 4 <= S; k += 4) {  // four slabs in flight, added in slab order (the sum order is part of the result)
+                const f32x4r t0 = *(const f32x4r*)(src + (k + 0) * mn), t1 = *(const f32x4r*)(src + (k + 1) * mn);
+                const f32x4r t2 = *(const f32x4r*)(src + (k + 2) * mn), t3 = *(const f32x4r*)(src + (k + 3) * mn);
+                a += t0;
+                a += t1;
+                a += t2;
+                a += t3;
+            }
+            for (; k < S; ++k) a += *(const f32x4r*)(src + k * mn);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float x = a[e];
