@@ -195,6 +195,174 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     }
 }
 
+// Few-sequence variant (batch-1 policy pass, top-k re-score): the kernel above gives one wave a whole query tile and
+// walks the keys serially -- 128 dependent f32 MFMAs (64 clocks each) per 32-key tile -- while most of the chip
+// idles.  Here a block is ONE 32-query tile of one (batch, head) and its four waves SPLIT THE KEY TILES (wave w takes
+// tiles w, w+4; Lk <= 256).  Each wave runs a complete softmax over its own keys (max m_w, sum l_w, un-normalised
+// O_w = sum exp(s - m_w) V) out of a wave-private LDS slab; the four partial results are merged the streaming-softmax
+// way: m = max m_w, O = sum_w e^{m_w - m} O_w / sum_w e^{m_w - m} l_w.  Same arithmetic as one softmax up to fp32
+// rounding of the re-association.
+template <typename T, int HDT>
+__global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
+    constexpr int HD = HDT * 32;
+    constexpr int ROWF = HD + 4;
+    constexpr int SLAB = 32 * ROWF;  // floats: one 32-row operand tile
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ldsQ = lds;                    // [32][ROWF]
+    float* ldsML = lds + SLAB;            // [4][32][2]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float* slab = lds + SLAB + 256 + wid * SLAB;  // this wave's K / V / O_w tile
+    const int b = blockIdx.x, head = blockIdx.y, q0 = blockIdx.z * 32;
+    const int Lk = p.L1 + p.L2;
+    const int nkt = (Lk + 31) / 32;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const T* Qb = (const T*)p.Q + b * p.q_bstride + head * HD;
+    const T* K1 = (const T*)p.K1 + b * p.kv1_bstride + head * HD;
+    const T* V1 = (const T*)p.V1 + b * p.kv1_bstride + head * HD;
+    const T* K2 = p.K2 ? (const T*)p.K2 + head * HD : nullptr;
+    const T* V2 = p.V2 ? (const T*)p.V2 + head * HD : nullptr;
+
+    for (int c = tid; c < 32 * (HD / 4); c += 256) {
+        const int r = c / (HD / 4), k4 = c % (HD / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (q0 + r < p.Lq) v = load4<T>(Qb + (long long)(q0 + r) * p.ldq + k4 * 4);
+        *(f32x4*)(ldsQ + r * ROWF + k4 * 4) = v;
+    }
+    __syncthreads();
+    f32x4 qf[HDT * 4];
+#pragma unroll
+    for (int s = 0; s < HDT * 4; ++s) qf[s] = *(const f32x4*)(ldsQ + l31 * ROWF + 8 * s + 4 * lh);
+
+    // one 32-row tile of K or V (rows j0 .. j0+31 of the concatenated key range) into this wave's slab
+    auto stage = [&](const T* S1, const T* S2, int j0) {
+        for (int x = lane; x < 32 * (HD / 4); x += 64) {
+            const int r = x / (HD / 4), k4 = x % (HD / 4), j = j0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j < p.L1)
+                v = load4<T>(S1 + (long long)j * p.ldkv1 + k4 * 4);
+            else if (j < Lk)
+                v = load4<T>(S2 + (long long)(j - p.L1) * p.ldkv2 + k4 * 4);
+            *(f32x4*)(slab + r * ROWF + k4 * 4) = v;
+        }
+    };
+
+    f32x16 sacc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[t][e] = 0.f;
+    // S^T tiles of this wave (barriers are block-wide, so every wave walks both slots)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int kt = wid + 4 * t;
+        if (kt < nkt) stage(K1, K2, kt * 32);
+        __syncthreads();
+        if (kt < nkt) {
+#pragma unroll
+            for (int s = 0; s < HDT * 4; ++s) {
+                const f32x4 kf = *(const f32x4*)(slab + l31 * ROWF + 8 * s + 4 * lh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[s][e], sacc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // softmax over this wave's keys for the lane's query column
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int j = (wid + 4 * t) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const float v = (j < Lk) ? sacc[t][e] * p.scale : -INFINITY;
+            sacc[t][e] = v;
+            m = fmaxf(m, v);
+        }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = m == -INFINITY ? 0.f : expf(sacc[t][e] - m);
+            sacc[t][e] = v;
+            l += v;
+        }
+    l += __shfl_xor(l, 32);
+    if (lh == 0) {
+        ldsML[(wid * 32 + l31) * 2 + 0] = m;
+        ldsML[(wid * 32 + l31) * 2 + 1] = l;
+    }
+    // O_w = P V
+    f32x16 oacc[HDT];
+#pragma unroll
+    for (int d = 0; d < HDT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int kt = wid + 4 * t;
+        if (kt < nkt) stage(V1, V2, kt * 32);
+        __syncthreads();
+        if (kt < nkt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int jr = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const float pe = sacc[t][e];
+#pragma unroll
+                for (int d = 0; d < HDT; ++d)
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(pe, slab[jr * ROWF + d * 32 + l31], oacc[d], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // park O_w in the wave's slab (row i, dim), then merge: wave w owns dim tile d = w
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = (e & 3) + 8 * (e >> 2) + 4 * lh;
+#pragma unroll
+        for (int d = 0; d < HDT; ++d) slab[i * ROWF + d * 32 + l31] = oacc[d][e];
+    }
+    __syncthreads();
+    if (wid < HDT) {
+        T* Ob = (T*)p.O + b * p.o_bstride + head * HD;
+        const float* slabs = lds + SLAB + 256;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = (e & 3) + 8 * (e >> 2) + 4 * lh;
+            float mw[4], lw[4], mt = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                mw[w] = ldsML[(w * 32 + i) * 2 + 0];
+                lw[w] = ldsML[(w * 32 + i) * 2 + 1];
+                mt = fmaxf(mt, mw[w]);
+            }
+            float lt = 0.f, o = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float f = mw[w] == -INFINITY ? 0.f : expf(mw[w] - mt);
+                lt = fmaf(lw[w], f, lt);
+                o = fmaf(slabs[w * SLAB + i * ROWF + wid * 32 + l31], f, o);
+            }
+            if (q0 + i < p.Lq) Ob[(long long)(q0 + i) * p.ldo + wid * 32 + l31] = (T)(o / lt);
+        }
+    }
+}
+
+template <typename T, int HDT>
+static void launch_split(const AttnP& p, hipStream_t st) {
+    constexpr int ROWF = HDT * 32 + 4;
+    const size_t smem = (size_t)(5 * 32 * ROWF + 256) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_split_kernel<T, HDT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid(p.batch, p.n_head, (p.Lq + 31) / 32), block(256);
+    hipLaunchKernelGGL((attn_split_kernel<T, HDT>), grid, block, smem, st, p);
+}
+
 template <typename T, int HDT, int NCH>
 static void launch_nch(const AttnP& p, dim3 grid, dim3 block, size_t smem, hipStream_t st) {
     static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
@@ -209,6 +377,10 @@ template <typename T, int HDT>
 static void launch_hd(const AttnP& p, hipStream_t st) {
     const int Lk = p.L1 + p.L2;
     const int qgroups = (p.Lq + 127) / 128;
+    if (Lk <= 256 && (long long)p.batch * p.n_head * qgroups <= 64 && !getenv("M3PC_NO_ATTN_SPLIT")) {
+        launch_split<T, HDT>(p, st);  // few sequences: split the keys over the waves instead
+        return;
+    }
     // always 4 waves: waves past the last query tile still help staging K/V (their MFMAs run on an otherwise
     // idle SIMD over zero-filled query rows and are never stored)
     const int nw = 4;
