@@ -371,8 +371,73 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(LnP p) {
         }
 }
 
+// Many-row single LayerNorm (candidate pass): two rows per wave so that twice the loads are in flight per wave (the
+// kernel is a pure HBM stream; per-row arithmetic and its order are those of layernorm_vec_kernel).
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_vec2_kernel(LnP p) {
+    const int lane = threadIdx.x & 63;
+    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (r0 >= p.rows) return;
+    const bool two = r0 + 1 < p.rows;
+    const float* x0 = p.X + (long long)map_row(p.xmap, r0) * p.ldx;
+    const float* x1 = p.X + (long long)map_row(p.xmap, two ? r0 + 1 : r0) * p.ldx;
+    f32x4v v[2][NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[0][i] = *(const f32x4v*)(x0 + i * 256 + lane * 4);
+        v[1][i] = *(const f32x4v*)(x1 + i * 256 + lane * 4);
+    }
+    f32x4v g[NV], b[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        g[i] = *(const f32x4v*)(p.g1 + i * 256 + lane * 4);
+        b[i] = *(const f32x4v*)(p.b1 + i * 256 + lane * 4);
+    }
+    const float inv_d = 1.0f / (float)p.d;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += (v[k][i][0] + v[k][i][1]) + (v[k][i][2] + v[k][i][3]);
+        const float mean = wave_sum(s) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c = v[k][i][e] - mean;
+                q += c * c;
+            }
+        const float rstd = rsqrtf(wave_sum(q) * inv_d + 1e-5f);
+        if (k == 1 && !two) break;
+        const long long o = (long long)(r0 + k) * p.d;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            f32x4v y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[k][i][e] - mean) * rstd * g[i][e] + b[i][e];
+            if (p.Yf) *(f32x4v*)(p.Yf + o + i * 256 + lane * 4) = y;
+            if (p.Yb) {
+                bf16x4v w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (bf16_t)y[e];
+                *(bf16x4v*)(p.Yb + o + i * 256 + lane * 4) = w;
+            }
+        }
+    }
+}
+
 void launch_layernorm(const LnP& p, hipStream_t st) {
     if (p.rows <= 0) return;
+    if (p.d % 256 == 0 && p.d <= 1024 && p.ldx % 4 == 0 && !p.g2 && p.rows >= 8192 && !getenv("M3PC_NO_LN2")) {
+        const dim3 grid((p.rows + 7) / 8), block(256);
+        switch (p.d / 256) {
+            case 1: hipLaunchKernelGGL(layernorm_vec2_kernel<1>, grid, block, 0, st, p); return;
+            case 2: hipLaunchKernelGGL(layernorm_vec2_kernel<2>, grid, block, 0, st, p); return;
+            case 3: hipLaunchKernelGGL(layernorm_vec2_kernel<3>, grid, block, 0, st, p); return;
+            default: hipLaunchKernelGGL(layernorm_vec2_kernel<4>, grid, block, 0, st, p); return;
+        }
+    }
     if (p.d % 256 == 0 && p.ldx % 4 == 0)
         hipLaunchKernelGGL(layernorm_vec_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, st, p);
     else
