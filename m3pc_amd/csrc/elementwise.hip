@@ -371,21 +371,20 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(LnP p) {
         }
 }
 
-// Many-row single LayerNorm (candidate pass): two rows per wave so that twice the loads are in flight per wave (the
-// kernel is a pure HBM stream; per-row arithmetic and its order are those of layernorm_vec_kernel).
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_vec2_kernel(LnP p) {
+// Many-row single LayerNorm (candidate pass): RPW rows per wave so that RPW times the loads are in flight per wave
+// (the kernel is a pure HBM stream; per-row arithmetic and its order are those of layernorm_vec_kernel).
+template <int NV, int RPW>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(LnP p) {
     const int lane = threadIdx.x & 63;
-    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
     if (r0 >= p.rows) return;
-    const bool two = r0 + 1 < p.rows;
-    const float* x0 = p.X + (long long)map_row(p.xmap, r0) * p.ldx;
-    const float* x1 = p.X + (long long)map_row(p.xmap, two ? r0 + 1 : r0) * p.ldx;
-    f32x4v v[2][NV];
+    f32x4v v[RPW][NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        v[0][i] = *(const f32x4v*)(x0 + i * 256 + lane * 4);
-        v[1][i] = *(const f32x4v*)(x1 + i * 256 + lane * 4);
+    for (int k = 0; k < RPW; ++k) {
+        const int r = r0 + k < p.rows ? r0 + k : p.rows - 1;
+        const float* x = p.X + (long long)map_row(p.xmap, r) * p.ldx;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[k][i] = *(const f32x4v*)(x + i * 256 + lane * 4);
     }
     f32x4v g[NV], b[NV];
 #pragma unroll
@@ -395,7 +394,7 @@ __global__ __launch_bounds__(256) void layernorm_vec2_kernel(LnP p) {
     }
     const float inv_d = 1.0f / (float)p.d;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < RPW; ++k) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) s += (v[k][i][0] + v[k][i][1]) + (v[k][i][2] + v[k][i][3]);
@@ -409,34 +408,41 @@ __global__ __launch_bounds__(256) void layernorm_vec2_kernel(LnP p) {
                 q += c * c;
             }
         const float rstd = rsqrtf(wave_sum(q) * inv_d + 1e-5f);
-        if (k == 1 && !two) break;
-        const long long o = (long long)(r0 + k) * p.d;
+        if (r0 + k < p.rows) {
+            const long long o = (long long)(r0 + k) * p.d;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            f32x4v y;
+            for (int i = 0; i < NV; ++i) {
+                f32x4v y;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = (v[k][i][e] - mean) * rstd * g[i][e] + b[i][e];
-            if (p.Yf) *(f32x4v*)(p.Yf + o + i * 256 + lane * 4) = y;
-            if (p.Yb) {
-                bf16x4v w;
+                for (int e = 0; e < 4; ++e) y[e] = (v[k][i][e] - mean) * rstd * g[i][e] + b[i][e];
+                if (p.Yf) *(f32x4v*)(p.Yf + o + i * 256 + lane * 4) = y;
+                if (p.Yb) {
+                    bf16x4v w;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) w[e] = (bf16_t)y[e];
-                *(bf16x4v*)(p.Yb + o + i * 256 + lane * 4) = w;
+                    for (int e = 0; e < 4; ++e) w[e] = (bf16_t)y[e];
+                    *(bf16x4v*)(p.Yb + o + i * 256 + lane * 4) = w;
+                }
             }
         }
+    }
+}
+template <int RPW>
+static void launch_ln_rows(const LnP& p, hipStream_t st) {
+    const dim3 grid((p.rows + 4 * RPW - 1) / (4 * RPW)), block(256);
+    switch (p.d / 256) {
+        case 1: hipLaunchKernelGGL((layernorm_rows_kernel<1, RPW>), grid, block, 0, st, p); return;
+        case 2: hipLaunchKernelGGL((layernorm_rows_kernel<2, RPW>), grid, block, 0, st, p); return;
+        case 3: hipLaunchKernelGGL((layernorm_rows_kernel<3, RPW>), grid, block, 0, st, p); return;
+        default: hipLaunchKernelGGL((layernorm_rows_kernel<4, RPW>), grid, block, 0, st, p); return;
     }
 }
 
 void launch_layernorm(const LnP& p, hipStream_t st) {
     if (p.rows <= 0) return;
-    if (p.d % 256 == 0 && p.d <= 1024 && p.ldx % 4 == 0 && !p.g2 && p.rows >= 8192 && !getenv("M3PC_NO_LN2")) {
-        const dim3 grid((p.rows + 7) / 8), block(256);
-        switch (p.d / 256) {
-            case 1: hipLaunchKernelGGL(layernorm_vec2_kernel<1>, grid, block, 0, st, p); return;
-            case 2: hipLaunchKernelGGL(layernorm_vec2_kernel<2>, grid, block, 0, st, p); return;
-            case 3: hipLaunchKernelGGL(layernorm_vec2_kernel<3>, grid, block, 0, st, p); return;
-            default: hipLaunchKernelGGL(layernorm_vec2_kernel<4>, grid, block, 0, st, p); return;
-        }
+    if (p.d % 256 == 0 && p.d <= 1024 && p.ldx % 4 == 0 && !p.g2 && p.rows >= 8192) {
+        static const int rpw = getenv("M3PC_LN_RPW") ? atoi(getenv("M3PC_LN_RPW")) : 2;  // 1 = the one-row kernel below
+        if (rpw == 4) return launch_ln_rows<4>(p, st);
+        if (rpw == 2) return launch_ln_rows<2>(p, st);
     }
     if (p.d % 256 == 0 && p.ldx % 4 == 0)
         hipLaunchKernelGGL(layernorm_vec_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, st, p);
