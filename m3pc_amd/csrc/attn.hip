@@ -377,7 +377,8 @@ template <typename T, int HDT>
 static void launch_hd(const AttnP& p, hipStream_t st) {
     const int Lk = p.L1 + p.L2;
     const int qgroups = (p.Lq + 127) / 128;
-    if (Lk <= 256 && (long long)p.batch * p.n_head * qgroups <= 64 && !getenv("M3PC_NO_ATTN_SPLIT")) {
+    static const bool no_split = getenv("M3PC_NO_ATTN_SPLIT") != nullptr;  // A/B switch
+    if (Lk <= 256 && (long long)p.batch * p.n_head * qgroups <= 64 && !no_split) {
         launch_split<T, HDT>(p, st);  // few sequences: split the keys over the waves instead
         return;
     }

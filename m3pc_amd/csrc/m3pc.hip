@@ -531,7 +531,8 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
                 int n_indep = 0) {
     // first-layer pruning (run_block): whole 32-query tiles of shared tokens, bf16 candidate passes only
     int n_sh = 0;
-    if (dt == DT_BF16 && batch >= 64 && h->d % 256 == 0 && h->d <= 1024 && n_indep >= 32 && !getenv("M3PC_NO_PRUNE1"))
+    static const bool no_prune1 = getenv("M3PC_NO_PRUNE1") != nullptr;  // A/B switch
+    if (dt == DT_BF16 && batch >= 64 && h->d % 256 == 0 && h->d <= 1024 && n_indep >= 32 && !no_prune1)
         n_sh = (n_indep / 32) * 32;
     EmbedP e;
     memset(&e, 0, sizeof(e));
@@ -827,7 +828,8 @@ int build_tables(m3pc_handle* h, Plan* pl, int qi, int dt, hipStream_t st) {
     g.out = tb.Yq;
     g.outb = nullptr;
     launch_gather_rows(g, st);
-    if (dt == DT_BF16 && q.all_masked && pl->Lm > 0 && pl->Lm <= 256 && !getenv("M3PC_NO_PRESTATS")) {
+    static const bool no_prestats = getenv("M3PC_NO_PRESTATS") != nullptr;  // A/B switch
+    if (dt == DT_BF16 && q.all_masked && pl->Lm > 0 && pl->Lm <= 256 && !no_prestats) {
         // queries and masked-token keys are both candidate-independent: reduce that block of the softmax once
         if (!tb.pre_m) {
             CHK(dmalloc(&tb.pre_m, (size_t)h->nh * q.nq));
