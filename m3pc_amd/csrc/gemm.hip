@@ -379,6 +379,10 @@ int launch_gemm(const GemmP& p, int dtype, hipStream_t st) {
         launch_gemm_glds(p, st))
         return 0;
     if (dtype == DT_BF16) return launch_t<bf16_t>(p, st);
+    // few-row fp32 GEMMs: K split inside a 16-wave workgroup, one launch (only where split-K is allowed at all, i.e.
+    // where every rank runs the same row count: p.ws is set exactly then).  variant 2 keeps the slab path for A/B runs.
+    static const bool no_direct = getenv("M3PC_NO_F32_DIRECT") != nullptr;  // A/B switch
+    if (p.ws && p.variant != 2 && !no_direct && launch_gemm_f32_direct(p, st)) return 0;
     return launch_t<float>(p, st);
 }
 

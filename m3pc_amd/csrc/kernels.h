@@ -57,6 +57,7 @@ bool launch_gemm_ring(const GemmP& p, hipStream_t st);  // bf16, many rows: 256x
 bool launch_gemm_persist(const GemmP& p, hipStream_t st);  // bf16, many rows: persistent 256x256 tiles (gemm_persist.hip)
 bool launch_gemm_glds(const GemmP& p, hipStream_t st);  // bf16, many rows: direct-to-LDS staging (gemm_glds.hip)
 void read_clock_probe(long long out[2]);                // debug: {shader clocks, 100-MHz ticks} of one ring workgroup
+bool launch_gemm_f32_direct(const GemmP& p, hipStream_t st);  // fp32, few rows: in-workgroup K split (gemm_f32_direct.hip)
 
 // LayerNorm over the last dim (eps 1e-5), one wave per row; optional second LayerNorm applied to
 // the result (decoder.norm followed by an output head's LayerNorm).  d <= 1024, d % 64 == 0.
