@@ -234,39 +234,31 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
 #pragma unroll
     for (int s = 0; s < HDT * 4; ++s) qf[s] = *(const f32x4*)(ldsQ + l31 * ROWF + 8 * s + 4 * lh);
 
-    // one 32-row tile of K or V (rows j0 .. j0+31 of the concatenated key range) into this wave's slab
-    auto stage = [&](const T* S1, const T* S2, int j0) {
-        for (int x = lane; x < 32 * (HD / 4); x += 64) {
-            const int r = x / (HD / 4), k4 = x % (HD / 4), j = j0 + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (j < p.L1)
-                v = load4<T>(S1 + (long long)j * p.ldkv1 + k4 * 4);
-            else if (j < Lk)
-                v = load4<T>(S2 + (long long)(j - p.L1) * p.ldkv2 + k4 * 4);
-            *(f32x4*)(slab + r * ROWF + k4 * 4) = v;
-        }
-    };
-
+    // K and V never touch LDS here: a lane reads its key row's fragment (16 bytes per k-step) and its V values
+    // (one float per (key pair, dim tile)) straight from global memory in MFMA operand order -- there is no reuse
+    // inside a wave to stage for, and the loads of a whole tile are in flight together.
     f32x16 sacc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) sacc[t][e] = 0.f;
-    // S^T tiles of this wave (barriers are block-wide, so every wave walks both slots)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int kt = wid + 4 * t;
-        if (kt < nkt) stage(K1, K2, kt * 32);
-        __syncthreads();
         if (kt < nkt) {
+            const int j = kt * 32 + l31;
+            const T* kr = j < p.L1 ? K1 + (long long)j * p.ldkv1 : (j < Lk ? K2 + (long long)(j - p.L1) * p.ldkv2 : nullptr);
+            f32x4 kf[HDT * 4];
 #pragma unroll
             for (int s = 0; s < HDT * 4; ++s) {
-                const f32x4 kf = *(const f32x4*)(slab + l31 * ROWF + 8 * s + 4 * lh);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[s][e], sacc[t], 0, 0, 0);
+                kf[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (kr) kf[s] = load4<T>(kr + 8 * s + 4 * lh);
             }
+#pragma unroll
+            for (int s = 0; s < HDT * 4; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s][e], qf[s][e], sacc[t], 0, 0, 0);
         }
-        __syncthreads();
     }
     // softmax over this wave's keys for the lane's query column
     float m = -INFINITY;
@@ -303,19 +295,20 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int kt = wid + 4 * t;
-        if (kt < nkt) stage(V1, V2, kt * 32);
-        __syncthreads();
         if (kt < nkt) {
+            float vv[16][HDT];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int jr = (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const float pe = sacc[t][e];
+                const int jr = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const T* vr = jr < p.L1 ? V1 + (long long)jr * p.ldkv1 : (jr < Lk ? V2 + (long long)(jr - p.L1) * p.ldkv2 : nullptr);
 #pragma unroll
-                for (int d = 0; d < HDT; ++d)
-                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(pe, slab[jr * ROWF + d * 32 + l31], oacc[d], 0, 0, 0);
+                for (int d = 0; d < HDT; ++d) vv[e][d] = vr ? (float)vr[d * 32 + l31] : 0.f;
             }
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+#pragma unroll
+                for (int d = 0; d < HDT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[t][e], vv[e][d], oacc[d], 0, 0, 0);
         }
-        __syncthreads();
     }
     // park O_w in the wave's slab (row i, dim), then merge: wave w owns dim tile d = w
 #pragma unroll
