@@ -161,6 +161,32 @@ def test_zeroshot_batched_windows_match_reference_goldens():
     p.handle.close()
 
 
+def test_planner_from_reference_style_checkpoints(tmp_path):
+    """`{"model": state_dict}` / `{"qf": ...}` files (train.py:1208-1216, model.py:310-320) give the
+    same planner as handing the tensors over directly."""
+    from m3pc_amd import checkpoint
+    dims = synth.Dims(11, 3, 8, n_embd=64, n_head=2)
+    sd = synth.make_state_dict(dims, 0)
+    st = synth.make_tokenizer_stats(dims, 0)
+    qsd, om, os_ = synth.make_critic(dims, 0)
+    torch.save({"model": sd, "optimizer": {}, "step": 3, "eval_max": {}}, tmp_path / "m.pt")
+    torch.save({"qf": qsd, "vf": {}, "actor": {}, "total_it": 1}, tmp_path / "iql_3.pt")
+    cfg = types.SimpleNamespace(traj_length=8, action_samples=16, horizon=4, discount=0.99, temperature=1.0, lmbda=0.6,
+                                plan_guidance="critic_lambda_guiding")
+    a = checkpoint.planner_from_checkpoints(cfg, str(tmp_path / "m.pt"), st, str(tmp_path / "iql_3.pt"), om, os_, n_head=2)
+    b = HipPlanner(cfg, sd, st, qsd, om, os_, n_embd=64, n_head=2)
+    hist = synth.make_history(dims, 0)
+    hist["path_length"] = 500
+    for pl in (a, b):
+        pl.generator = torch.Generator(device="cuda").manual_seed(5)
+    ea = a.action_sample(hist, plan=True, eval=True, rtg=3.0)
+    eb = b.action_sample(hist, plan=True, eval=True, rtg=3.0)
+    assert torch.equal(ea, eb)
+    assert torch.equal(a.last["expect_return"], b.last["expect_return"])
+    a.handle.close()
+    b.handle.close()
+
+
 def test_omtm_and_tokenizer_mirror_compose_like_the_reference():
     """tokenizer_manager.decode(mtm(tokenizer_manager.encode(traj), mask)) -- the reference's idiom
     (learner.py:108-111) -- on the mirror classes."""
