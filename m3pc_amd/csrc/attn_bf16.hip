@@ -216,6 +216,188 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
     }
 }
 
+// Lk <= 64 (every bf16 attention of the T = 32 plan step).  The kernel above stages Q, then K, then V through LDS with
+// a barrier after each: three dependent global round trips per tiny block.  Here the Q and K fragments are read
+// straight from global memory in MFMA operand order (lane (row, h) reads the 16 bytes holding dims 16s+8h..+7 of its
+// row; all 8 + 16 loads of a wave are in flight together), only V goes through LDS (its B operand needs the
+// transposing ds_read_b64_tr_b16), and V's loads are issued as soon as the K registers are free so that the softmax
+// runs under them.  One wave per 32-query tile, NW tiles per block sharing the V image.  Arithmetic and its order are
+// those of attn_bf16_kernel<HDT, 1>.
+template <int HDT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bf16_direct_kernel(AttnP p) {
+    constexpr int HD = HDT * 32;
+    constexpr int ROWB = HD * 2 + 16;
+    constexpr int NS = HD / 16;
+    constexpr int CPR = HD / 8;
+    constexpr int NTHR = NW * 64;
+    constexpr int VPT = 64 * CPR / NTHR;  // 16-byte V chunks per thread
+    static_assert(64 * CPR % NTHR == 0, "V tile must divide over the block");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float* fbuf = (float*)(lds + 64 * ROWB);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int b = blockIdx.x, head = blockIdx.y, q0 = blockIdx.z * (NW * 32);
+    const int Lk = p.L1 + p.L2;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const bf16_t* Qb = (const bf16_t*)p.Q + b * p.q_bstride + head * HD;
+    const bf16_t* K1 = (const bf16_t*)p.K1 + b * p.kv1_bstride + head * HD;
+    const bf16_t* V1 = (const bf16_t*)p.V1 + b * p.kv1_bstride + head * HD;
+    const bf16_t* K2 = p.K2 ? (const bf16_t*)p.K2 + head * HD : nullptr;
+    const bf16_t* V2 = p.V2 ? (const bf16_t*)p.V2 + head * HD : nullptr;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const int Lq1p = (p.Lq + 31) & ~31;
+    const bf16_t* Q2b = p.Q2 ? (const bf16_t*)p.Q2 + head * HD : nullptr;
+
+    // this lane's query row (query slot q0 + wid*32 + l31) and its two key rows (keys l31 and 32 + l31)
+    const int qi = q0 + wid * 32 + l31;
+    const bf16_t* qrow = nullptr;
+    if (qi < p.Lq)
+        qrow = Qb + (long long)qi * p.ldq;
+    else if (Q2b && qi >= Lq1p && qi - Lq1p < p.Lq2)
+        qrow = Q2b + (long long)(qi - Lq1p) * p.ldq2;
+    const bf16_t* krow[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        const int j = jt * 32 + l31;
+        krow[jt] = j < p.L1 ? K1 + (long long)j * p.ldkv1 : (j < Lk ? K2 + (long long)(j - p.L1) * p.ldkv2 : nullptr);
+    }
+    u32x4 qf[NS], kf[2][NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        qf[s] = zero4;
+        if (qrow) qf[s] = *(const u32x4*)(qrow + 16 * s + 8 * lh);
+    }
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            kf[jt][s] = zero4;
+            if (krow[jt]) kf[jt][s] = *(const u32x4*)(krow[jt] + 16 * s + 8 * lh);
+        }
+
+    f32x16 sacc[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[jt][e] = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+        if (jt * 32 < Lk) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                sacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[jt][s]), __builtin_bit_cast(bf16x8, qf[s]),
+                                                                   sacc[jt], 0, 0, 0);
+        }
+    // V: issue the loads now (the K registers are dead), park them in LDS after the softmax
+    u32x4 vv[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int x = tid + i * NTHR, r = x / CPR, kc = x % CPR;
+        vv[i] = zero4;
+        if (r < p.L1)
+            vv[i] = *(const u32x4*)(V1 + (long long)r * p.ldkv1 + kc * 8);
+        else if (r < Lk)
+            vv[i] = *(const u32x4*)(V2 + (long long)(r - p.L1) * p.ldkv2 + kc * 8);
+    }
+
+    float m = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int j = jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const float v = (j < Lk) ? sacc[jt][e] * p.scale : -INFINITY;
+            sacc[jt][e] = v;
+            m = fmaxf(m, v);
+        }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = __builtin_amdgcn_exp2f((sacc[jt][e] - m) * 1.44269504088896340736f);
+            sacc[jt][e] = v;
+            l += v;
+        }
+    l += __shfl_xor(l, 32);
+    float inv = 1.0f / l;
+    if (p.pre_m) {
+        float mp = -INFINITY, lp = 0.f;
+        if (qi < p.Lq) {
+            mp = p.pre_m[head * p.Lq + qi];
+            lp = p.pre_l[head * p.Lq + qi];
+        }
+        const float mt = fmaxf(m, mp);
+        const float a = __builtin_amdgcn_exp2f((m - mt) * 1.44269504088896340736f);
+        const float bs = __builtin_amdgcn_exp2f((mp - mt) * 1.44269504088896340736f);
+        const float lt = l * a + lp * bs;
+        inv = a / lt;
+        if (lh == 0) fbuf[wid * 32 + l31] = bs / lt;
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int x = tid + i * NTHR, r = x / CPR, kc = x % CPR;
+        *(u32x4*)(lds + r * ROWB + kc * 16) = vv[i];
+    }
+    __syncthreads();
+
+    f32x16 oacc[HDT];
+#pragma unroll
+    for (int d = 0; d < HDT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+    const int gi = lane & 15;
+    const int tr_off = (gi >> 2) * ROWB + (((lane >> 4) & 1) * 16 + (gi & 3) * 4) * 2;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        if (jt * 32 < Lk) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pa;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pa[e] = (bf16_t)(sacc[jt][8 * s2 + e] * inv);
+                const int kb = jt * 32 + 16 * s2 + 4 * lh;
+#pragma unroll
+                for (int d = 0; d < HDT; ++d) {
+                    const char* base = lds + kb * ROWB + d * 64 + tr_off;
+                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base));
+                    const s16x4 v1 =
+                        __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + 8 * ROWB));
+                    const s16x8 vb = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8, vb), oacc[d], 0, 0, 0);
+                }
+            }
+        }
+    }
+    bf16_t* Ob = (bf16_t*)p.O + b * p.o_bstride + head * HD;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = q0 + wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        int orow = -1;
+        if (i < p.Lq)
+            orow = p.orow1 + i;
+        else if (Q2b && i >= Lq1p && i - Lq1p < p.Lq2)
+            orow = p.orow2 + i - Lq1p;
+        if (orow >= 0) {
+            if (p.pre_m) {
+                const float f = fbuf[i - q0];
+                const float* po = p.pre_O + ((long long)head * p.Lq + i) * HD;
+#pragma unroll
+                for (int d = 0; d < HDT; ++d) oacc[d][e] = fmaf(f, po[d * 32 + l31], oacc[d][e]);
+            }
+#pragma unroll
+            for (int d = 0; d < HDT; ++d) Ob[(long long)orow * p.ldo + d * 32 + l31] = (bf16_t)oacc[d][e];
+        }
+    }
+}
+template <int HDT, int NW>
+static void launch_direct(const AttnP& p, int slots, hipStream_t st) {
+    const size_t smem = (size_t)64 * (HDT * 64 + 16) + NW * 32 * sizeof(float);
+    const int qgroups = (slots + NW * 32 - 1) / (NW * 32);
+    hipLaunchKernelGGL((attn_bf16_direct_kernel<HDT, NW>), dim3(p.batch, p.n_head, qgroups), dim3(NW * 64), smem, st, p);
+}
+
 template <int HDT, int NCH>
 static void launch_nch(const AttnP& p, dim3 grid, dim3 block, size_t smem, hipStream_t st) {
     hipLaunchKernelGGL((attn_bf16_kernel<HDT, NCH>), grid, block, smem, st, p);
@@ -230,7 +412,13 @@ static void launch_hd(const AttnP& p, hipStream_t st) {
     const int rows = nw * 32 > 64 ? nw * 32 : 64;
     const size_t smem = (size_t)rows * (HDT * 64 + 16) + 512;  // + per-query weights of the pre-reduced block
     dim3 grid(p.batch, p.n_head, qgroups), block(nw * 64);
-    if (Lk <= 64)
+    static const bool no_direct = getenv("M3PC_NO_ATTN_DIRECT") != nullptr;  // A/B switch
+    if (Lk <= 64 && !no_direct) {
+        if (slots <= 32)
+            launch_direct<HDT, 1>(p, slots, st);
+        else
+            launch_direct<HDT, 2>(p, slots, st);
+    } else if (Lk <= 64)
         launch_nch<HDT, 1>(p, grid, block, smem, st);
     else if (Lk <= 128)
         launch_nch<HDT, 2>(p, grid, block, smem, st);
