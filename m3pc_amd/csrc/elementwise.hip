@@ -408,13 +408,37 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(LnP p) {
                 q += c * c;
             }
         const float rstd = rsqrtf(wave_sum(q) * inv_d + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[k][i][e] = (v[k][i][e] - mean) * rstd * g[i][e] + b[i][e];
+        if (p.g2) {  // second LayerNorm on the result (decoder.norm followed by an output head's norm)
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) s2 += (v[k][i][0] + v[k][i][1]) + (v[k][i][2] + v[k][i][3]);
+            const float mean2 = wave_sum(s2) * inv_d;
+            float q2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float c = v[k][i][e] - mean2;
+                    q2 += c * c;
+                }
+            const float rstd2 = rsqrtf(wave_sum(q2) * inv_d + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const f32x4v gg = *(const f32x4v*)(p.g2 + i * 256 + lane * 4);
+                const f32x4v bb = *(const f32x4v*)(p.b2 + i * 256 + lane * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[k][i][e] = (v[k][i][e] - mean2) * rstd2 * gg[e] + bb[e];
+            }
+        }
         if (r0 + k < p.rows) {
             const long long o = (long long)(r0 + k) * p.d;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                f32x4v y;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = (v[k][i][e] - mean) * rstd * g[i][e] + b[i][e];
+                const f32x4v y = v[k][i];
                 if (p.Yf) *(f32x4v*)(p.Yf + o + i * 256 + lane * 4) = y;
                 if (p.Yb) {
                     bf16x4v w;
@@ -439,7 +463,7 @@ static void launch_ln_rows(const LnP& p, hipStream_t st) {
 
 void launch_layernorm(const LnP& p, hipStream_t st) {
     if (p.rows <= 0) return;
-    if (p.d % 256 == 0 && p.d <= 1024 && p.ldx % 4 == 0 && !p.g2 && p.rows >= 8192) {
+    if (p.d % 256 == 0 && p.d <= 1024 && p.ldx % 4 == 0 && p.rows >= 8192) {
         static const int rpw = getenv("M3PC_LN_RPW") ? atoi(getenv("M3PC_LN_RPW")) : 2;  // 1 = the one-row kernel below
         if (rpw == 4) return launch_ln_rows<4>(p, st);
         if (rpw == 2) return launch_ln_rows<2>(p, st);
