@@ -187,6 +187,15 @@ class HipPlanner:
     def assemble_goal_window(self, sequence_history, rtg=None, percentage=1.0):
         """research/zeroshot_omtm/learner.py:164-223: the history window, with the observation rows of the
         WHOLE window taken from the buffer (future rows are way-points), shortened near the 1000-step end."""
+        horizon, return_to_go = self._goal_window_host(sequence_history, rtg, percentage, self._host)
+        dev = torch.from_numpy(self._host).to(self.device)
+        states = dev[:, : self.S].contiguous()
+        actions = dev[:, self.S : self.S + self.A].contiguous()
+        rewards = dev[:, self.S + self.A :].contiguous()
+        return states, actions, rewards, horizon, return_to_go
+
+    def _goal_window_host(self, sequence_history, rtg, percentage, buf):
+        """Host half of ``assemble_goal_window``: fills ``buf`` (T, S+A+1) and returns (horizon, rtg)."""
         T = self.T
         horizon = int(self.cfg.horizon)
         end_idx = int(sequence_history["path_length"])
@@ -196,23 +205,18 @@ class HipPlanner:
         if end_idx + horizon > 1000:
             smart = smart - (end_idx + horizon - 1000)
         hl = T - horizon + 1
-        buf = self._host
         buf[:] = 0.0
         lo = end_idx - hl + 1
         buf[:hl, self.S : self.S + self.A] = sequence_history["actions"][lo : end_idx + 1]
         buf[:hl, self.S + self.A :] = np.asarray(sequence_history["rewards"][lo : end_idx + 1]).reshape(hl, 1)
         buf[:hl, : self.S] = sequence_history["observations"][lo : end_idx + 1]
         buf[:smart, : self.S] = sequence_history["observations"][lo : lo + T]
-        dev = torch.from_numpy(buf).to(self.device)
-        states = dev[:, : self.S].contiguous()
-        actions = dev[:, self.S : self.S + self.A].contiguous()
-        rewards = dev[:, self.S + self.A :].contiguous()
         if rtg is not None:
             return_to_go = float(rtg)
         else:
             st = self.tokenizer_manager.tokenizers["returns"].stats
             return_to_go = float(np.asarray(st.min + (st.max - st.min) * percentage).reshape(-1)[0])
-        return states, actions, rewards, horizon, return_to_go
+        return horizon, return_to_go
 
     def _goal_tokens(self, states, actions, rewards, rtg):
         T = self.T
@@ -268,16 +272,19 @@ class HipPlanner:
             assert rtg is not None
         from .masks import create_fid_mask, create_pi_mask, mask_rows
         T, E = self.T, len(sequence_histories)
-        wins = [self.assemble_goal_window(hst, rtg, percentage) for hst in sequence_histories]
+        host = np.empty((E, T, self.S + self.A + 1), dtype=np.float32)
+        meta = [self._goal_window_host(hst, rtg, percentage, host[i]) for i, hst in enumerate(sequence_histories)]
+        dev = torch.from_numpy(host).to(self.device)  # one packed H2D copy for all windows
         out = torch.empty((E, self.A), dtype=torch.float32, device=self.device)
         infer = [None] * E
-        for h in sorted({w[3] for w in wins}):
-            ids = [i for i, w in enumerate(wins) if w[3] == h]
+        for h in sorted({m[0] for m in meta}):
+            ids = [i for i, m in enumerate(meta) if m[0] == h]
             idx = T - h
-            s = torch.stack([wins[i][0] for i in ids])
-            a = torch.stack([wins[i][1] for i in ids]).contiguous()
-            r = torch.stack([wins[i][2] for i in ids])
-            ret = torch.tensor([wins[i][4] for i in ids], dtype=torch.float64, device=self.device)[:, None, None].expand(-1, T, 1)
+            sel = dev if len(ids) == E else dev[torch.tensor(ids, device=self.device)]
+            s = sel[:, :, : self.S].contiguous()
+            a = sel[:, :, self.S : self.S + self.A].contiguous()
+            r = sel[:, :, self.S + self.A :].contiguous()
+            ret = torch.tensor([meta[i][1] for i in ids], dtype=torch.float64, device=self.device)[:, None, None].expand(-1, T, 1)
             toks = [self.handle.tokenize(capi.STATES, s), a, self.handle.tokenize(capi.REWARDS, r),
                     self.handle.tokenize(capi.RETURNS, ret.contiguous())]
             raw = self.handle.forward(toks, mask_rows(create_pi_mask(T, "cpu", idx)), want=("states",))["states"]
