@@ -157,8 +157,11 @@ __device__ __forceinline__ void gemm_glds_tile(const GemmP& p, char* smem, int b
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // residual prefetch (same element order as the epilogue)
-    float rres[(EPI & EPI_RES) ? TM * 16 * TN : 1];
-    if constexpr (EPI & EPI_RES) {
+    // (only for wave tiles up to 64x64: a 128x64 wave tile already holds 128 accumulator registers and loads its
+    // residual in the epilogue instead)
+    constexpr bool RES_PREFETCH = (EPI & EPI_RES) != 0 && TM * TN <= 4;
+    float rres[RES_PREFETCH ? TM * 16 * TN : 1];
+    if constexpr (RES_PREFETCH) {
         if (p.cmap.rpg == 0 && row0 + BM <= p.M) {  // scalar row offsets, one per-lane offset (gemm_epilogue.h)
             const long long rb = (long long)p.M * p.ldr * 4;
             const __amdgpu_buffer_rsrc_t rrs =
@@ -433,16 +436,24 @@ __device__ __forceinline__ void gemm_glds_tile(const GemmP& p, char* smem, int b
         const int wu = __builtin_amdgcn_readfirstlane(wid);
         const int rbase = row0 + (wu / WN) * WTM, cbase = col0 + (wu % WN) * WTN;
         const int vo_c = (4 * lh * p.ldc + l31) * ES;
+        const long long rb2 = (long long)p.M * p.ldr * 4;
+        const __amdgpu_buffer_rsrc_t rrs2 = __builtin_amdgcn_make_buffer_rsrc(
+            (EPI & EPI_RES) ? (void*)p.res : cptr, 0, rb2 > 0xfffff000ll ? 0xfffff000u : (unsigned)rb2, 0x00020000);
+        const int vo_r2 = (4 * lh * p.ldr + l31) * 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int so_c = ((rbase + i * 32 + (reg & 3) + 8 * (reg >> 2)) * p.ldc + cbase) * ES;
+                const int so_r2 = ((rbase + i * 32 + (reg & 3) + 8 * (reg >> 2)) * p.ldr + cbase) * 4;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     float v = acc[i][j][reg] + bj[j];
                     if constexpr (EPI & EPI_GELU) v = gelu_fast2(v);
-                    if constexpr (EPI & EPI_RES) v += rres[(i * 16 + reg) * TN + j];
+                    if constexpr (RES_PREFETCH)
+                        v += rres[(i * 16 + reg) * TN + j];
+                    else if constexpr (EPI & EPI_RES)
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs2, vo_r2 + j * 128, so_r2, 0));
                     if constexpr (EPI & EPI_F32OUT)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, vo_c + j * 128, so_c, 0);
                     else
@@ -466,7 +477,10 @@ __device__ __forceinline__ void gemm_glds_tile(const GemmP& p, char* smem, int b
                     float v = acc[i][j][reg] + bj[j];
                     if constexpr (EPI & EPI_ROWTAB) v += p.rowtab[(long long)(r % p.rt_mod) * p.rt_ld + c];
                     if constexpr (EPI & EPI_GELU) v = gelu_fast2(v);
-                    if constexpr (EPI & EPI_RES) v += rres[(i * 16 + reg) * TN + j];
+                    if constexpr (RES_PREFETCH)
+                        v += rres[(i * 16 + reg) * TN + j];
+                    else if constexpr (EPI & EPI_RES)
+                        v += p.res[pr * p.ldr + c];
                     if constexpr (EPI & EPI_F32OUT)
                         p.Cf[pr * p.ldc + c] = v;
                     else
@@ -612,13 +626,11 @@ bool launch_gemm_glds(const GemmP& p, hipStream_t st) {
     const long long big_tiles = (long long)((p.M + 127) / 128) * (p.N / 128);
     if (big_tiles < 512) return false;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || (p.lda % 8) || (p.ldw % 8)) return false;
-    if (p.variant == 4) return launch_tile<256, 128, 2, 2>(p, st);
-    if (p.variant == 5 && p.N % 256 == 0) return launch_tile<256, 256, 2, 4>(p, st);
-    if (p.variant == 6) return launch_tile<256, 128, 4, 2>(p, st);
+    // (the 256-row double-buffer tilings, former variants 4-6 / 25, were retired: under the two-workgroups-per-CU
+    // register budget this kernel is compiled for they spill, and they never beat the 128x128 tile on these shapes)
     if (p.variant == 3) return launch_tile<128, 128, 2, 2>(p, st);
     if (p.variant == 2) return launch_tile<128, 128, 2, 2, 64>(p, st);
     if ((p.variant >= 20 && p.variant <= 22) || p.variant == 24) return launch_tile<128, 128, 2, 2>(p, st);
-    if (p.variant == 25 && p.N % 256 == 0) return launch_tile<256, 256, 2, 4>(p, st);
     GemmP q = p;
     q.peel = 0;
     if (p.variant == 26 || (p.variant >= 28 && p.variant <= 30) || p.variant == 32) return launch_ring3(q, st);  // ring, no peeling (32: flat-address DMA)
