@@ -53,7 +53,8 @@ typedef void __attribute__((address_space(3))) * lptr_t;
 // 48 KiB of LDS per 128x128 workgroup => three workgroups per CU.
 template <int N>
 __device__ __forceinline__ void glds_wait_barrier() {
-    static_assert(N == 0 || N == 2 || N == 4 || N == 6, "add the immediate");
+    static_assert(N == 0 || N == 2 || N == 4 || N == 6 || N == 8, "add the immediate");
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
     if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
