@@ -627,8 +627,8 @@ bool launch_gemm_glds(const GemmP& p, hipStream_t st) {
     const long long big_tiles = (long long)((p.M + 127) / 128) * (p.N / 128);
     if (big_tiles < 512) return false;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || (p.lda % 8) || (p.ldw % 8)) return false;
-    // (the 256-row double-buffer tilings, former variants 4-6 / 25, were retired: under the two-workgroups-per-CU
-    // register budget this kernel is compiled for they spill, and they never beat the 128x128 tile on these shapes)
+    // (the 256-row double-buffer tilings, former variants 4-6 / 25, were retired: after this round's refactors they
+    // spill under their 256-register budget, and they never beat the 128x128 tile on these shapes)
     if (p.variant == 3) return launch_tile<128, 128, 2, 2>(p, st);
     if (p.variant == 2) return launch_tile<128, 128, 2, 2, 64>(p, st);
     if ((p.variant >= 20 && p.variant <= 22) || p.variant == 24) return launch_tile<128, 128, 2, 2>(p, st);
