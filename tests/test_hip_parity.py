@@ -235,6 +235,44 @@ def test_c2_bf16_screen_quality():
     h.close()
 
 
+def test_c4_block_bf16_screen_quality():
+    """T=64 / H=32 shapes in bf16 (halfcheetah dims): exercises the two-chunk attention kernel with two query / key
+    segments (64 shared + 33 own tokens in the first layer) and the pre-reduced masked-key block at Lk = 97.
+    Bar: 3 % of the score scale (the T=32 study measured up to 2.9 %), reference block arg-max inside the bf16 top-32."""
+    g, dims, h, cfg, win = _full("c4", 512)
+    N, H, T = cfg.action_samples, cfg.horizon, cfg.traj_length
+    eps = synth.make_eps(N, dims, 1)[:, 0, :, 0, :].cuda()
+    s, a, r = window_dev(win)
+    b0, b1 = (int(x) for x in g["blocks"][0])
+    res = h.plan_step(capi.MODE_RTG, s, a, r, eps, H, 3.0, 0.6, 0.99, N, n_begin=b0, n_count=b1 - b0, precision=capi.PREC_BF16)
+    er = res["expect_return"]
+    got = (er - er.max()).cpu().numpy()
+    ref = g["expect_return_shifted_blocks"][0]
+    err = np.abs((got - got.mean()) - (ref - ref.mean())).max()
+    scale = float(er.abs().max())
+    assert err <= 3e-2 * scale, f"bf16 expect_return err {err:.3f} vs scale {scale:.1f}"
+    assert int(np.argmax(ref)) in torch.topk(er, 32).indices.tolist()
+    h.close()
+
+
+def test_c3_critic_bf16_screen_quality():
+    """critic_lambda_guiding in bf16 (walker2d dims, N=4096): per-candidate decoder queries (no shared query table),
+    first-layer history sharing on, twin-Q on bf16-decoded states.  Same bar as the rtg screen."""
+    g, dims, h, cfg, win = _full("c3", 4096)
+    N, H, T = cfg.action_samples, cfg.horizon, cfg.traj_length
+    eps = synth.make_eps(N, dims, 1)[:, 0, :, 0, :].cuda()
+    s, a, r = window_dev(win)
+    res = h.plan_step(capi.MODE_CRITIC, s, a, r, eps, H, 3.0, 0.6, 0.99, N, precision=capi.PREC_BF16)
+    er = res["expect_return"]
+    got = (er - er.max()).cpu().numpy()
+    ref = g["expect_return_shifted"]
+    err = np.abs((got - got.mean()) - (ref - ref.mean())).max()
+    scale = max(float(er.abs().max()), float(np.abs(ref).max()), 1.0)
+    assert err <= 3e-2 * scale, f"bf16 critic expect_return err {err:.4f} vs scale {scale:.2f}"
+    assert int(g["argmax"]) in torch.topk(er, 32).indices.tolist()
+    h.close()
+
+
 # ------------------------------------------------------------------------------------ edge shapes vs the oracle
 @pytest.mark.parametrize("T,H,N,mode", [(8, 4, 625, "rtg"), (8, 4, 625, "critic"), (8, 1, 37, "rtg"), (8, 8, 130, "critic"),
                                         (16, 5, 1, "rtg"), (8, 4, 64, "noise")])
