@@ -119,8 +119,63 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* v, int n, int n
     }
     for (int i = tid; i < k; i += 1024) idx_out[i] = (int)(~(unsigned int)(keys[i] & 0xffffffffull));
 }
+// k <= 64 of n <= 16384 by selection instead of a full sort: every wave extracts the k best of its own 1/16 of the
+// values with k rounds of (register-local arg-max, 64-lane butterfly) -- no barrier --, then wave 0 does the same over
+// the 16 k survivors.  Same order as the bitonic kernel (descending value, ties to the lower index); ~3x faster
+// at n = 1024 and independent of n up to 16384 (the replicated top-k of an 8-GPU run sorts 8192 scores).
+__global__ __launch_bounds__(1024) void topk_select_kernel(const float* v, int n, int k, int* idx_out) {
+    __shared__ float cv[16 * 64];
+    __shared__ int ci[16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float val[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int e = s * 1024 + tid;
+        val[s] = e < n ? v[e] : -INFINITY;
+    }
+    for (int r = 0; r < k; ++r) {
+        ArgMax a{-INFINITY, 0x7fffffff};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) a = better(a, ArgMax{val[s], s * 1024 + tid});
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a = better(a, ArgMax{__shfl_xor(a.v, o), __shfl_xor(a.i, o)});
+        if (lane == 0) {
+            cv[wid * k + r] = a.v;
+            ci[wid * k + r] = a.i;
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            if (s * 1024 + tid == a.i) val[s] = -INFINITY;
+    }
+    __syncthreads();
+    if (wid != 0) return;
+    float mv[16];
+    int mi[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = j * 64 + lane;
+        mv[j] = c < 16 * k ? cv[c] : -INFINITY;
+        mi[j] = c < 16 * k ? ci[c] : 0x7fffffff;
+    }
+    for (int r = 0; r < k; ++r) {
+        ArgMax a{-INFINITY, 0x7fffffff};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a = better(a, ArgMax{mv[j], mi[j]});
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a = better(a, ArgMax{__shfl_xor(a.v, o), __shfl_xor(a.i, o)});
+        if (lane == 0) idx_out[r] = a.i;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (mi[j] == a.i) mv[j] = -INFINITY;
+    }
+}
+
 void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st) {
     if (n <= 0 || k <= 0) return;
+    if (k <= 64 && n <= 16384) {
+        hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(1024), 0, st, v, n, k, idx_out);
+        return;
+    }
     int np = 2;
     while (np < n) np <<= 1;
     static bool attr = false;
