@@ -16,7 +16,7 @@ def main():
     f = glob.glob(src + "/**/*kernel_trace.csv", recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    ends = [i for i, r in enumerate(rows) if "select_kernel" in r["Kernel_Name"]]
+    ends = [i for i, r in enumerate(rows) if "::select_kernel" in r["Kernel_Name"]]  # (not topk_select_kernel)
     a, b = ends[-12] + 1, ends[-11] + 1  # one step well inside the timed region
     step = rows[a:b]
     t0 = int(step[0]["Start_Timestamp"])
