@@ -465,18 +465,30 @@ __device__ __forceinline__ void gemm_glds_tile(const GemmP& p, char* smem, int b
         }
         return;
     }
+    // General path (row-mapped outputs, row tables, partial tiles).  The row map and the row-table index need an
+    // integer division per ROW; done per lane and element they cost more than the tile's MFMAs, so one thread per tile
+    // row does them once and parks {physical row | -1, row-table row} in LDS (free after the K loop).
+    __syncthreads();
+    int* rowinfo = (int*)smem;
+    for (int rr = tid; rr < BM; rr += NW * 64) {
+        const int gr = row0 + rr;
+        rowinfo[2 * rr] = gr < p.M ? map_row2(p.cmap, gr) : -1;
+        rowinfo[2 * rr + 1] = (EPI & EPI_ROWTAB) ? gr % p.rt_mod : 0;
+    }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const int r = row0 + wr * WTM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-            if (r < p.M) {
-                const long long pr = map_row2(p.cmap, r);
+            const int rl = wr * WTM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            const int pri = rowinfo[2 * rl], tri = rowinfo[2 * rl + 1];
+            if (pri >= 0) {
+                const long long pr = pri;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int c = col0 + wc * WTN + j * 32 + l31;
                     float v = acc[i][j][reg] + bj[j];
-                    if constexpr (EPI & EPI_ROWTAB) v += p.rowtab[(long long)(r % p.rt_mod) * p.rt_ld + c];
+                    if constexpr (EPI & EPI_ROWTAB) v += p.rowtab[tri * p.rt_ld + c];
                     if constexpr (EPI & EPI_GELU) v = gelu_fast2(v);
                     if constexpr (RES_PREFETCH)
                         v += rres[(i * 16 + reg) * TN + j];
