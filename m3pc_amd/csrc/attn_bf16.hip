@@ -223,17 +223,18 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
 // transposing ds_read_b64_tr_b16), and V's loads are issued as soon as the K registers are free so that the softmax
 // runs under them.  One wave per 32-query tile, NW tiles per block sharing the V image.  Arithmetic and its order are
 // those of attn_bf16_kernel<HDT, 1>.
-template <int HDT, int NW>
+// NKT = 32-key tiles held in accumulators (2: Lk <= 64, 4: Lk <= 128)
+template <int HDT, int NW, int NKT>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_direct_kernel(AttnP p) {
     constexpr int HD = HDT * 32;
     constexpr int ROWB = HD * 2 + 16;
     constexpr int NS = HD / 16;
     constexpr int CPR = HD / 8;
     constexpr int NTHR = NW * 64;
-    constexpr int VPT = 64 * CPR / NTHR;  // 16-byte V chunks per thread
-    static_assert(64 * CPR % NTHR == 0, "V tile must divide over the block");
+    constexpr int VPT = NKT * 32 * CPR / NTHR;  // 16-byte V chunks per thread
+    static_assert(NKT * 32 * CPR % NTHR == 0, "V image must divide over the block");
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    float* fbuf = (float*)(lds + 64 * ROWB);
+    float* fbuf = (float*)(lds + NKT * 32 * ROWB);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.x, head = blockIdx.y, q0 = blockIdx.z * (NW * 32);
@@ -255,39 +256,39 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_direct_kernel(AttnP p) {
         qrow = Qb + (long long)qi * p.ldq;
     else if (Q2b && qi >= Lq1p && qi - Lq1p < p.Lq2)
         qrow = Q2b + (long long)(qi - Lq1p) * p.ldq2;
-    const bf16_t* krow[2];
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-        const int j = jt * 32 + l31;
-        krow[jt] = j < p.L1 ? K1 + (long long)j * p.ldkv1 : (j < Lk ? K2 + (long long)(j - p.L1) * p.ldkv2 : nullptr);
-    }
-    u32x4 qf[NS], kf[2][NS];
+    u32x4 qf[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         qf[s] = zero4;
         if (qrow) qf[s] = *(const u32x4*)(qrow + 16 * s + 8 * lh);
     }
+    f32x16 sacc[NKT];
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            kf[jt][s] = zero4;
-            if (krow[jt]) kf[jt][s] = *(const u32x4*)(krow[jt] + 16 * s + 8 * lh);
-        }
-
-    f32x16 sacc[2];
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+    for (int jt = 0; jt < NKT; ++jt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) sacc[jt][e] = 0.f;
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-        if (jt * 32 < Lk) {
+    for (int pr = 0; pr < NKT / 2; ++pr) {  // two key tiles' fragments in registers at a time
+        u32x4 kf[2][NS];
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                sacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[jt][s]), __builtin_bit_cast(bf16x8, qf[s]),
-                                                                   sacc[jt], 0, 0, 0);
+        for (int t = 0; t < 2; ++t) {
+            const int j = (2 * pr + t) * 32 + l31;
+            const bf16_t* krow = j < p.L1 ? K1 + (long long)j * p.ldkv1 : (j < Lk ? K2 + (long long)(j - p.L1) * p.ldkv2 : nullptr);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                kf[t][s] = zero4;
+                if (krow) kf[t][s] = *(const u32x4*)(krow + 16 * s + 8 * lh);
+            }
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            if ((2 * pr + t) * 32 < Lk) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    sacc[2 * pr + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[t][s]),
+                                                                               __builtin_bit_cast(bf16x8, qf[s]), sacc[2 * pr + t], 0, 0, 0);
+            }
+    }
     // V: issue the loads now (the K registers are dead), park them in LDS after the softmax
     u32x4 vv[VPT];
 #pragma unroll
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_direct_kernel(AttnP p) {
 
     float m = -INFINITY;
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+    for (int jt = 0; jt < NKT; ++jt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int j = jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_direct_kernel(AttnP p) {
     m = fmaxf(m, __shfl_xor(m, 32));
     float l = 0.f;
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+    for (int jt = 0; jt < NKT; ++jt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const float v = __builtin_amdgcn_exp2f((sacc[jt][e] - m) * 1.44269504088896340736f);
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_direct_kernel(AttnP p) {
     const int gi = lane & 15;
     const int tr_off = (gi >> 2) * ROWB + (((lane >> 4) & 1) * 16 + (gi & 3) * 4) * 2;
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
+    for (int jt = 0; jt < NKT; ++jt) {
         if (jt * 32 < Lk) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -391,11 +392,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_direct_kernel(AttnP p) {
         }
     }
 }
-template <int HDT, int NW>
+template <int HDT, int NW, int NKT>
 static void launch_direct(const AttnP& p, int slots, hipStream_t st) {
-    const size_t smem = (size_t)64 * (HDT * 64 + 16) + NW * 32 * sizeof(float);
+    const size_t smem = (size_t)NKT * 32 * (HDT * 64 + 16) + NW * 32 * sizeof(float);
     const int qgroups = (slots + NW * 32 - 1) / (NW * 32);
-    hipLaunchKernelGGL((attn_bf16_direct_kernel<HDT, NW>), dim3(p.batch, p.n_head, qgroups), dim3(NW * 64), smem, st, p);
+    hipLaunchKernelGGL((attn_bf16_direct_kernel<HDT, NW, NKT>), dim3(p.batch, p.n_head, qgroups), dim3(NW * 64), smem, st, p);
 }
 
 template <int HDT, int NCH>
@@ -415,9 +416,11 @@ static void launch_hd(const AttnP& p, hipStream_t st) {
     static const bool no_direct = getenv("M3PC_NO_ATTN_DIRECT") != nullptr;  // A/B switch
     if (Lk <= 64 && !no_direct) {
         if (slots <= 32)
-            launch_direct<HDT, 1>(p, slots, st);
+            launch_direct<HDT, 1, 2>(p, slots, st);
         else
-            launch_direct<HDT, 2>(p, slots, st);
+            launch_direct<HDT, 2, 2>(p, slots, st);
+    } else if (Lk <= 128 && !no_direct) {  // (two waves per block: the 128-row V image divides over 128 threads)
+        launch_direct<HDT, 2, 4>(p, slots, st);
     } else if (Lk <= 64)
         launch_nch<HDT, 1>(p, grid, block, smem, st);
     else if (Lk <= 128)
