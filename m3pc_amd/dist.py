@@ -38,6 +38,13 @@ def gather_candidates(er_shard: torch.Tensor, a0_shard: torch.Tensor, n_total: i
     if world == 1:
         return er_shard, a0_shard
     A = a0_shard.shape[1]
+    if n_total % world == 0:
+        # equal shards (the usual case): pack with one cat, gather, one copy for the scores (the re-score writes into
+        # them); the first actions stay a strided view of the gathered buffer (m3pc_select takes a row stride)
+        pack = torch.cat([er_shard[:, None], a0_shard], dim=1)
+        out = torch.empty((n_total, 1 + A), dtype=pack.dtype, device=pack.device)
+        dist.all_gather_into_tensor(out, pack, group=group)
+        return out[:, 0].contiguous(), out[:, 1:]
     nmax = -(-n_total // world)
     pack = torch.zeros((nmax, 1 + A), dtype=er_shard.dtype, device=er_shard.device)
     n_r = er_shard.shape[0]

@@ -126,7 +126,7 @@ class HipPlanner:
         res = self.handle.plan_step(mode, states, actions, rewards, eps, h, rtg, float(lmbda), float(cfg.discount),
                                     N, begin, count, precision=self.precision)
         er, a0 = res["expect_return"], res["sample_actions"][:, 0]
-        er, a0 = mdist.gather_candidates(er, a0.contiguous() if self.world > 1 else a0, N, self.group)
+        er, a0 = mdist.gather_candidates(er, a0, N, self.group)
         top = None
         if self.rescore_topk > 0:
             # replicated on every rank (identical inputs => identical result): top-k of the gathered scores,
