@@ -374,6 +374,15 @@ int launch_gemm(const GemmP& p, int dtype, hipStream_t st) {
     // default (variant 0): many-row bf16 problems on the LDS-DMA kernel (gemm_glds.hip, 128x128 tiles),
     // few-row problems on the register-staged kernel below; variants 4-9 are the experimental tilings
     if (dtype == DT_BF16 && p.variant == 9 && launch_gemm_persist(p, st)) return 0;
+    if (dtype == DT_BF16 && p.variant == 36 && launch_gemm_rs(p, st)) return 0;
+    // long-K many-row problems (this step's FFN2, K = 2048): 256x256 tiles at one wave per SIMD (gemm_big.hip).  Same
+    // MFMA instruction, k order and epilogue arithmetic as the 128x128 ring kernel, so results are bit-identical and the
+    // choice may depend on the row count.  It needs about one tile per CU to pay (one workgroup per CU, no overlap).
+    static const bool no_big = getenv("M3PC_NO_GEMM_BIG") != nullptr;  // A/B switch
+    if (dtype == DT_BF16 && p.variant >= 37 && p.variant <= 42 && launch_gemm_big(p, st)) return 0;
+    if (dtype == DT_BF16 && p.variant == 0 && !no_big && p.K >= 1024 && (long long)((p.M + 255) / 256) * (p.N / 256) >= 224 &&
+        launch_gemm_big(p, st))
+        return 0;
     if (dtype == DT_BF16 && p.variant >= 7 && p.variant != 9 && p.variant < 20 && launch_gemm_ring(p, st)) return 0;
     if (dtype == DT_BF16 && (p.variant == 0 || (p.variant >= 2 && p.variant < 7) || (p.variant >= 20 && p.variant <= 32)) &&
         launch_gemm_glds(p, st))

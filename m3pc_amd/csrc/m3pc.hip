@@ -1569,6 +1569,12 @@ int m3pc_debug_clock(long long* out2) {
     return 0;
 }
 
+int m3pc_debug_clock_big(long long* out4) {
+    HIPCHK(hipDeviceSynchronize());
+    read_big_probe(out4);
+    return 0;
+}
+
 int m3pc_profile_enable(m3pc_handle* h, int enable) {
     if (!h) return fail(M3PC_EINVAL, "null handle");
     h->prof = enable != 0;

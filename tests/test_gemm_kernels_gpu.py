@@ -1,0 +1,58 @@
+"""GPU checks of the bf16 GEMM kernels against each other and against torch fp32 (needs an MI355X).
+
+The library picks a GEMM kernel by shape (128x128 three-slot ring by default, 256x256 tiles at one wave per SIMD for
+long-K many-row problems).  Sharded and single-GPU runs must agree bit for bit (tests/test_hip_parity.py::
+test_sharding_is_exact), and a shard sees a different row count, hence possibly a different kernel: every
+kernel on the default dispatch must therefore produce IDENTICAL bits -- same MFMA instruction, same k order, same
+epilogue arithmetic.  This test holds them to that through the library's debug entry (m3pc_debug_gemm; not part of the
+public header).
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+from m3pc_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _gemm(lib, A, W, bias, R, out, gelu, variant):
+    fn = lib.m3pc_debug_gemm
+    fn.restype = C.c_int
+    vp, i = C.c_void_p, C.c_int
+    fn.argtypes = [i, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
+    M, K = A.shape
+    N = W.shape[0]
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = fn(1, A.data_ptr(), W.data_ptr(), bias.data_ptr(), R.data_ptr() if R is not None else None, out.data_ptr(),
+            M, N, K, gelu, int(out.dtype == torch.float32), variant, st)
+    assert rc == 0, lib.m3pc_last_error()
+    torch.cuda.synchronize()
+
+
+# (M, N, K, residual): full 256-row tiles, a ragged last tile, the long-K residual GEMM the 256x256 kernel is used for
+@pytest.mark.parametrize("M,N,K,res", [(57344, 512, 2048, True), (57344 + 77, 512, 1024, True), (61440, 256, 2048, False)])
+def test_big_tile_kernel_is_bit_identical_to_the_ring(M, N, K, res):
+    lib = capi.load_library()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev, generator=g)
+    R = torch.randn(M, N, device=dev, generator=g) if res else None
+    outs = {}
+    for v in (0, 26, 37, 2):  # default dispatch, ring (no peeling), 256x256 tiles, plain double buffer
+        out = torch.full((M, N), float("nan"), device=dev, dtype=torch.float32)
+        _gemm(lib, A, W, bias, R, out, 0, v)
+        outs[v] = out
+    assert torch.equal(outs[37], outs[26]), "256x256 kernel and 128x128 ring differ"
+    assert torch.equal(outs[0], outs[26]), "default dispatch differs from the ring"
+    assert torch.equal(outs[2], outs[26]), "double-buffer kernel differs from the ring"
+    # and all of them are the right product: fp32 reference on a row sample (bf16 operands are exact in fp32)
+    sel = torch.cat([torch.arange(300), torch.arange(M - 300, M)]).to(dev)
+    ref = A[sel].float() @ W.float().T + bias
+    if res:
+        ref = ref + R[sel]
+    err = float((outs[37][sel] - ref).abs().max())
+    assert err <= 2e-5 * float(ref.abs().max()), err  # fp32 accumulation, summation order only
