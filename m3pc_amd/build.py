@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libm3pc_hip.so")
-SOURCES = ["gemm.hip", "gemm_glds.hip", "gemm_ring.hip", "gemm_persist.hip", "gemm_rs.hip", "gemm_big.hip", "gemm_f32_direct.hip", "attn.hip", "attn_bf16.hip", "elementwise.hip", "select.hip", "m3pc.hip"]
+SOURCES = ["gemm.hip", "gemm_glds.hip", "gemm_ring.hip", "gemm_persist.hip", "gemm_rs.hip", "gemm_big.hip", "gemm_line.hip", "gemm_f32_direct.hip", "attn.hip", "attn_bf16.hip", "elementwise.hip", "select.hip", "m3pc.hip"]
 ARCH = "gfx950"
 
 

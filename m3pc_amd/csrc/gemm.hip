@@ -380,6 +380,14 @@ int launch_gemm(const GemmP& p, int dtype, hipStream_t st) {
     // choice may depend on the row count.  It needs about one tile per CU to pay (one workgroup per CU, no overlap).
     static const bool no_big = getenv("M3PC_NO_GEMM_BIG") != nullptr;  // A/B switch
     if (dtype == DT_BF16 && p.variant >= 37 && p.variant <= 42 && launch_gemm_big(p, st)) return 0;
+    if (dtype == DT_BF16 && p.variant >= 43 && p.variant <= 46 && launch_gemm_line(p, p.variant == 44 ? 256 : 128, st)) return 0;
+    // K = 512-class many-row problems without a residual stream: 128x128 tiles fed by whole-cache-line DMA pieces through
+    // a five-unit ring, persistent workgroups (gemm_line.hip).  The residual GEMMs of this class are HBM-bound and stay
+    // on the three-slot ring kernel, as do output row maps / row tables.
+    static const bool no_line = getenv("M3PC_NO_GEMM_LINE") != nullptr;  // A/B switch
+    if (dtype == DT_BF16 && p.variant == 0 && !no_line && !p.res && p.K < 1024 &&
+        (long long)((p.M + 127) / 128) * (p.N / 128) >= 384 && launch_gemm_line(p, 128, st))
+        return 0;
     if (dtype == DT_BF16 && p.variant == 0 && !no_big && p.K >= 1024 && (long long)((p.M + 255) / 256) * (p.N / 256) >= 224 &&
         launch_gemm_big(p, st))
         return 0;

@@ -32,6 +32,26 @@ __device__ __forceinline__ float ge_gelu(float x) {
     return fmaf(fabsf(hx), erf_abs, hx);
 }
 
+// the same arithmetic on two values at once: the polynomial runs on v_pk_fma_f32 / v_pk_mul_f32 (two fp32 lanes per
+// instruction), which halves its VALU cost; every operation and its order match ge_gelu, so the results are identical
+typedef float ge_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ge_f32x2 ge_gelu2(ge_f32x2 x) {
+    const ge_f32x2 one = {1.0f, 1.0f};
+    const ge_f32x2 ax = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
+    const ge_f32x2 d = __builtin_elementwise_fma((ge_f32x2){0.3275911f, 0.3275911f}, ax, one);
+    const ge_f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    ge_f32x2 p = __builtin_elementwise_fma(t, (ge_f32x2){1.061405429f, 1.061405429f}, (ge_f32x2){-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(t, p, (ge_f32x2){1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(t, p, (ge_f32x2){-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(t, p, (ge_f32x2){0.254829592f, 0.254829592f});
+    p *= t;
+    const ge_f32x2 a = -ax * ax * 1.44269504088896340736f;
+    const ge_f32x2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    const ge_f32x2 erf_abs = __builtin_elementwise_fma(-p, e, one);
+    const ge_f32x2 hx = 0.5f * x;
+    return __builtin_elementwise_fma(__builtin_elementwise_abs(hx), erf_abs, hx);
+}
+
 __device__ __forceinline__ int ge_map_row(const RowMap& m, int r) {
     if (m.rpg == 0) return r;
     return (r / m.rpg) * m.gstride + (r % m.rpg) + m.off;
@@ -40,13 +60,15 @@ __device__ __forceinline__ int ge_map_row(const RowMap& m, int r) {
 __device__ __forceinline__ unsigned ge_clamp_bytes(long long b) { return b > 0xfffff000ll ? 0xfffff000u : (unsigned)b; }
 
 // rbase / cbase: first row / column of this WAVE's tile, wave-uniform (pass values derived from readfirstlane)
+// bias_pre: the TN bias values of this lane's columns when the caller fetched them earlier (a persistent kernel has
+// the next tile's DMA in flight here and a load issued now would wait for all of it), else nullptr
 template <int EPI, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, ge_f32x16 (&acc)[TM][TN], int rbase, int cbase, int tile_row0,
-                                              int tile_rows, int lane) {
+                                              int tile_rows, int lane, const float* bias_pre = nullptr) {
     const int l31 = lane & 31, lh = lane >> 5;
     float bj[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bj[j] = p.bias ? p.bias[cbase + j * 32 + l31] : 0.f;
+    for (int j = 0; j < TN; ++j) bj[j] = bias_pre ? bias_pre[j] : (p.bias ? p.bias[cbase + j * 32 + l31] : 0.f);
     const bool fast = p.cmap.rpg == 0 && tile_row0 + tile_rows <= p.M && !(EPI & GE_ROWTAB);
     if (fast) {
         constexpr int ES = (EPI & GE_F32OUT) ? 4 : 2;
@@ -67,10 +89,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, ge_f32x16 (&acc)[T
                 const int rr = rbase + i * 32 + (reg & 3) + 8 * (reg >> 2);
                 const int so_c = (rr * p.ldc + cbase) * ES;
                 const int so_r = (rr * p.ldr + cbase) * 4;
+                float vj[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) vj[j] = acc[i][j][reg] + bj[j];
+                if constexpr ((EPI & GE_GELU) != 0) {
+                    if constexpr (TN % 2 == 0) {
+#pragma unroll
+                        for (int j = 0; j < TN; j += 2) {
+                            const ge_f32x2 g2 = ge_gelu2((ge_f32x2){vj[j], vj[j + 1]});
+                            vj[j] = g2.x;
+                            vj[j + 1] = g2.y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) vj[j] = ge_gelu(vj[j]);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    float v = acc[i][j][reg] + bj[j];
-                    if constexpr (EPI & GE_GELU) v = ge_gelu(v);
+                    float v = vj[j];
                     if constexpr (EPI & GE_RES)
                         v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, vo_r + j * 128, so_r, 0));
                     if constexpr (EPI & GE_F32OUT)

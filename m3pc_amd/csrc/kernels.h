@@ -57,6 +57,7 @@ bool launch_gemm_ring(const GemmP& p, hipStream_t st);  // bf16, many rows: 256x
 bool launch_gemm_persist(const GemmP& p, hipStream_t st);  // bf16, many rows: persistent 256x256 tiles (gemm_persist.hip)
 bool launch_gemm_rs(const GemmP& p, hipStream_t st);    // bf16, many rows: register-staged 128x128 ring (gemm_rs.hip)
 bool launch_gemm_big(const GemmP& p, hipStream_t st);   // bf16, many rows, K >= 1024: 256x256 tile, one wave per SIMD (gemm_big.hip)
+bool launch_gemm_line(const GemmP& p, int bt, hipStream_t st);  // bf16, many rows: whole-cache-line DMA pieces, 5-unit ring (gemm_line.hip)
 bool launch_gemm_glds(const GemmP& p, hipStream_t st);  // bf16, many rows: direct-to-LDS staging (gemm_glds.hip)
 void read_big_probe(long long out[4]);                   // debug: gemm_big.hip phase timers
 void read_clock_probe(long long out[2]);                // debug: {shader clocks, 100-MHz ticks} of one ring workgroup

@@ -42,13 +42,15 @@ def test_big_tile_kernel_is_bit_identical_to_the_ring(M, N, K, res):
     bias = torch.randn(N, device=dev, generator=g)
     R = torch.randn(M, N, device=dev, generator=g) if res else None
     outs = {}
-    for v in (0, 26, 37, 2):  # default dispatch, ring (no peeling), 256x256 tiles, plain double buffer
+    for v in (0, 26, 37, 2, 43, 44):  # default dispatch, ring (no peeling), 256x256 tiles, plain double buffer, line 128/256
         out = torch.full((M, N), float("nan"), device=dev, dtype=torch.float32)
         _gemm(lib, A, W, bias, R, out, 0, v)
         outs[v] = out
     assert torch.equal(outs[37], outs[26]), "256x256 kernel and 128x128 ring differ"
     assert torch.equal(outs[0], outs[26]), "default dispatch differs from the ring"
     assert torch.equal(outs[2], outs[26]), "double-buffer kernel differs from the ring"
+    assert torch.equal(outs[43], outs[26]), "whole-line 128x128 kernel differs from the ring"
+    assert torch.equal(outs[44], outs[26]), "whole-line 256x256 kernel differs from the ring"
     # and all of them are the right product: fp32 reference on a row sample (bf16 operands are exact in fp32)
     sel = torch.cat([torch.arange(300), torch.arange(M - 300, M)]).to(dev)
     ref = A[sel].float() @ W.float().T + bias
@@ -56,3 +58,28 @@ def test_big_tile_kernel_is_bit_identical_to_the_ring(M, N, K, res):
         ref = ref + R[sel]
     err = float((outs[37][sel] - ref).abs().max())
     assert err <= 2e-5 * float(ref.abs().max()), err  # fp32 accumulation, summation order only
+
+
+# the K = 512 class (bf16 out, optional GELU): default dispatch = whole-line kernel, persistent workgroups; ragged and
+# row-mapped shapes take its one-workgroup-per-tile form
+@pytest.mark.parametrize("M,N,K,gelu", [(50176, 1536, 512, 0), (50176 + 40, 1024, 512, 1), (16384, 512, 192, 0), (70000, 2048, 512, 1)])
+def test_line_kernel_is_bit_identical_to_the_ring_bf16_out(M, N, K, gelu):
+    lib = capi.load_library()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(M + N + K + gelu)
+    A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev, generator=g)
+    outs = {}
+    for v in (0, 26, 43):
+        out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        _gemm(lib, A, W, bias, None, out, gelu, v)
+        outs[v] = out
+    assert torch.equal(outs[43], outs[26]), "whole-line kernel and ring differ"
+    assert torch.equal(outs[0], outs[26]), "default dispatch differs from the ring"
+    sel = torch.cat([torch.arange(300), torch.arange(M - 300, M)]).to(dev)
+    ref = A[sel].float() @ W.float().T + bias
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    err = float((outs[43][sel].float() - ref).abs().max())
+    assert err <= 2.0 ** -8 * max(float(ref.abs().max()), 1.0), err  # one bf16 rounding of the result
