@@ -190,8 +190,8 @@ def main():
     f_step = alg_flops(n_local, T, H, S, A, mode="critic" if critic_mode else "rtg")
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.precision),
-                "kernel": f"m3pc::gemm_glds_ring3_kernel (few-row launches: gemm_kernel), the {args.precision} MFMA GEMM "
-                          "launches of the candidate pass",
+                "kernel": f"m3pc::gemm_line_kernel / gemm_glds_ring3_kernel / gemm_big_kernel (few-row launches: gemm_kernel), the "
+                          f"{args.precision} MFMA GEMM launches of the candidate pass",
                 "all_gemm_ms_per_step": all_ms / args.steps, "all_gemm_launches_per_step": all_launches / args.steps,
                 "flops_per_launch": gemm_flops / max(launches, 1), "avg_launch_us": 1e3 * gemm_ms / max(launches, 1),
                 "launches_per_step": launches / args.steps, "gemm_ms_per_step": gemm_ms / args.steps,
@@ -231,7 +231,7 @@ def pmc_traffic(precision):
         return None
     n = b = 0
     for name, v in ks.items():
-        if "gemm_glds" in name or "gemm_kernelIDF16b" in name:
+        if "gemm_glds" in name or "gemm_line" in name or "gemm_big" in name or "gemm_kernelIDF16b" in name:
             n += v["launches_profiled"]
             b += v["launches_profiled"] * v["hbm_bytes_per_launch"]
     return int(b / n) if n else None

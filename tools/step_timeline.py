@@ -17,7 +17,8 @@ def main():
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ends = [i for i, r in enumerate(rows) if "::select_kernel" in r["Kernel_Name"]]  # (not topk_select_kernel)
-    a, b = ends[-12] + 1, ends[-11] + 1  # one step well inside the timed region
+    k = len(ends) // 5  # bench.py runs warmup, timed, latency and instrumented passes: this one is inside the timed region
+    a, b = ends[k] + 1, ends[k + 1] + 1
     step = rows[a:b]
     t0 = int(step[0]["Start_Timestamp"])
     prev = None
