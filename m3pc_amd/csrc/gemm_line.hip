@@ -33,11 +33,12 @@ typedef void __attribute__((address_space(3))) * lptr_t;
 
 template <int PU>
 __device__ __forceinline__ void line_wait_barrier() {
-    static_assert(PU == 4 || PU == 8 || PU == 6 || PU == 12 || PU == 24, "add the immediate");
+    static_assert(PU == 4 || PU == 8 || PU == 6 || PU == 12 || PU == 16 || PU == 24, "add the immediate");
     if constexpr (PU == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if constexpr (PU == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if constexpr (PU == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if constexpr (PU == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (PU == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if constexpr (PU == 24) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 1) void gemm_line_kernel(GemmP
 #pragma unroll
     for (int t = 0; t < 4; ++t) foff[t] = l31 * 128 + (((2 * t + lh) ^ sw) * 16);
     const int fragA = wr * (BT / 2) * 128, fragW = wc * (BT / 2) * 128;
-    u32x4 fa[2][T], fw[2][T];
+    u32x4 fa[4][T], fw[4][T];  // four fragment register sets: k-step t of a pair multiplies set t while set t+2 is being read
     // one fragment read of k-step t: g < T -> A row tile g (unit in slot sa), else W row tile g - T (slot sw_)
     auto frag = [&](int set, int sa, int sw_, int t, int g) {
         if (g < T)
@@ -134,8 +135,8 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 1) void gemm_line_kernel(GemmP
     piece_offsets(row0, col0);
     int a_base = uniform ? row0 * lda_b : 0, w_base = uniform ? col0 * ldw_b : 0;  // this tile's scalar offsets
 
-    // prologue (first tile only): A(0) W(0) A(1) W(1) A(2) in flight -- the state every later tile starts from, see the
-    // epilogue -- A(0), W(0) landed; first fragments read.  (np >= 3 is guaranteed by the launcher)
+    // prologue (first tile only): A(0) W(0) A(1) W(1) in flight, A(0), W(0) landed, the fragments of k-steps 0 and 1
+    // read -- the state every later tile finds when its predecessor's loop ends.  (np >= 3: the launcher checks)
 #pragma unroll
     for (int i = 0; i < PU; ++i) piece(0, a_base, false, i);
 #pragma unroll
@@ -144,11 +145,11 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 1) void gemm_line_kernel(GemmP
     for (int i = 0; i < PU; ++i) piece(2, a_base + 128, false, i);
 #pragma unroll
     for (int i = 0; i < PU; ++i) piece(3, w_base + 128, true, i);
-#pragma unroll
-    for (int i = 0; i < PU; ++i) piece(4, a_base + 256, false, i);
-    line_wait_barrier<3 * PU>();
+    line_wait_barrier<2 * PU>();
 #pragma unroll
     for (int g = 0; g < G; ++g) frag(0, 0, 1, 0, g);
+#pragma unroll
+    for (int g = 0; g < G; ++g) frag(1, 0, 1, 1, g);
 
     int a0 = 0;  // slot of A(u)
     const int wu = __builtin_amdgcn_readfirstlane(wid);
@@ -214,64 +215,50 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 1) void gemm_line_kernel(GemmP
                                                                         __builtin_bit_cast(bf16x8, fw[set][j]), acc[i][j], 0, 0, 0);
         };
 
-        // One pair.  FIRST (pair 0 of a tile): the pieces of k-steps 0-2 -- second half of W(1), A(2) -- were issued
-        // ahead, by the prologue or at the start of the previous tile's epilogue, so that the DMA stream does not pause
-        // while a workgroup is busy with its epilogue (the K loop is bound by that stream).
-        auto body = [&](int u, auto first_c) {
-            constexpr bool FIRST = decltype(first_c)::value;
+        for (int u = 0; u < np; ++u) {
             // slots of A(u) W(u) A(u+1) W(u+1) A(u+2).  Pairs u+1, u+2 past the end of K are pairs 0, 1 of the next tile
             // (selected arithmetically: the body stays ONE basic block and the vmcnt immediate a constant).
             const int s_a = a0, s_w = a0 + 1 >= 5 ? a0 - 4 : a0 + 1, s_a1 = a0 + 2 >= 5 ? a0 - 3 : a0 + 2,
                       s_w1 = a0 + 3 >= 5 ? a0 - 2 : a0 + 3, s_a2 = a0 + 4 >= 5 ? a0 - 1 : a0 + 4;
-            const bool nx1 = u + 1 >= np, nx2 = u + 2 >= np;
-            const int so_w1 = (nx1 ? w_base_n + (u + 1 - np) * 128 : w_base + (u + 1) * 128);
+            const bool nx2 = u + 2 >= np;
             const int so_a2 = (nx2 ? a_base_n + (u + 2 - np) * 128 : a_base + (u + 2) * 128);
             const int so_w2 = (nx2 ? w_base_n + (u + 2 - np) * 128 : w_base + (u + 2) * 128);
             // (reads and DMA pieces alternate in SOURCE order: the compiler must assume they alias, so it keeps that order)
-            // k-step 0: second half of W(u+1)
+            // k-step 0: fragments of k-step 2; first half of A(u+2) into the slot W(u-1) left at the last barrier
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                frag(1, s_a, s_w, 1, g);
-                if (!FIRST && (g & 1)) piece(s_w1, so_w1, true, PU / 2 + (g >> 1));
+                frag(2, s_a, s_w, 2, g);
+                if (g & 1) piece(s_a2, so_a2, false, g >> 1);
             }
             mma(0);
-            pattern(!FIRST);
-            // k-step 1: first half of A(u+2)
+            pattern(true);
+            // k-step 1: fragments of k-step 3; second half of A(u+2)
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                frag(0, s_a, s_w, 2, g);
-                if (!FIRST && (g & 1)) piece(s_a2, so_a2, false, g >> 1);
+                frag(3, s_a, s_w, 3, g);
+                if (g & 1) piece(s_a2, so_a2, false, PU / 2 + (g >> 1));
             }
             mma(1);
-            pattern(!FIRST);
-            // k-step 2: second half of A(u+2)
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                frag(1, s_a, s_w, 3, g);
-                if (!FIRST && (g & 1)) piece(s_a2, so_a2, false, PU / 2 + (g >> 1));
-            }
-            mma(0);
-            pattern(!FIRST);
-            // k-step 3: first half of W(u+2) into the slot A(u) vacated, first fragments of pair u+1
+            pattern(true);
+            // k-step 2: every read of pair u is back and A(u+1), W(u+1) have landed everywhere -> fragments of pair u+1,
+            // k-step 0; first half of W(u+2) into the slot A(u) vacated
             line_wait_barrier<PU>();
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 frag(0, s_a1, s_w1, 0, g);
                 if (g & 1) piece(s_a, so_w2, true, g >> 1);
             }
-            mma(1);
+            mma(2);
+            pattern(true);
+            // k-step 3: fragments of pair u+1, k-step 1; second half of W(u+2)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                frag(1, s_a1, s_w1, 1, g);
+                if (g & 1) piece(s_a, so_w2, true, PU / 2 + (g >> 1));
+            }
+            mma(3);
             pattern(true);
             a0 = s_a1;
-        };
-        body(0, std::true_type{});
-        for (int u = 1; u < np; ++u) body(u, std::false_type{});
-        // the next tile's pair-0 issues, made now (slots relative to its A(0) = a0: W(1) in a0+3, A(2) in a0+4)
-        {
-            const int s_w1 = a0 + 3 >= 5 ? a0 - 2 : a0 + 3, s_a2 = a0 + 4 >= 5 ? a0 - 1 : a0 + 4;
-#pragma unroll
-            for (int i = PU / 2; i < PU; ++i) piece(s_w1, w_base_n + 128, true, i);
-#pragma unroll
-            for (int i = 0; i < PU; ++i) piece(s_a2, a_base_n + 256, false, i);
         }
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (MFMA results are read by the epilogue's VALU right away)
 

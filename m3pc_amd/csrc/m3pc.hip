@@ -1569,6 +1569,12 @@ int m3pc_debug_clock(long long* out2) {
     return 0;
 }
 
+// Not part of the public header (tests/test_gemm_kernels_gpu.py): the top-k kernels on their own.
+int m3pc_debug_topk(const float* v, int n, int k, int* idx_out, void* stream) {
+    launch_topk(v, n, k, idx_out, (hipStream_t)stream);
+    return check_launch("debug_topk");
+}
+
 int m3pc_debug_clock_big(long long* out4) {
     HIPCHK(hipDeviceSynchronize());
     read_big_probe(out4);

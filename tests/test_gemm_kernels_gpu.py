@@ -83,3 +83,28 @@ def test_line_kernel_is_bit_identical_to_the_ring_bf16_out(M, N, K, gelu):
         ref = torch.nn.functional.gelu(ref)
     err = float((outs[43][sel].float() - ref).abs().max())
     assert err <= 2.0 ** -8 * max(float(ref.abs().max()), 1.0), err  # one bf16 rounding of the result
+
+
+# top-k kernels (rank-by-counting for n <= 2048, k-round selection up to 16384, bitonic beyond / for k > 64): descending
+# value, ties to the lower index -- torch's stable sort of the negated scores
+@pytest.mark.parametrize("n", [5, 64, 1000, 1024, 1025, 2048, 2049, 8192, 16384])
+@pytest.mark.parametrize("k", [1, 16, 64])
+def test_topk_order_matches_stable_sort(n, k):
+    if k > n:
+        pytest.skip("k <= n by contract")
+    lib = capi.load_library()
+    fn = lib.m3pc_debug_topk
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(n * 131 + k)
+    for ties in (False, True):
+        v = torch.randn(n, device=dev, generator=g)
+        if ties:
+            v = torch.round(v * 2.0) / 2.0  # a handful of distinct values: the order is decided by the index
+        out = torch.full((k,), -1, device=dev, dtype=torch.int32)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert fn(v.data_ptr(), n, k, out.data_ptr(), st) == 0, lib.m3pc_last_error()
+        torch.cuda.synchronize()
+        ref = torch.sort(-v, stable=True).indices[:k].to(torch.int32)
+        assert torch.equal(out, ref), (n, k, ties)
