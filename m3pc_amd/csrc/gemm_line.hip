@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 1) void gemm_line_kernel(GemmP
 #pragma unroll
     for (int t = 0; t < 4; ++t) foff[t] = l31 * 128 + (((2 * t + lh) ^ sw) * 16);
     const int fragA = wr * (BT / 2) * 128, fragW = wc * (BT / 2) * 128;
-    u32x4 fa[4][T], fw[4][T];  // four fragment register sets: k-step t of a pair multiplies set t while set t+2 is being read
+    u32x4 fa[2][T], fw[2][T];  // two fragment register sets: k-step t multiplies set t & 1 while the other is being read
     // one fragment read of k-step t: g < T -> A row tile g (unit in slot sa), else W row tile g - T (slot sw_)
     auto frag = [&](int set, int sa, int sw_, int t, int g) {
         if (g < T)
@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 1) void gemm_line_kernel(GemmP
     piece_offsets(row0, col0);
     int a_base = uniform ? row0 * lda_b : 0, w_base = uniform ? col0 * ldw_b : 0;  // this tile's scalar offsets
 
-    // prologue (first tile only): A(0) W(0) A(1) W(1) in flight, A(0), W(0) landed, the fragments of k-steps 0 and 1
-    // read -- the state every later tile finds when its predecessor's loop ends.  (np >= 3: the launcher checks)
+    // prologue (first tile only): A(0) W(0) A(1) and the first half of W(1) in flight, A(0), W(0) landed, the fragments
+    // of k-step 0 read -- the state every later tile finds when its predecessor's loop ends.  (np >= 3: the launcher checks)
 #pragma unroll
     for (int i = 0; i < PU; ++i) piece(0, a_base, false, i);
 #pragma unroll
@@ -144,14 +144,71 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 1) void gemm_line_kernel(GemmP
 #pragma unroll
     for (int i = 0; i < PU; ++i) piece(2, a_base + 128, false, i);
 #pragma unroll
-    for (int i = 0; i < PU; ++i) piece(3, w_base + 128, true, i);
-    line_wait_barrier<2 * PU>();
+    for (int i = 0; i < PU / 2; ++i) piece(3, w_base + 128, true, i);
+    line_wait_barrier<PU + PU / 2>();
 #pragma unroll
     for (int g = 0; g < G; ++g) frag(0, 0, 1, 0, g);
-#pragma unroll
-    for (int g = 0; g < G; ++g) frag(1, 0, 1, 1, g);
 
     int a0 = 0;  // slot of A(u)
+    auto mma = [&](f32x16 (&acc)[T][T], int set) {
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+#pragma unroll
+            for (int j = 0; j < T; ++j)
+                if (DBG == 2) {
+                    if (i == j) acc[i][j][0] += __builtin_bit_cast(float, fa[set][i][0] ^ fw[set][j][1]);
+                } else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][i]),
+                                                                    __builtin_bit_cast(bf16x8, fw[set][j]), acc[i][j], 0, 0, 0);
+    };
+    // One pair of the K loop on the accumulators `acc`; `mid()` runs right after the pair's barrier.
+    auto pair = [&](int u, int npairs, f32x16 (&acc)[T][T], int a_base_n, int w_base_n, auto&& mid) {
+        // slots of A(u) W(u) A(u+1) W(u+1) A(u+2).  Pairs u+1, u+2 past the end of K are pairs 0, 1 of the next tile
+        // (selected arithmetically: the body stays ONE basic block and the vmcnt immediate a constant).
+        const int s_a = a0, s_w = a0 + 1 >= 5 ? a0 - 4 : a0 + 1, s_a1 = a0 + 2 >= 5 ? a0 - 3 : a0 + 2,
+                  s_w1 = a0 + 3 >= 5 ? a0 - 2 : a0 + 3, s_a2 = a0 + 4 >= 5 ? a0 - 1 : a0 + 4;
+        const bool nx1 = u + 1 >= npairs, nx2 = u + 2 >= npairs;
+        const int so_w1 = (nx1 ? w_base_n + (u + 1 - npairs) * 128 : w_base + (u + 1) * 128);
+        const int so_a2 = (nx2 ? a_base_n + (u + 2 - npairs) * 128 : a_base + (u + 2) * 128);
+        const int so_w2 = (nx2 ? w_base_n + (u + 2 - npairs) * 128 : w_base + (u + 2) * 128);
+        // (reads and DMA pieces alternate in SOURCE order: the compiler must assume they alias, so it keeps that order)
+        // k-step 0: second half of W(u+1)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            frag(1, s_a, s_w, 1, g);
+            if (g & 1) piece(s_w1, so_w1, true, PU / 2 + (g >> 1));
+        }
+        mma(acc, 0);
+        pattern(true);
+        // k-step 1: first half of A(u+2) into the slot W(u-1) left at the last barrier
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            frag(0, s_a, s_w, 2, g);
+            if (g & 1) piece(s_a2, so_a2, false, g >> 1);
+        }
+        mma(acc, 1);
+        pattern(true);
+        // k-step 2: second half of A(u+2)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            frag(1, s_a, s_w, 3, g);
+            if (g & 1) piece(s_a2, so_a2, false, PU / 2 + (g >> 1));
+        }
+        mma(acc, 0);
+        pattern(true);
+        // k-step 3: every read of pair u is back and A(u+1), W(u+1) have landed everywhere -> first fragments of pair
+        // u+1; first half of W(u+2) into the slot A(u) vacated
+        line_wait_barrier<PU>();
+        mid();
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            frag(0, s_a1, s_w1, 0, g);
+            if (g & 1) piece(s_a, so_w2, true, g >> 1);
+        }
+        mma(acc, 1);
+        pattern(true);
+        a0 = s_a1;
+    };
     const int wu = __builtin_amdgcn_readfirstlane(wid);
     while (true) {
         const int tile_n = tile + (int)gridDim.x;
@@ -203,63 +260,7 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 1) void gemm_line_kernel(GemmP
             for (int j = 0; j < T; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        auto mma = [&](int set) {
-#pragma unroll
-            for (int i = 0; i < T; ++i)
-#pragma unroll
-                for (int j = 0; j < T; ++j)
-                    if (DBG == 2) {
-                        if (i == j) acc[i][j][0] += __builtin_bit_cast(float, fa[set][i][0] ^ fw[set][j][1]);
-                    } else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][i]),
-                                                                        __builtin_bit_cast(bf16x8, fw[set][j]), acc[i][j], 0, 0, 0);
-        };
-
-        for (int u = 0; u < np; ++u) {
-            // slots of A(u) W(u) A(u+1) W(u+1) A(u+2).  Pairs u+1, u+2 past the end of K are pairs 0, 1 of the next tile
-            // (selected arithmetically: the body stays ONE basic block and the vmcnt immediate a constant).
-            const int s_a = a0, s_w = a0 + 1 >= 5 ? a0 - 4 : a0 + 1, s_a1 = a0 + 2 >= 5 ? a0 - 3 : a0 + 2,
-                      s_w1 = a0 + 3 >= 5 ? a0 - 2 : a0 + 3, s_a2 = a0 + 4 >= 5 ? a0 - 1 : a0 + 4;
-            const bool nx2 = u + 2 >= np;
-            const int so_a2 = (nx2 ? a_base_n + (u + 2 - np) * 128 : a_base + (u + 2) * 128);
-            const int so_w2 = (nx2 ? w_base_n + (u + 2 - np) * 128 : w_base + (u + 2) * 128);
-            // (reads and DMA pieces alternate in SOURCE order: the compiler must assume they alias, so it keeps that order)
-            // k-step 0: fragments of k-step 2; first half of A(u+2) into the slot W(u-1) left at the last barrier
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                frag(2, s_a, s_w, 2, g);
-                if (g & 1) piece(s_a2, so_a2, false, g >> 1);
-            }
-            mma(0);
-            pattern(true);
-            // k-step 1: fragments of k-step 3; second half of A(u+2)
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                frag(3, s_a, s_w, 3, g);
-                if (g & 1) piece(s_a2, so_a2, false, PU / 2 + (g >> 1));
-            }
-            mma(1);
-            pattern(true);
-            // k-step 2: every read of pair u is back and A(u+1), W(u+1) have landed everywhere -> fragments of pair u+1,
-            // k-step 0; first half of W(u+2) into the slot A(u) vacated
-            line_wait_barrier<PU>();
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                frag(0, s_a1, s_w1, 0, g);
-                if (g & 1) piece(s_a, so_w2, true, g >> 1);
-            }
-            mma(2);
-            pattern(true);
-            // k-step 3: fragments of pair u+1, k-step 1; second half of W(u+2)
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                frag(1, s_a1, s_w1, 1, g);
-                if (g & 1) piece(s_a, so_w2, true, PU / 2 + (g >> 1));
-            }
-            mma(3);
-            pattern(true);
-            a0 = s_a1;
-        }
+        for (int u = 0; u < np; ++u) pair(u, np, acc, a_base_n, w_base_n, [] {});
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (MFMA results are read by the epilogue's VALU right away)
 
         bool done = false;
