@@ -78,7 +78,7 @@ def main():
                 lib.m3pc_debug_clock(buf)
                 if buf[1] > 0:
                     line += f" clk {100.0 * buf[0] / buf[1]:.0f}MHz wg {buf[1] / 100.0:.1f}us"
-            if 37 <= v <= 45:  # gemm_big.hip phase timers of one workgroup (100-MHz ticks)
+            if 37 <= v <= 42:  # gemm_big.hip phase timers of one workgroup (100-MHz ticks)
                 buf = (C.c_longlong * 4)()
                 lib.m3pc_debug_clock_big(buf)
                 line += f" [pro {buf[0] / 100.0:.1f} loop {buf[1] / 100.0:.1f} epi {buf[2] / 100.0:.1f}us clk {100.0 * buf[3] / max(buf[1], 1):.0f}MHz]"
