@@ -343,6 +343,120 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
     }
 }
 
+// Few sequences AND at most two key tiles (Lk <= 64: the batch-1 policy pass and the top-k re-score at T = 32): with the
+// keys split over waves only two of the four waves would work and each would run two 64-MFMA chains.  Here every wave
+// works in both phases and every chain is 32 MFMAs:
+//   S phase:  wave w takes key tile w & 1 and HALF of the head dimension (w >> 1): Q and K fragments straight from
+//             global memory in operand order (no LDS staging, no barrier before the first MFMA); the two partial S^T tiles
+//             of a key tile meet in LDS, waves 0 / 1 finish the softmax of their key tile (scale, max, exp, sum);
+//   PV phase: P^T (still in accumulator layout = the A operand of P V, one private 64-byte LDS slot per lane) and
+//             (max, sum) of both key tiles go through LDS to all four waves; wave w computes output dims 32 w .. +31
+//             over both key tiles, with P rescaled by exp(m_kt - m) beforehand, and stores its slice of O directly.
+// Two barriers, no O merge.  (fp32: v_mfma_f32_32x32x2_f32, every product an exact fp32 fma.)
+template <typename T, int HDT>
+__global__ __launch_bounds__(256) void attn_pair_kernel(AttnP p) {
+    static_assert(HDT == 4 || HDT == 2, "head dims 128 / 64");
+    constexpr int HD = HDT * 32, HH = HDT / 2;  // HH: 32-wide d tiles per half
+    __shared__ f32x16 lds_s[2][64];   // partial S^T of the upper d half, per key tile, one slot per lane
+    __shared__ f32x16 lds_p[2][64];   // exp(S - m_kt) per key tile, accumulator layout
+    __shared__ float lds_ml[2][32][2];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int kt = wid & 1, dh = wid >> 1;
+    const int b = blockIdx.x, head = blockIdx.y, q0 = blockIdx.z * 32;
+    const int Lk = p.L1 + p.L2;
+
+    const T* Qb = (const T*)p.Q + b * p.q_bstride + head * HD;
+    const T* K1 = (const T*)p.K1 + b * p.kv1_bstride + head * HD;
+    const T* V1 = (const T*)p.V1 + b * p.kv1_bstride + head * HD;
+    const T* K2 = p.K2 ? (const T*)p.K2 + head * HD : nullptr;
+    const T* V2 = p.V2 ? (const T*)p.V2 + head * HD : nullptr;
+
+    // S^T partial: keys of tile kt x queries, over d in [dh * HD/2, (dh + 1) * HD/2)
+    const int jq = q0 + l31, jk = kt * 32 + l31;
+    const T* qr = jq < p.Lq ? Qb + (long long)jq * p.ldq + dh * (HD / 2) : nullptr;
+    const T* kr = jk < p.L1 ? K1 + (long long)jk * p.ldkv1 + dh * (HD / 2)
+                            : (jk < Lk ? K2 + (long long)(jk - p.L1) * p.ldkv2 + dh * (HD / 2) : nullptr);
+    f32x4 qf[HH * 4], kf[HH * 4];
+#pragma unroll
+    for (int s = 0; s < HH * 4; ++s) {
+        qf[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        kf[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (qr) qf[s] = load4<T>(qr + 8 * s + 4 * lh);
+        if (kr) kf[s] = load4<T>(kr + 8 * s + 4 * lh);
+    }
+    // V values of this wave's output dims for both key tiles (issued now, used after the second barrier)
+    float vv[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int jr = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const T* vr = jr < p.L1 ? V1 + (long long)jr * p.ldkv1 : (jr < Lk ? V2 + (long long)(jr - p.L1) * p.ldkv2 : nullptr);
+            vv[t][e] = vr ? (float)vr[wid * 32 + l31] : 0.f;
+        }
+    f32x16 sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < HH * 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s][e], qf[s][e], sacc, 0, 0, 0);
+    if (dh == 1) lds_s[kt][lane] = sacc;
+    __syncthreads();
+    if (dh == 0) {
+        const f32x16 hi = lds_s[kt][lane];
+        float m = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int j = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const float v = (j < Lk) ? (sacc[e] + hi[e]) * p.scale : -INFINITY;
+            sacc[e] = v;
+            m = fmaxf(m, v);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = m == -INFINITY ? 0.f : expf(sacc[e] - m);
+            sacc[e] = v;
+            l += v;
+        }
+        l += __shfl_xor(l, 32);
+        lds_p[kt][lane] = sacc;
+        if (lh == 0) {
+            lds_ml[kt][l31][0] = m;
+            lds_ml[kt][l31][1] = l;
+        }
+    }
+    __syncthreads();
+    // O[:, 32 wid .. +31] = sum_kt exp(m_kt - m) P_kt V_kt / sum_kt exp(m_kt - m) l_kt   (query = l31 on the A side)
+    const float m0 = lds_ml[0][l31][0], l0 = lds_ml[0][l31][1], m1 = lds_ml[1][l31][0], l1 = lds_ml[1][l31][1];
+    const float mt = fmaxf(m0, m1);
+    const float f0 = m0 == -INFINITY ? 0.f : expf(m0 - mt), f1 = m1 == -INFINITY ? 0.f : expf(m1 - mt);
+    f32x16 oacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const f32x16 pt = lds_p[t][lane];
+        const float f = t == 0 ? f0 : f1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pt[e] * f, vv[t][e], oacc, 0, 0, 0);
+    }
+    // oacc[e] is (query (e & 3) + 8 (e >> 2) + 4 lh, dim 32 wid + l31): the sums of that QUERY live in lds_ml[.][query]
+    T* Ob = (T*)p.O + b * p.o_bstride + head * HD;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const float a0 = lds_ml[0][i][0], b0 = lds_ml[0][i][1], a1 = lds_ml[1][i][0], b1 = lds_ml[1][i][1];
+        const float am = fmaxf(a0, a1);
+        const float g0 = a0 == -INFINITY ? 0.f : expf(a0 - am), g1 = a1 == -INFINITY ? 0.f : expf(a1 - am);
+        const float lt = fmaf(b1, g1, b0 * g0);
+        if (q0 + i < p.Lq) Ob[(long long)(q0 + i) * p.ldo + wid * 32 + l31] = (T)(oacc[e] / lt);
+    }
+}
+
 template <typename T, int HDT>
 static void launch_split(const AttnP& p, hipStream_t st) {
     constexpr int ROWF = HDT * 32 + 4;
@@ -372,6 +486,14 @@ static void launch_hd(const AttnP& p, hipStream_t st) {
     const int qgroups = (p.Lq + 127) / 128;
     static const bool no_split = getenv("M3PC_NO_ATTN_SPLIT") != nullptr;  // A/B switch
     if (Lk <= 256 && (long long)p.batch * p.n_head * qgroups <= 64 && !no_split) {
+        static const bool no_pair = getenv("M3PC_NO_ATTN_PAIR") != nullptr;  // A/B switch
+        if constexpr (HDT == 4) {  // (each wave owns one 32-wide slice of the output: four waves = head dim 128)
+            if (Lk <= 64 && !no_pair) {
+                dim3 grid(p.batch, p.n_head, (p.Lq + 31) / 32), block(256);
+                hipLaunchKernelGGL((attn_pair_kernel<T, HDT>), grid, block, 0, st, p);
+                return;
+            }
+        }
         launch_split<T, HDT>(p, st);  // few sequences: split the keys over the waves instead
         return;
     }
