@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256, 1) void gemm_big_kernel(GemmP p) {
         w_vo[i] = (col0 + r) * ldw_b + q * 16;
     }
     const int wave_dst = __builtin_amdgcn_readfirstlane(wid) * 1024;
+    (void)a_rs, (void)w_rs, (void)wave_dst;  // (only the device pass uses them: the DMA builtin is hidden from the host pass)
     // one DMA piece: i < 4 -> A piece i of this wave, i >= 4 -> W piece i - 4.  src_st is the (clamped) stage index the
     // bytes come from, st the stage whose slot they land in (they differ only past the end of K, see the loop)
     auto piece = [&](int st, int src_st, int i) {

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 1) void gemm_line_kernel(GemmP
         }
     };
     const int wave_dst = __builtin_amdgcn_readfirstlane(wid) * 1024;
+    (void)a_rs, (void)w_rs, (void)wave_dst;  // (only the device pass uses them: the DMA builtin is hidden from the host pass)
     // piece i of the A (w = false) or W (w = true) rows at scalar byte offset `so` (tile + pair) into ring slot `slot`
     auto piece = [&](int slot, int so, bool w, int i) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc does not know this builtin)
