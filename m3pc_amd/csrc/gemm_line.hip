@@ -72,9 +72,10 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 1) void gemm_line_kernel(GemmP
     };
     // DMA pieces: piece I = wid + 4 i (i < PU) of a unit = its rows 8 I .. 8 I + 7, 8 lanes per 128-byte row.  The
     // per-lane source offsets are relative to the tile, the tile itself is a scalar byte offset (buffer soffset) -- so
-    // moving on to the next tile costs no registers.  That needs every tile to look alike: no A row map, no ragged last
-    // tile; otherwise (`uniform` false) the launcher starts one workgroup per tile and the offsets are absolute.
-    const bool uniform = p.amap.rpg == 0 && p.M % BT == 0;
+    // moving on to the next tile costs no registers.  That needs every tile to look alike: no A row map (a ragged
+    // last tile is fine: its rows past M lie outside the buffer resource, read as zeros and are never stored); otherwise
+    // (`uniform` false) the launcher starts one workgroup per tile and the offsets are absolute.
+    const bool uniform = p.amap.rpg == 0;
     int a_vo[PU], w_vo[PU];
     auto piece_offsets = [&](int r0, int c0) {
 #pragma unroll
@@ -311,7 +312,7 @@ static bool launch_line(const GemmP& p, hipStream_t st) {
     const bool f32out = p.Cf != nullptr;
     const int epi = (p.gelu ? GE_GELU : 0) | (p.res ? GE_RES : 0) | (f32out ? GE_F32OUT : 0);
     const int tiles = ((p.M + BT - 1) / BT) * (p.N / BT), slots = (BT == 128 ? 2 : 1) * 256;  // resident workgroups on 256 CUs
-    const bool uniform = p.amap.rpg == 0 && p.M % BT == 0;  // (see the kernel: persistent workgroups need look-alike tiles)
+    const bool uniform = p.amap.rpg == 0;  // (see the kernel: persistent workgroups need look-alike tiles)
     const dim3 grid(uniform && tiles > slots ? slots : tiles), block(256);
     switch (epi) {
         case 0:
