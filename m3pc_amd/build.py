@@ -10,8 +10,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libm3pc_hip.so")
-SOURCES = ["gemm.hip", "gemm_glds.hip", "gemm_ring.hip", "gemm_persist.hip", "gemm_rs.hip", "gemm_big.hip", "gemm_line.hip", "gemm_f32_direct.hip", "attn.hip", "attn_bf16.hip", "elementwise.hip", "select.hip", "m3pc.hip"]
+SOURCES = ["gemm.hip", "gemm_glds.hip", "gemm_ring.hip", "gemm_persist.hip", "gemm_rs.hip", "gemm_big.hip", "gemm_line.hip", "gemm_f32_direct.hip", "block_fused.hip", "attn.hip", "attn_bf16.hip", "elementwise.hip", "select.hip", "m3pc.hip"]
 ARCH = "gfx950"
+# per-file flags.  block_fused.hip: its gelu runs beside MFMAs, where packed fp32 VALU instructions cost more issue time
+# than the two scalar ones they replace (MI355X_MICROARCH.md, cycle constants) -- keep the SLP vectorizer off there.
+EXTRA_FLAGS = {"block_fused.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -42,7 +45,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc, *flags, "-c", src, "-o", obj])
+            jobs.append([hipcc, *flags, *EXTRA_FLAGS.get(s, []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -1,0 +1,525 @@
+// The tail of one pre-LN transformer layer (mtm_model.py:379-409, the nn.TransformerEncoderLayer halves after the
+// attention itself) as ONE launch on bf16 operands:
+//
+//     X' = res + bo + O Wo^T              out-proj + residual
+//     a  = LayerNorm2(X')                 (bf16)
+//     H  = gelu(a W1^T + b1)              (bf16, never leaves the registers)
+//     X''= X' + b2 + H W2^T               FFN2 + residual
+//     Hout = bf16(LN_B?(LN_A(X'')))       the LayerNorm(s) that consume the block output
+//
+// d = 512, ff = 2048.  A workgroup owns 128 token rows, each of its four waves (one per SIMD, the whole 512-entry
+// register file) a strip of 32 of them -- through the whole chain, so nothing but O, the residual rows and the
+// outputs touches HBM and no activation ever crosses a wave.  Every product is computed TRANSPOSED,
+//     D^T[feature][token] += W[feature][k] * act^T[k][token]
+// i.e. the weights are the MFMA A operand (32 output features x 16 k per v_mfma_f32_32x32x16_bf16) and the
+// activations the B operand.  An accumulator then holds  lane = token, registers = features:
+//   * a finished accumulator tile, rounded pairwise to bf16, IS the B operand of the next product (registers
+//     8s..8s+7 are the fragment of k-step s, cdna_hip_programming.md section 3) -- the hidden chunk goes from FFN1 to
+//     FFN2 and the LayerNorm-2 rows go into FFN1 without a lane ever exchanging data;
+//   * LayerNorm statistics are sums over a lane's own registers plus one exchange with lane ^ 32;
+//   * X' simply stays in the 256 accumulator registers while FFN2 adds to it.
+// Register order of such a fragment permutes k inside each group of 16 (element j of lane half h is feature
+// 16 s + 8 (j >> 2) + 4 h + (j & 3)); the weights are packed with the same permutation, so the dot products are complete.
+//
+// Weights: the A fragments of the whole chain, 1 KiB each (64 lanes x 16 B, exactly the register image), are packed
+// ONCE per weight load in the order the kernel consumes them (pack_block_stream): 4608 fragments = 4.5 MiB per layer.
+// The kernel is then a linear stream: LDS-DMA pieces of 1 KiB (whole cache lines, contiguous source, contiguous
+// destination, one scalar offset), a ring of four 16-KiB stages (16 fragments = 16 MFMAs per wave), one
+// ds_read_b128 per MFMA at lane * 16 + immediate -- conflict-free by construction, no swizzle, no address arithmetic.
+// Per byte of L2->LDS traffic a 128-row tile does 128 FLOP (a 128x128 GEMM tile that also streams its A operand: 64).
+//
+// Phase order (144 phases of 32 MFMAs = two ring stages per tile):
+//   out-proj, phase sb = 0..15:  k-steps 2 sb, 2 sb + 1 of all 16 feature tiles; the two O fragments of a phase are
+//            loaded from global memory one phase ahead (the attention output is read exactly once)
+//   FFN, chunk c = 0..31 of 64 hidden units:  A0 A1 B1 B2
+//            A0 / A1: hidden tile 64c..+31 / 64c+32..+63 over the 32 k-steps of the model width (FFN1)
+//            B1 / B2: hidden k-steps 0,1 / 2,3 of the chunk into all 16 feature tiles (FFN2)
+//            gelu of hidden tile 0 runs on the VALU beside the MFMAs of A1, that of tile 1 beside B1.
+// Registers: 256 accumulators + the 32 LayerNorm-2 fragments (128) + hidden tiles, their bf16 fragments and the
+// fragment window do not fit 512 with room for the compiler, so the fragments of k-steps 16..31 live in LDS (16 KiB per
+// wave, private to it) and are read like the weights, two per group of four MFMAs.
+// Sync: ONE s_waitcnt vmcnt(8) lgkmcnt(0) + s_barrier per ring stage, placed four MFMAs before the stage ends: every
+// wave has read all of stage t (slot t % 4 is free: stage t+4's pieces go there) and stage t+1 has landed everywhere
+// (its first fragments are read under the last MFMAs of stage t).  Stages t+2 and t+3 stay in flight across the barrier.
+// Fragments are read four at a time, one group (four MFMAs) ahead: one lgkmcnt wait per four MFMAs.
+// With one wave per SIMD the kernel is bound by what that wave has to ISSUE besides its MFMAs (an MFMA leaves room for
+// about five other instructions); the layout above is what keeps that count down.
+#include <type_traits>
+
+#include "gemm_epilogue.h"
+#include "kernels.h"
+
+namespace m3pc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef void __attribute__((address_space(3))) * lptr_t;
+
+namespace {
+constexpr int BD = 512, BFF = 2048;              // model width / FFN width this kernel is built for
+constexpr int NT = BD / 32;                      // 16 feature tiles of 32
+constexpr int KS = BD / 16;                      // 32 k-steps over the model width
+constexpr int NCH = BFF / 64;                    // 32 hidden chunks of 64
+constexpr int FR_OUT = NT * KS;                  // 512 out-proj fragments
+constexpr int FR_TOTAL = FR_OUT + NCH * 128;     // 4608
+constexpr int RS_FR = 16, RS_B = RS_FR * 1024, NRS = FR_TOTAL / RS_FR;  // 288 ring stages of 16 KiB
+constexpr int ACT_OFF = 4 * RS_B;                // LayerNorm-2 fragments of k-steps 16..31: 16 KiB per wave
+// parameter tables (floats) behind them
+constexpr int T_B1 = 0, T_B2 = T_B1 + BFF, T_G2 = T_B2 + BD, T_BE2 = T_G2 + BD, T_GA = T_BE2 + BD, T_BA = T_GA + BD,
+              T_GB = T_BA + BD, T_BB = T_GB + 2 * BD, T_END = T_BB + 2 * BD;
+constexpr int TAB_OFF = ACT_OFF + 4 * 16 * 1024;
+constexpr int LDS_BYTES = TAB_OFF + T_END * 4;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+// k-step of the i-th MFMA of an FFN1 phase: per group of four, two k-steps from registers (0..15), two from LDS (16..31)
+__host__ __device__ constexpr int a_kstep(int i) { return (i % 4 < 2) ? 2 * (i / 4) + i % 4 : 16 + 2 * (i / 4) + (i % 4 - 2); }
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ weight stream
+// element j of lane (r = lane & 31, h = lane >> 5) of fragment f
+__global__ __launch_bounds__(256) void pack_block_stream_kernel(const bf16_t* __restrict__ Wo, const bf16_t* __restrict__ W1,
+                                                                const bf16_t* __restrict__ W2, bf16_t* __restrict__ out) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;  // one thread per 16-byte piece
+    if (gid >= FR_TOTAL * 64) return;
+    const int f = gid >> 6, lane = gid & 63, r = lane & 31, h = lane >> 5;
+    bf16_t v[8];
+    if (f < FR_OUT) {  // phase sb: (kk, jn) -> k-step 2 sb + kk of feature tile jn, natural k order
+        const int sb = f / 32, kk = (f % 32) / 16, jn = f % 16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = Wo[(size_t)(32 * jn + r) * BD + 16 * (2 * sb + kk) + 8 * h + j];
+    } else {
+        const int g = f - FR_OUT, c = g / 128, w = g % 128;
+        if (w < 64) {  // A0 | A1: hidden tile t, MFMA i (permuted k order: the operand is a LayerNorm-2 accumulator)
+            const int t = w / KS, s = a_kstep(w % KS);
+            const size_t row = (size_t)(64 * c + 32 * t + r) * BD;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = W1[row + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
+        } else {       // B1 | B2: hidden k-step s2 of the chunk, feature tile jn
+            const int s2 = (w - 64) / 16, jn = (w - 64) % 16;
+            const size_t row = (size_t)(32 * jn + r) * BFF + 64 * c + 16 * s2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = W2[row + 8 * (j >> 2) + 4 * h + (j & 3)];
+        }
+    }
+    bf16_t* o = out + (size_t)gid * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = v[j];
+}
+
+size_t block_stream_bytes() { return (size_t)FR_TOTAL * 1024; }
+bool block_fused_supported(int d, int ff) { return d == BD && ff == BFF; }
+
+void launch_pack_block_stream(const bf16_t* Wo, const bf16_t* W1, const bf16_t* W2, bf16_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(pack_block_stream_kernel, dim3(FR_TOTAL * 64 / 256), dim3(256), 0, st, Wo, W1, W2, out);
+}
+
+// ------------------------------------------------------------------------------------------------ the kernel
+namespace {
+
+__device__ __forceinline__ float half_swap_sum(float v) { return v + __shfl_xor(v, 32); }
+
+// Every MFMA is an asm statement with fixed register classes: the 256 feature accumulators ARE the accumulator half
+// of the register file ("a"), the hidden tiles (read by the gelu on the VALU) live in the architectural half ("v").
+// Left to the builtin, hipcc picks one form for all MFMAs of the function and then rotates 16-register accumulator
+// tiles through v_accvgpr copies and scratch around the loops -- differently after every edit.  What the compiler
+// does not know about an asm MFMA (cdna_hip_programming.md 5.7): the wait states between its result and a VALU /
+// accvgpr reader (mfma_done below), and between a VALU-written operand and the MFMA (the hidden fragments are
+// packed at least one MFMA slot before their first use).
+__device__ __forceinline__ void mfma_a(f32x16& c, u32x4 a, u32x4 b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_v(f32x16& c, u32x4 a, u32x4 b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// after the last MFMA into c, before anything but an MFMA reads it (8-pass MFMA: 12 wait states; 18 given)
+__device__ __forceinline__ void mfma_done_v(f32x16& c) { asm volatile("s_nop 15\n\ts_nop 1" : "+v"(c)); }
+__device__ __forceinline__ void mfma_done_a(f32x16 (&c)[16]) {
+    asm volatile("s_nop 15\n\ts_nop 1"
+                 : "+a"(c[0]), "+a"(c[1]), "+a"(c[2]), "+a"(c[3]), "+a"(c[4]), "+a"(c[5]), "+a"(c[6]), "+a"(c[7]), "+a"(c[8]), "+a"(c[9]),
+                   "+a"(c[10]), "+a"(c[11]), "+a"(c[12]), "+a"(c[13]), "+a"(c[14]), "+a"(c[15]));
+}
+
+// DBG (timing experiments): 1 = no DMA pieces, 2 = no gelu, 3 = clocks per FFN phase kind into p.stamps[8..11],
+// 4 = VALU slice in a region of its own behind its MFMA, 5 = gelu of every second value only, 6 = no s_barrier in the
+// per-stage sync, 7 = weight fragments read once (no LDS reads in the loops).  2, 5, 6, 7 compute wrong results.  p.stamps: phase stamps (shader clocks) of one workgroup
+template <int DBG>
+__global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int row0 = blockIdx.x * 128;
+    const int rtok = row0 + 32 * wu + l31;          // this lane's token row
+    const bool valid = rtok < p.M;
+    const int rld = valid ? rtok : p.M - 1;         // (loads of the padding rows read the last row)
+    const int lane16 = lane * 16;
+    long long stamps[7];  // (scalar registers; stored at the very end, and only when p.stamps is set)
+    long long psum[4] = {0, 0, 0, 0}, pt = 0;  // clocks spent in the four FFN phase kinds (A0, A1, B1, B2)
+    (void)pt;
+    stamps[0] = __builtin_readcyclecounter();
+
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream, 0, (unsigned)(FR_TOTAL * 1024), 0x00020000);
+    (void)w_rs;
+    // piece pc (0..3) of ring stage st: fragment wu + 4 pc of that stage -> the same position of ring slot st % 4
+    auto piece = [&](int st, int pc) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc does not know this builtin)
+        if (DBG == 1) return;
+        const int sw = st >= NRS ? st - NRS : st;  // past the end: the head of the stream again (never read)
+        const int fo = (wu + 4 * pc) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lptr_t)(smem + (st & 3) * RS_B + fo), 16, lane16, sw * RS_B + fo, 0, 0);
+#endif
+    };
+    const char* const lbase = smem + lane16;  // (every ring offset fits the 16-bit immediate of ds_read)
+    auto frag = [&](int slot, int f) -> u32x4 { return *(const u32x4*)(lbase + slot * RS_B + f * 1024); };
+    // LayerNorm-2 fragment of k-step 16 + m of this wave
+    char* const abase = smem + ACT_OFF + wu * 16 * 1024 + lane16;
+    auto afrag = [&](int m) -> u32x4 { return *(const u32x4*)(abase + m * 1024); };
+    float* const tab = (float*)(smem + TAB_OFF);
+
+    // ---- prologue: first stages in flight, parameter tables, accumulators = residual + out-proj bias
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) piece(s, pc);
+    piece(3, 0);
+    {
+        for (int i = tid; i < BFF / 4; i += 256) *(f32x4*)(tab + T_B1 + 4 * i) = *(const f32x4*)(p.b1 + 4 * i);
+        if (tid < BD / 4) {
+            const int i = 4 * tid;
+            *(f32x4*)(tab + T_B2 + i) = *(const f32x4*)(p.b2 + i);
+            *(f32x4*)(tab + T_G2 + i) = *(const f32x4*)(p.ln2_g + i);
+            *(f32x4*)(tab + T_BE2 + i) = *(const f32x4*)(p.ln2_b + i);
+            if (p.Hout) {
+                *(f32x4*)(tab + T_GA + i) = *(const f32x4*)(p.lnA_g + i);
+                *(f32x4*)(tab + T_BA + i) = *(const f32x4*)(p.lnA_b + i);
+            }
+            if (p.Hout && p.lnB_g[0]) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    *(f32x4*)(tab + T_GB + k * BD + i) = *(const f32x4*)(p.lnB_g[k] + i);
+                    *(f32x4*)(tab + T_BB + k * BD + i) = *(const f32x4*)(p.lnB_b[k] + i);
+                }
+            }
+        }
+    }
+    f32x16 acc[NT];
+    {
+        const float* rrow = p.rowtab ? p.rowtab + (size_t)(rld % p.rt_mod) * BD : p.res + (size_t)rld * p.ldr;
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = 32 * jn + 8 * q + 4 * lh;
+                const f32x4 x = *(const f32x4*)(rrow + n);
+                const f32x4 b = *(const f32x4*)(p.bo + n);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[jn][4 * q + i] = x[i] + b[i];
+                if (q == 3 && jn % 4 == 3) __builtin_amdgcn_sched_barrier(0);  // (at most four tiles of loads in registers)
+            }
+    }
+    u32x4 ofr[KS];  // O fragments (B operand of the out-proj): dead after it, the LayerNorm-2 fragments take their place
+    {
+        const bf16_t* const orow = p.O + (size_t)rld * p.ldo + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) ofr[s] = *(const u32x4*)(orow + 16 * s);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    stamps[1] = __builtin_readcyclecounter();
+
+    u32x4 R[2][4];   // weight fragment groups: group g of a ring stage lives in R[g & 1]
+    u32x4 R2[2][2];  // the two LDS-resident LayerNorm-2 fragments of an FFN1 group, same parity
+#pragma unroll
+    for (int k = 0; k < 4; ++k) R[0][k] = frag(0, k);
+
+    // one phase = two ring stages = 8 groups of {reads of the next group, one DMA piece, 4 x (MFMA, VALU slice)}
+    //   ph: phase index (runtime); SL: ring slot of its first stage (0 or 2, static)
+    //   extra(gn): further LDS reads for group gn of this phase (gn = 8: group 0 of the next phase)
+    //   mma(i, a, g): MFMA i (0..31) with weight fragment a, group g;  valu(g, k): VALU work beside MFMA k of group g
+    // Every MFMA slot is its own scheduling region, so the VALU slices stay between the MFMAs they are written beside.
+    auto phase = [&](int ph, auto sl_c, auto&& extra, auto&& mma, auto&& valu) {
+        constexpr int SL = decltype(sl_c)::value;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int rs = 2 * ph + g / 4;          // ring stage
+            const int gl = g % 4;                   // group within it
+            const int slot = (SL + g / 4) & 3;
+            if (gl == 3) {  // every read of this ring stage is issued: sync, then on into the next stage's slot
+                if (DBG == 6) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            if (DBG != 7) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) R[(g + 1) & 1][k] = gl < 3 ? frag(slot, 4 * (gl + 1) + k) : frag((slot + 1) & 3, k);
+            }
+            extra(g + 1);
+            // 4 DMA pieces per ring stage: pieces 1..3 of stage rs+3 before the sync, piece 0 of stage rs+4 after it
+            if (gl < 3) piece(rs + 3, 1 + gl);
+            else piece(rs + 4, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mma(4 * g + k, R[DBG == 7 ? 0 : g & 1][k], g);
+                if (DBG == 4) __builtin_amdgcn_sched_barrier(0);
+                valu(g, k);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto no_valu = [](int, int) {};
+    auto no_extra = [](int) {};
+    using S0 = std::integral_constant<int, 0>;
+    using S2 = std::integral_constant<int, 2>;
+
+    // ---- out-proj: phase sb = k-steps 2 sb, 2 sb + 1 of all 16 feature tiles (straight-line: the O fragment index is static)
+#define OUTPROJ2(sb)                                                                                                   \
+    phase(sb, S0{}, no_extra, [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], a, ofr[2 * (sb) + i / 16]); }, no_valu);      \
+    phase(sb + 1, S2{}, no_extra, [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], a, ofr[2 * (sb) + 2 + i / 16]); }, no_valu);
+    OUTPROJ2(0) OUTPROJ2(2) OUTPROJ2(4) OUTPROJ2(6) OUTPROJ2(8) OUTPROJ2(10) OUTPROJ2(12) OUTPROJ2(14)
+#undef OUTPROJ2
+    mfma_done_a(acc);  // (the accumulators are next read by v_accvgpr_read)
+    stamps[2] = __builtin_readcyclecounter();
+
+    // ---- LayerNorm-2 of X' (in the accumulators) -> act (bf16 B-operand fragments of FFN1)
+    u32x4 act[16];  // k-steps 0..15; k-steps 16..31 go to this wave's LDS region
+    {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float x = acc[jn][e];
+                s1 += x;
+                s2 = fmaf(x, x, s2);
+                if (e == 15) __builtin_amdgcn_sched_barrier(0);  // (keeps the accumulator reads of one tile together)
+            }
+        s1 = half_swap_sum(s1);
+        s2 = half_swap_sum(s2);
+        const float mean = s1 * (1.0f / BD);
+        const float rstd = rsqrtf(fmaxf(s2 * (1.0f / BD) - mean * mean, 0.f) + 1e-5f);
+        const float nmr = -mean * rstd;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int jn = s >> 1;
+            float y[8];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int q = 2 * (s & 1) + k, n = 32 * jn + 8 * q + 4 * lh;
+                const f32x4 g = *(const f32x4*)(tab + T_G2 + n);
+                const f32x4 b = *(const f32x4*)(tab + T_BE2 + n);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[4 * k + i] = fmaf(fmaf(acc[jn][4 * q + i], rstd, nmr), g[i], b[i]);
+            }
+            bf16x8 w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = (bf16_t)y[j];
+            if (s < 16) act[s] = __builtin_bit_cast(u32x4, w);
+            else *(u32x4*)(abase + (s - 16) * 1024) = __builtin_bit_cast(u32x4, w);
+        }
+    }
+    stamps[3] = __builtin_readcyclecounter();
+
+    // ---- FFN
+    f32x16 h0, h1;   // hidden accumulators of the chunk
+    u32x4 hb[4];     // its four bf16 k-step fragments (B operand of FFN2)
+    auto bias_init = [&](f32x16& hh, int c, int t) {  // hidden accumulator := linear1 bias of its 32 units
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *(const f32x4*)(tab + T_B1 + 64 * c + 32 * t + 8 * q + 4 * lh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hh[4 * q + i] = b[i];
+        }
+    };
+    // gelu (exact-erf form of gemm_epilogue.h: ge_gelu, same arithmetic) of registers e, e + 1 (e even) of hidden tile t:
+    // both values advance by a quarter per MFMA slot of the group, so that neighbouring VALU instructions belong to
+    // different dependency chains (a chain of dependent fmas issues every ~6.6 clocks, independent ones every 4);
+    // the last quarter packs the pair into fragment 2 t + (e >> 3) of hb
+    float gx[2], gt[2], ge[2], gp[2];
+    auto gelu_slice = [&](const f32x16& hh, int t, int e, int k) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (k == 0) {         // t = 1 / (1 + p |x| / sqrt 2)
+                const float x = hh[e + j];
+                gx[j] = x;
+                const float ax = fabsf(x) * 0.70710678118654752440f;
+                gt[j] = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+            } else if (k == 1) {  // e = exp(-x^2 / 2)
+                const float ax = fabsf(gx[j]) * 0.70710678118654752440f;
+                ge[j] = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
+                gx[j] = 0.5f * gx[j];
+            } else if (k == 2) {  // the polynomial in t
+                const float tt = gt[j];
+                float pp = fmaf(tt, 1.061405429f, -1.453152027f);
+                pp = fmaf(tt, pp, 1.421413741f);
+                pp = fmaf(tt, pp, -0.284496736f);
+                gp[j] = fmaf(tt, pp, 0.254829592f);
+            } else {              // 0.5 x (1 + erf)
+                const float erf_abs = fmaf(-(gp[j] * gt[j]), ge[j], 1.0f);
+                gx[j] = DBG == 2 ? gx[j] : fmaf(fabsf(gx[j]), erf_abs, gx[j]);
+            }
+        }
+        if (k == 3) {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            bf16x2 w;
+            w[0] = (bf16_t)gx[0];
+            w[1] = (bf16_t)gx[1];
+            hb[2 * t + (e >> 3)][(e & 7) >> 1] = __builtin_bit_cast(unsigned, w);
+        }
+    };
+    // B operand of MFMA i of an FFN1 phase (group g = i / 4): registers for the first two of a group, LDS for the others
+    auto a_operand = [&](int i, int g) -> u32x4 { return i % 4 < 2 ? act[a_kstep(i)] : R2[g & 1][i % 4 - 2]; };
+    auto act_reads = [&](int gn) {  // LDS-resident fragments of group gn (8 = group 0 of the next FFN1 phase)
+        const int g = gn & 7;
+        R2[gn & 1][0] = afrag(2 * g);
+        R2[gn & 1][1] = afrag(2 * g + 1);
+    };
+    bias_init(h0, 0, 0);
+    bias_init(h1, 0, 1);
+    act_reads(0);
+    for (int c = 0; c < NCH; ++c) {
+        const int ph = 16 + 4 * c;
+        const int cn = c + 1 < NCH ? c + 1 : c;
+        if (DBG == 3) pt = __builtin_readcyclecounter();
+        // A0: hidden tile 0
+        phase(ph, S0{}, act_reads, [&](int i, u32x4 a, int g) { mfma_v(h0, a, a_operand(i, g)); }, no_valu);
+        mfma_done_v(h0);
+        if (DBG == 3) { const long long t = __builtin_readcyclecounter(); psum[0] += t - pt; pt = t; }
+        // A1: hidden tile 1; gelu of tile 0 (two values per group)
+        phase(ph + 1, S2{}, [&](int gn) { if (gn < 8) act_reads(gn); },
+              [&](int i, u32x4 a, int g) { mfma_v(h1, a, a_operand(i, g)); },
+              [&](int g, int k) { if (DBG != 5 || g % 2 == 0) gelu_slice(h0, 0, 2 * g, k); });
+        mfma_done_v(h1);
+        if (DBG == 3) { const long long t = __builtin_readcyclecounter(); psum[1] += t - pt; pt = t; }
+        // B1: hidden k-steps 0, 1 into the 16 feature tiles; gelu of tile 1
+        phase(ph + 2, S0{}, no_extra, [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], a, hb[i / 16]); },
+              [&](int g, int k) { if (DBG != 5 || g % 2 == 0) gelu_slice(h1, 1, 2 * g, k); });
+        if (DBG == 3) { const long long t = __builtin_readcyclecounter(); psum[2] += t - pt; pt = t; }
+        // B2: hidden k-steps 2, 3; the next chunk's linear1 bias goes into the (now free) hidden accumulators
+        phase(ph + 3, S2{}, [&](int gn) { if (gn == 8) act_reads(8); },
+              [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], a, hb[2 + i / 16]); },
+              [&](int g, int k) {
+                  if (g == 1 && k == 0) bias_init(h0, cn, 0);
+                  if (g == 4 && k == 0) bias_init(h1, cn, 1);
+              });
+        if (DBG == 3) psum[3] += __builtin_readcyclecounter() - pt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the pieces issued past the end of the stream
+    mfma_done_a(acc);
+    stamps[4] = __builtin_readcyclecounter();
+
+    // ---- epilogue: X'' = acc + b2 (fp32, optional) and the LayerNorm(s) of it (bf16)
+#pragma unroll
+    for (int jn = 0; jn < NT; ++jn) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *(const f32x4*)(tab + T_B2 + 32 * jn + 8 * q + 4 * lh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[jn][4 * q + i] += b[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (p.Xout && valid) {
+        float* xrow = p.Xout + (size_t)rtok * p.ldx;
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 x;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = acc[jn][4 * q + i];
+                *(f32x4*)(xrow + 32 * jn + 8 * q + 4 * lh) = x;
+                if (q == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+    stamps[5] = __builtin_readcyclecounter();
+    if (p.Hout) {
+        int orow_h = rtok, sel = 0;
+        if (p.out_mod > 0) {  // two row groups per out_mod rows: group s rows go to the s-th compact block, LN_B[s] applies
+            const int w = rtok % p.out_mod;
+            sel = w / p.out_grp;
+            orow_h = sel * (p.M / p.out_mod) * p.out_grp + (rtok / p.out_mod) * p.out_grp + w % p.out_grp;
+        }
+        auto row_stats = [&](float& rstd, float& nmr) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float x = acc[jn][e];
+                    s1 += x;
+                    s2 = fmaf(x, x, s2);
+                    if (e == 15) __builtin_amdgcn_sched_barrier(0);
+                }
+            s1 = half_swap_sum(s1);
+            s2 = half_swap_sum(s2);
+            const float mean = s1 * (1.0f / BD);
+            rstd = rsqrtf(fmaxf(s2 * (1.0f / BD) - mean * mean, 0.f) + 1e-5f);
+            nmr = -mean * rstd;
+        };
+        float rstd, nmr;
+        row_stats(rstd, nmr);
+        const bool two = p.lnB_g[0] != nullptr;
+        if (two) {  // acc := LN_A(acc), then statistics of that
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = 32 * jn + 8 * q + 4 * lh;
+                    const f32x4 g = *(const f32x4*)(tab + T_GA + n);
+                    const f32x4 b = *(const f32x4*)(tab + T_BA + n);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[jn][4 * q + i] = fmaf(fmaf(acc[jn][4 * q + i], rstd, nmr), g[i], b[i]);
+                    if (q == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            row_stats(rstd, nmr);
+        }
+        const float* const gtab = two ? tab + T_GB + sel * BD : tab + T_GA;
+        const float* const btab = two ? tab + T_BB + sel * BD : tab + T_BA;
+        bf16_t* hrow = p.Hout + (size_t)(valid ? orow_h : 0) * p.ldh;
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = 32 * jn + 8 * q + 4 * lh;
+                const f32x4 g = *(const f32x4*)(gtab + n);
+                const f32x4 b = *(const f32x4*)(btab + n);
+                bf16x4 w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = (bf16_t)fmaf(fmaf(acc[jn][4 * q + i], rstd, nmr), g[i], b[i]);
+                if (valid) *(bf16x4*)(hrow + n) = w;
+                if (q == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+    stamps[6] = __builtin_readcyclecounter();
+    if (p.stamps && (int)blockIdx.x == p.stamp_block && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) p.stamps[wu * 16 + k] = stamps[k];
+        if (DBG == 3)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p.stamps[wu * 16 + 8 + k] = psum[k];
+    }
+}
+
+}  // namespace
+
+bool launch_block_fused(const BlockP& p, hipStream_t st) {
+    if (p.M <= 0) return true;
+    if (((uintptr_t)p.O & 15) || (p.ldo % 8) || ((uintptr_t)p.wstream & 1023)) return false;
+    if (!p.rowtab && (((uintptr_t)p.res & 15) || (p.ldr % 4))) return false;
+    if (p.Xout && (((uintptr_t)p.Xout & 15) || (p.ldx % 4))) return false;
+    if (p.Hout && (((uintptr_t)p.Hout & 7) || (p.ldh % 4))) return false;
+    if (p.out_mod > 0 && (p.M % p.out_mod != 0 || p.out_mod != 2 * p.out_grp)) return false;
+    const dim3 grid((p.M + 127) / 128), block(256);
+    if (p.variant == 1) hipLaunchKernelGGL(block_fused_kernel<1>, grid, block, 0, st, p);
+    else if (p.variant == 2) hipLaunchKernelGGL(block_fused_kernel<2>, grid, block, 0, st, p);
+    else if (p.variant == 3) hipLaunchKernelGGL(block_fused_kernel<3>, grid, block, 0, st, p);
+    else if (p.variant == 4) hipLaunchKernelGGL(block_fused_kernel<4>, grid, block, 0, st, p);
+    else if (p.variant == 5) hipLaunchKernelGGL(block_fused_kernel<5>, grid, block, 0, st, p);
+    else if (p.variant == 6) hipLaunchKernelGGL(block_fused_kernel<6>, grid, block, 0, st, p);
+    else if (p.variant == 7) hipLaunchKernelGGL(block_fused_kernel<7>, grid, block, 0, st, p);
+    else hipLaunchKernelGGL(block_fused_kernel<0>, grid, block, 0, st, p);
+    return true;
+}
+
+}  // namespace m3pc

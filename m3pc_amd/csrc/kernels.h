@@ -63,6 +63,42 @@ void read_big_probe(long long out[4]);                   // debug: gemm_big.hip 
 void read_clock_probe(long long out[2]);                // debug: {shader clocks, 100-MHz ticks} of one ring workgroup
 bool launch_gemm_f32_direct(const GemmP& p, hipStream_t st);  // fp32, few rows: in-workgroup K split (gemm_f32_direct.hip)
 
+// The tail of one pre-LN transformer layer after its attention, as one launch (block_fused.hip; d = 512, ff = 2048,
+// bf16 operands):  X' = res + bo + O Wo^T;  X'' = X' + b2 + gelu(LN2(X') W1^T + b1) W2^T;
+// Xout = X'' (fp32, optional);  Hout = bf16(LN_B[sel]?(LN_A(X''))).
+struct BlockP {
+    const bf16_t* O;        // (M, d) attention output rows
+    int ldo;
+    int M;
+    const float* res;       // (M, d) residual rows (fp32), or
+    int ldr;
+    const float* rowtab;    // (rt_mod, d): row r takes rowtab[r % rt_mod] as its residual (res unused)
+    int rt_mod;
+    const bf16_t* wstream;  // packed weight fragments of the layer (launch_pack_block_stream)
+    const float* bo;        // out_proj.bias (d)
+    const float* b1;        // linear1.bias (ff)
+    const float* b2;        // linear2.bias (d)
+    const float* ln2_g;     // norm2
+    const float* ln2_b;
+    float* Xout;            // optional; may alias res
+    int ldx;
+    const float* lnA_g;     // LayerNorm of the block output (next block's norm1 / the stack's final norm)
+    const float* lnA_b;
+    const float* lnB_g[2];  // optional second LayerNorm on top (an output head's norm), per row group
+    const float* lnB_b[2];
+    int out_mod, out_grp;   // out_mod > 0: row r belongs to group s = (r % out_mod) / out_grp (out_mod == 2 out_grp); its
+                            // Hout row is s * (M / out_mod) * out_grp + (r / out_mod) * out_grp + r % out_grp and LN_B[s] applies
+    bf16_t* Hout;           // optional
+    int ldh;
+    int variant;            // 0 = product kernel; 1, 2: timing experiments (tools/block_bench.py)
+    long long* stamps;      // optional (4 waves, 16) shader-clock phase stamps of workgroup stamp_block
+    int stamp_block;
+};
+bool block_fused_supported(int d, int ff);
+size_t block_stream_bytes();
+void launch_pack_block_stream(const bf16_t* Wo, const bf16_t* W1, const bf16_t* W2, bf16_t* out, hipStream_t st);
+bool launch_block_fused(const BlockP& p, hipStream_t st);  // false: arguments not covered (caller takes the unfused path)
+
 // LayerNorm over the last dim (eps 1e-5), one wave per row; optional second LayerNorm applied to
 // the result (decoder.norm followed by an output head's LayerNorm).  d <= 1024, d % 64 == 0.
 struct LnP {

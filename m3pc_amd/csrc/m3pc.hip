@@ -143,6 +143,8 @@ struct m3pc_handle {
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::map<std::string, std::unique_ptr<Plan>> plans;
+    // packed MFMA-fragment weight streams of the fused layer tails (block_fused.hip), by block prefix
+    std::map<std::string, bf16_t*> wstream;
     // profiling
     bool prof = false;
     std::vector<EventPair> ev;
@@ -381,8 +383,9 @@ void invalidate_tables(m3pc_handle* h) {
 // One pre-LN layer (mtm_model.py:379-409) over `batch` sequences of L rows, in place on X (fp32).
 // next_ln: the LayerNorm that follows this block on X (next block's norm1 or the stack's final norm); when the
 // FFN2 GEMM can apply it in its split-K reduce, *next_ln_done is set and the caller skips that launch.
+// x_dead: nothing reads X after this block except through next_ln (lets the fused tail skip the fp32 store).
 int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L, int dt, hipStream_t st, bool ln1_done = false,
-              int n_sh = 0, const LnP* next_ln = nullptr, bool* next_ln_done = nullptr) {
+              int n_sh = 0, const LnP* next_ln = nullptr, bool* next_ln_done = nullptr, bool x_dead = false) {
     const int d = h->d, ff = h->ff;
     const int rows = batch * L;
     const int es = (int)dtype_size(dt);
@@ -480,6 +483,40 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
         a.scale = 1.0f / sqrtf((float)h->hd);
         launch_attention(a, dt, st);
     }
+    }
+    // many-row bf16 passes: everything after the attention is one launch (block_fused.hip)
+    static const bool no_fused = getenv("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
+    if (dt == DT_BF16 && !no_fused && rows >= 512 && h->wstream.count(pfx)) {
+        BlockP b;
+        memset(&b, 0, sizeof(b));
+        b.O = (const bf16_t*)h->O;
+        b.ldo = d;
+        b.M = rows;
+        b.res = X;
+        b.ldr = d;
+        b.wstream = h->wstream[pfx];
+        b.bo = W(h, pfx + ".self_attn.out_proj.bias").f;
+        b.b1 = W(h, pfx + ".linear1.bias").f;
+        b.b2 = W(h, pfx + ".linear2.bias").f;
+        b.ln2_g = W(h, pfx + ".norm2.weight").f;
+        b.ln2_b = W(h, pfx + ".norm2.bias").f;
+        const bool fuse_ln = next_ln && next_ln->Yb && !next_ln->Yf && !next_ln->g2 && next_ln->X == X && next_ln->xmap.rpg == 0 &&
+                             next_ln->rows == rows;
+        if (fuse_ln) {
+            b.lnA_g = next_ln->g1;
+            b.lnA_b = next_ln->b1;
+            b.Hout = next_ln->Yb;
+            b.ldh = d;
+        }
+        if (!(fuse_ln && x_dead)) {
+            b.Xout = X;
+            b.ldx = d;
+        }
+        GemmTimer t(h, st, 2.0 * rows * ((double)d * d + 2.0 * d * ff), dt);
+        if (launch_block_fused(b, st)) {
+            if (next_ln_done) *next_ln_done = fuse_ln;
+            return check_launch(pfx.c_str());
+        }
     }
     {
         GemmP p = gemm_basic(h->O, d, Wop(h, pfx + ".self_attn.out_proj.weight", dt), d, rows, d, d,
@@ -581,12 +618,13 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
         if (i + 1 < nl) {
             nxt.g1 = W(h, "encoder.layers." + std::to_string(i + 1) + ".norm1.weight").f;
             nxt.b1 = W(h, "encoder.layers." + std::to_string(i + 1) + ".norm1.bias").f;
-            nxt.Yb = nullptr;
+            nxt.Yb = dt == DT_BF16 ? (bf16_t*)h->Hn : nullptr;
             nxt.Yf = dt == DT_F32 ? (float*)h->Hn : nullptr;
         }
         const bool l1 = ln_done;
         ln_done = false;
-        CHK(run_block(h, "encoder.layers." + std::to_string(i), h->X, batch, pl->Le, dt, st, l1, i == 0 ? n_sh : 0, &nxt, &ln_done));
+        CHK(run_block(h, "encoder.layers." + std::to_string(i), h->X, batch, pl->Le, dt, st, l1, i == 0 ? n_sh : 0, &nxt, &ln_done,
+                      i + 1 == nl && bf16_out_only));
     }
     if (!ln_done) launch_layernorm(ln, st);
     return check_launch("encoder");
@@ -618,6 +656,8 @@ int run_decoder_full(m3pc_handle* h, const void* Zop, int batch, int dt, hipStre
     return check_launch("decoder");
 }
 
+int run_head_tail(m3pc_handle* h, int k, const void* ln_rows, int rows, float* out, int ldy, bool detok, int dt, hipStream_t st);
+
 // Output head of key k (not actions) on `rows` logical rows of Ysrc selected by xmap:
 // decoder.norm -> head LN -> Linear+GELU -> Linear(D_k) [-> de-tokenize]
 int run_head(m3pc_handle* h, int k, const float* Ysrc, RowMap xmap, int rows, float* out, int ldy, bool detok, int dt,
@@ -640,7 +680,14 @@ int run_head(m3pc_handle* h, int k, const float* Ysrc, RowMap xmap, int rows, fl
     else
         ln.Yf = (float*)h->Hn;
     launch_layernorm(ln, st);
-    GemmP p = gemm_basic(h->Hn, d, Wop(h, "output_head_dict." + kn + ".1.weight", dt), d, rows, d, d,
+    return run_head_tail(h, k, h->Hn, rows, out, ldy, detok, dt, st);
+}
+
+// ... from the head's LayerNorm output (rows, d) in the operand dtype on: Linear+GELU -> Linear(D_k) [-> de-tokenize]
+int run_head_tail(m3pc_handle* h, int k, const void* ln_rows, int rows, float* out, int ldy, bool detok, int dt, hipStream_t st) {
+    const int d = h->d;
+    const std::string kn = KEYN[k];
+    GemmP p = gemm_basic(ln_rows, d, Wop(h, "output_head_dict." + kn + ".1.weight", dt), d, rows, d, d,
                          W(h, "output_head_dict." + kn + ".1.bias").f);
     p.gelu = 1;
     gemm_out(p, DT_F32, h->G, d);
@@ -986,6 +1033,52 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         launch_attention(at, dt, st);
     }
     float* Y1 = h->EncOut;  // (n*nq, d) decoder residual of the scored tokens (EncOut is dead: Z/Y hold its uses)
+    static const bool no_fused = getenv("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
+    bool tail_done = false;
+    if (dt == DT_BF16 && !no_fused && (long long)n * nq >= 512 && h->wstream.count(pfx)) {
+        // out-proj, norm2, FFN, decoder.norm and the two heads' LayerNorms in one launch (block_fused.hip): the rows of
+        // head s land in the s-th block of n*h rows of Hn
+        BlockP b;
+        memset(&b, 0, sizeof(b));
+        b.O = (const bf16_t*)h->O;
+        b.ldo = d;
+        b.M = n * nq;
+        if (q.all_masked) {
+            b.rowtab = tb.Yq;
+            b.rt_mod = nq;
+        } else {
+            b.res = Yq_rows;
+            b.ldr = d;
+        }
+        b.wstream = h->wstream[pfx];
+        b.bo = W(h, pfx + ".self_attn.out_proj.bias").f;
+        b.b1 = W(h, pfx + ".linear1.bias").f;
+        b.b2 = W(h, pfx + ".linear2.bias").f;
+        b.ln2_g = W(h, pfx + ".norm2.weight").f;
+        b.ln2_b = W(h, pfx + ".norm2.bias").f;
+        b.lnA_g = W(h, "decoder.norm.weight").f;
+        b.lnA_b = W(h, "decoder.norm.bias").f;
+        for (int s = 0; s < 2; ++s) {
+            b.lnB_g[s] = W(h, std::string("output_head_dict.") + KEYN[q.qkeys[s]] + ".0.weight").f;
+            b.lnB_b[s] = W(h, std::string("output_head_dict.") + KEYN[q.qkeys[s]] + ".0.bias").f;
+        }
+        b.out_mod = nq;
+        b.out_grp = hh;
+        b.Hout = (bf16_t*)h->Hn;
+        b.ldh = d;
+        bool ok;
+        {
+            GemmTimer t(h, st, 2.0 * n * nq * ((double)d * d + 2.0 * d * h->ff), dt);
+            ok = launch_block_fused(b, st);
+        }
+        if (ok) {
+            for (int s = 0; s < 2; ++s)
+                CHK(run_head_tail(h, q.qkeys[s], (const char*)h->Hn + (size_t)s * n * hh * d * es, n * hh, h->pred[s],
+                                  h->feat[q.qkeys[s]], true, dt, st));
+            tail_done = true;
+        }
+    }
+    if (!tail_done) {
     {
         GemmP p = gemm_basic(h->O, d, Wop(h, pfx + ".self_attn.out_proj.weight", dt), d, n * nq, d, d,
                              W(h, pfx + ".self_attn.out_proj.bias").f);
@@ -1026,6 +1119,7 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     for (int s = 0; s < 2; ++s) {
         RowMap xm{hh, nq, s * hh};
         CHK(run_head(h, q.qkeys[s], Y1, xm, n * hh, h->pred[s], h->feat[q.qkeys[s]], true, dt, st));
+    }
     }
     const float* rw;
     const float* boot;
@@ -1226,6 +1320,8 @@ int m3pc_destroy(m3pc_handle* h) {
         hipEventDestroy(e.a);
         hipEventDestroy(e.b);
     }
+    for (auto& kv : h->wstream)
+        if (kv.second) hipFree(kv.second);
     delete h;
     return 0;
 }
@@ -1243,6 +1339,17 @@ int m3pc_load_weights(m3pc_handle* h, const m3pc_named_tensor* tensors, int n, v
                               tensors[i].on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         if (kv.second.gemm) launch_f32_to_bf16(kv.second.f, kv.second.b, kv.second.numel, st);
         kv.second.loaded = true;
+    }
+    if (block_fused_supported(h->d, h->ff)) {  // fragment streams of the fused layer tails (block_fused.hip)
+        auto pack = [&](const std::string& pfx) -> int {
+            bf16_t*& ws = h->wstream[pfx];
+            if (!ws) CHK(dmalloc((char**)&ws, block_stream_bytes()));
+            launch_pack_block_stream(W(h, pfx + ".self_attn.out_proj.weight").b, W(h, pfx + ".linear1.weight").b,
+                                     W(h, pfx + ".linear2.weight").b, ws, st);
+            return 0;
+        };
+        for (int i = 0; i < h->dm.n_enc_layer; ++i) CHK(pack("encoder.layers." + std::to_string(i)));
+        for (int i = 0; i < h->dm.n_dec_layer; ++i) CHK(pack("decoder.layers." + std::to_string(i)));
     }
     HIPCHK(hipStreamSynchronize(st));
     // small derived tables on the host
@@ -1573,6 +1680,51 @@ int m3pc_debug_clock(long long* out2) {
 int m3pc_debug_topk(const float* v, int n, int k, int* idx_out, void* stream) {
     launch_topk(v, n, k, idx_out, (hipStream_t)stream);
     return check_launch("debug_topk");
+}
+
+// Not part of the public header (tests/test_block_fused_gpu.py, tools/block_bench.py): the fused layer tail on its own.
+//   O (M,512) bf16; res (M,512) fp32 or rowtab (rt_mod,512); Wo (512,512), W1 (2048,512), W2 (512,2048) bf16 in torch
+//   Linear layout; stream: scratch of m3pc_debug_block_stream_bytes() bytes (packed when pack != 0);
+//   lnB_g0 / lnB_g1 optional (with out_mod / out_grp); Xout (M,512) fp32 optional; Hout (M,512) bf16 optional
+long long m3pc_debug_block_stream_bytes(void) { return (long long)block_stream_bytes(); }
+int m3pc_debug_block_fused(const void* O, int M, const float* res, const float* rowtab, int rt_mod, const void* Wo, const void* W1,
+                           const void* W2, void* stream_buf, int pack, const float* bo, const float* b1, const float* b2,
+                           const float* ln2_g, const float* ln2_b, const float* lnA_g, const float* lnA_b, const float* lnB_g0,
+                           const float* lnB_b0, const float* lnB_g1, const float* lnB_b1, int out_mod, int out_grp, float* Xout,
+                           void* Hout, int variant, void* stream, long long* stamps) {
+    hipStream_t st = (hipStream_t)stream;
+    if (pack) launch_pack_block_stream((const bf16_t*)Wo, (const bf16_t*)W1, (const bf16_t*)W2, (bf16_t*)stream_buf, st);
+    BlockP b;
+    memset(&b, 0, sizeof(b));
+    b.O = (const bf16_t*)O;
+    b.ldo = 512;
+    b.M = M;
+    b.res = res;
+    b.ldr = 512;
+    b.rowtab = rowtab;
+    b.rt_mod = rt_mod;
+    b.wstream = (const bf16_t*)stream_buf;
+    b.bo = bo;
+    b.b1 = b1;
+    b.b2 = b2;
+    b.ln2_g = ln2_g;
+    b.ln2_b = ln2_b;
+    b.Xout = Xout;
+    b.ldx = 512;
+    b.lnA_g = lnA_g;
+    b.lnA_b = lnA_b;
+    b.lnB_g[0] = lnB_g0;
+    b.lnB_b[0] = lnB_b0;
+    b.lnB_g[1] = lnB_g1;
+    b.lnB_b[1] = lnB_b1;
+    b.out_mod = out_mod;
+    b.out_grp = out_grp;
+    b.Hout = (bf16_t*)Hout;
+    b.ldh = 512;
+    b.variant = variant;
+    b.stamps = stamps;
+    if (!launch_block_fused(b, st)) return fail(M3PC_EINVAL, "block_fused: arguments not covered");
+    return check_launch("debug_block_fused");
 }
 
 int m3pc_debug_clock_big(long long* out4) {

@@ -1,0 +1,117 @@
+"""GPU check of the fused layer tail (m3pc_amd/csrc/block_fused.hip) against plain torch fp32 with the same bf16
+rounding points: out-proj + residual -> LayerNorm2 -> Linear/GELU/Linear + residual -> LayerNorm(s)
+(mtm_model.py:379-409 halves of nn.TransformerEncoderLayer, norm_first, exact-erf GELU).  Through the library's debug
+entry m3pc_debug_block_fused (not part of the public header)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from m3pc_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+D, FF = 512, 2048
+
+
+def _call(lib, O, res, rowtab, rt_mod, W, stream_buf, pack, p, lnB, out_mod, out_grp, Xout, Hout, variant=0, sync=True,
+          stamps=None):
+    fn = lib.m3pc_debug_block_fused
+    fn.restype = C.c_int
+    vp, i = C.c_void_p, C.c_int
+    fn.argtypes = [vp, i, vp, vp, i, vp, vp, vp, vp, i] + [vp] * 11 + [i, i, vp, vp, i, vp, vp]
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = fn(O.data_ptr(), O.shape[0], ptr(res), ptr(rowtab), rt_mod, W["o"].data_ptr(), W["1"].data_ptr(), W["2"].data_ptr(),
+            stream_buf.data_ptr(), pack, p["bo"].data_ptr(), p["b1"].data_ptr(), p["b2"].data_ptr(), p["g2"].data_ptr(),
+            p["be2"].data_ptr(), p["gA"].data_ptr(), p["bA"].data_ptr(), ptr(lnB[0]), ptr(lnB[1]), ptr(lnB[2]), ptr(lnB[3]),
+            out_mod, out_grp, ptr(Xout), ptr(Hout), variant, st, ptr(stamps))
+    assert rc == 0, lib.m3pc_last_error()
+    if sync:
+        torch.cuda.synchronize()
+
+
+def make_params(seed):
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+    W = {"o": (rn(D, D) / D ** 0.5).to(torch.bfloat16), "1": (rn(FF, D) / D ** 0.5).to(torch.bfloat16),
+         "2": (rn(D, FF) / FF ** 0.5).to(torch.bfloat16)}
+    p = {"bo": 0.1 * rn(D), "b1": 0.1 * rn(FF), "b2": 0.1 * rn(D), "g2": 1 + 0.1 * rn(D), "be2": 0.1 * rn(D),
+         "gA": 1 + 0.1 * rn(D), "bA": 0.1 * rn(D)}
+    lnB = [1 + 0.1 * rn(D), 0.1 * rn(D), 1 + 0.1 * rn(D), 0.1 * rn(D)]
+    return W, p, lnB, g
+
+
+def reference(O, R, W, p, lnB=None, sel=None):
+    """fp32 torch with the kernel's bf16 rounding points (operands bf16, accumulation fp32)."""
+    x1 = R + p["bo"] + O.float() @ W["o"].float().T
+    a = F.layer_norm(x1, (D,), p["g2"], p["be2"], 1e-5).to(torch.bfloat16).float()
+    hid = F.gelu(a @ W["1"].float().T + p["b1"]).to(torch.bfloat16).float()
+    x2 = x1 + p["b2"] + hid @ W["2"].float().T
+    y = F.layer_norm(x2, (D,), p["gA"], p["bA"], 1e-5)
+    if lnB is not None:
+        y0 = F.layer_norm(y, (D,), lnB[0], lnB[1], 1e-5)
+        y1 = F.layer_norm(y, (D,), lnB[2], lnB[3], 1e-5)
+        y = torch.where(sel[:, None] == 0, y0, y1)
+    return x2, y
+
+
+@pytest.mark.parametrize("M", [128, 4096 + 37, 50176])
+def test_block_fused_matches_torch(M):
+    lib = capi.load_library()
+    dev = torch.device("cuda")
+    W, p, _, g = make_params(M)
+    O = torch.randn(M, D, device=dev, generator=g).to(torch.bfloat16)
+    R = torch.randn(M, D, device=dev, generator=g)
+    nbytes = lib.m3pc_debug_block_stream_bytes
+    nbytes.restype = C.c_longlong
+    sb = torch.empty(int(nbytes()), dtype=torch.uint8, device=dev)
+    Xout = torch.full((M, D), float("nan"), device=dev)
+    Hout = torch.full((M, D), float("nan"), device=dev, dtype=torch.bfloat16)
+    _call(lib, O, R, None, 1, W, sb, 1, p, [None] * 4, 0, 0, Xout, Hout)
+    rows = torch.arange(M, device=dev) if M <= 8192 else torch.cat([torch.arange(2048), torch.arange(M - 2048, M),
+                                                                     torch.randint(0, M, (4096,))]).to(dev)
+    x2, y = reference(O[rows], R[rows], W, p)
+    assert torch.isfinite(Xout).all() and torch.isfinite(Hout.float()).all()
+    ex = float((Xout[rows] - x2).abs().max()) / float(x2.abs().max())
+    ey = float((Hout[rows].float() - y).abs().max())
+    # X'': fp32 accumulation of bf16 products; a hidden value on a bf16 rounding boundary may round the other way
+    assert ex <= 2e-3, ex
+    assert ey <= 4e-2, ey  # bf16 output (|y| <~ 4: half an ulp is 1.6e-2) on top of ex
+    # in place (Xout aliases the residual rows), and bit-identical to the first launch; every row depends on itself only
+    R2 = R.clone()
+    H2 = torch.empty_like(Hout)
+    _call(lib, O, R2, None, 1, W, sb, 0, p, [None] * 4, 0, 0, R2, H2)
+    assert torch.equal(R2, Xout) and torch.equal(H2, Hout)
+    if M >= 4096:  # a shard of the rows gives the same bits (sharding exactness)
+        lo, n = 1280, 1000
+        X3 = torch.empty(n, D, device=dev)
+        H3 = torch.empty(n, D, device=dev, dtype=torch.bfloat16)
+        _call(lib, O[lo:lo + n].contiguous(), R[lo:lo + n].contiguous(), None, 1, W, sb, 0, p, [None] * 4, 0, 0, X3, H3)
+        assert torch.equal(X3, Xout[lo:lo + n]) and torch.equal(H3, Hout[lo:lo + n])
+
+
+def test_block_fused_rowtab_and_head_norms():
+    """decoder form: residual from a shared row table, no fp32 output, decoder.norm then one of two head LayerNorms by
+    row group, rows regrouped per head"""
+    lib = capi.load_library()
+    dev = torch.device("cuda")
+    n, nq, hh = 512, 32, 16
+    M = n * nq
+    W, p, lnB, g = make_params(7)
+    O = torch.randn(M, D, device=dev, generator=g).to(torch.bfloat16)
+    tab = torch.randn(nq, D, device=dev, generator=g)
+    nbytes = lib.m3pc_debug_block_stream_bytes
+    nbytes.restype = C.c_longlong
+    sb = torch.empty(int(nbytes()), dtype=torch.uint8, device=dev)
+    Hout = torch.full((M, D), float("nan"), device=dev, dtype=torch.bfloat16)
+    _call(lib, O, None, tab, nq, W, sb, 1, p, lnB, nq, hh, None, Hout)
+    r = torch.arange(M, device=dev)
+    sel = (r % nq) // hh
+    _, y = reference(O, tab[r % nq], W, p, lnB, sel)
+    orow = sel * (M // nq) * hh + (r // nq) * hh + r % hh
+    got = Hout[orow].float()
+    assert torch.isfinite(Hout.float()).all()
+    assert float((got - y).abs().max()) <= 4e-2
