@@ -24,11 +24,11 @@
 // Weights: the A fragments of the whole chain, 1 KiB each (64 lanes x 16 B, exactly the register image), are packed
 // ONCE per weight load in the order the kernel consumes them (pack_block_stream): 4608 fragments = 4.5 MiB per layer.
 // The kernel is then a linear stream: LDS-DMA pieces of 1 KiB (whole cache lines, contiguous source, contiguous
-// destination, one scalar offset), a ring of four 16-KiB stages (16 fragments = 16 MFMAs per wave), one
+// destination, one scalar offset), a ring of three 32-KiB stages (32 fragments = 32 MFMAs per wave), one
 // ds_read_b128 per MFMA at lane * 16 + immediate -- conflict-free by construction, no swizzle, no address arithmetic.
 // Per byte of L2->LDS traffic a 128-row tile does 128 FLOP (a 128x128 GEMM tile that also streams its A operand: 64).
 //
-// Phase order (144 phases of 32 MFMAs = two ring stages per tile):
+// Phase order (144 phases of 32 MFMAs = one ring stage each per tile):
 //   out-proj, phase sb = 0..15:  k-steps 2 sb, 2 sb + 1 of all 16 feature tiles; the two O fragments of a phase are
 //            loaded from global memory one phase ahead (the attention output is read exactly once)
 //   FFN, chunk c = 0..31 of 64 hidden units:  A0 A1 B1 B2
@@ -36,11 +36,11 @@
 //            B1 / B2: hidden k-steps 0,1 / 2,3 of the chunk into all 16 feature tiles (FFN2)
 //            gelu of hidden tile 0 runs on the VALU beside the MFMAs of A1, that of tile 1 beside B1.
 // Registers: 256 accumulators + the 32 LayerNorm-2 fragments (128) + hidden tiles, their bf16 fragments and the
-// fragment window do not fit 512 with room for the compiler, so the fragments of k-steps 16..31 live in LDS (16 KiB per
-// wave, private to it) and are read like the weights, two per group of four MFMAs.
-// Sync: ONE s_waitcnt vmcnt(8) lgkmcnt(0) + s_barrier per ring stage, placed four MFMAs before the stage ends: every
-// wave has read all of stage t (slot t % 4 is free: stage t+4's pieces go there) and stage t+1 has landed everywhere
-// (its first fragments are read under the last MFMAs of stage t).  Stages t+2 and t+3 stay in flight across the barrier.
+// fragment window do not fit 512 with room for the compiler, so the fragments of k-steps 24..31 live in LDS (8 KiB per
+// wave, private to it) and are read like the weights, one per group of four MFMAs.
+// Sync: ONE s_waitcnt vmcnt(8) lgkmcnt(0) + s_barrier per stage, placed four MFMAs before the stage ends: every wave
+// has read all of stage t (slot t % 3 is free: stage t+3's pieces go there) and stage t+1 has landed everywhere (its
+// first fragments are read under the last MFMAs of stage t).  Stage t+2 stays in flight across the barrier.
 // Fragments are read four at a time, one group (four MFMAs) ahead: one lgkmcnt wait per four MFMAs.
 // With one wave per SIMD the kernel is bound by what that wave has to ISSUE besides its MFMAs (an MFMA leaves room for
 // about five other instructions); the layout above is what keeps that count down.
@@ -65,16 +65,18 @@ constexpr int KS = BD / 16;                      // 32 k-steps over the model wi
 constexpr int NCH = BFF / 64;                    // 32 hidden chunks of 64
 constexpr int FR_OUT = NT * KS;                  // 512 out-proj fragments
 constexpr int FR_TOTAL = FR_OUT + NCH * 128;     // 4608
-constexpr int RS_FR = 16, RS_B = RS_FR * 1024, NRS = FR_TOTAL / RS_FR;  // 288 ring stages of 16 KiB
-constexpr int ACT_OFF = 4 * RS_B;                // LayerNorm-2 fragments of k-steps 16..31: 16 KiB per wave
+constexpr int RS_FR = 32, RS_B = RS_FR * 1024, NRS = FR_TOTAL / RS_FR;  // 144 ring stages (= phases) of 32 KiB
+constexpr int NSLOT = 3;
+constexpr int ACT_LDS = 8;                       // LayerNorm-2 fragments of k-steps 24..31 live in LDS: 8 KiB per wave
+constexpr int ACT_OFF = NSLOT * RS_B;
 // parameter tables (floats) behind them
 constexpr int T_B1 = 0, T_B2 = T_B1 + BFF, T_G2 = T_B2 + BD, T_BE2 = T_G2 + BD, T_GA = T_BE2 + BD, T_BA = T_GA + BD,
               T_GB = T_BA + BD, T_BB = T_GB + 2 * BD, T_END = T_BB + 2 * BD;
-constexpr int TAB_OFF = ACT_OFF + 4 * 16 * 1024;
+constexpr int TAB_OFF = ACT_OFF + 4 * ACT_LDS * 1024;
 constexpr int LDS_BYTES = TAB_OFF + T_END * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-// k-step of the i-th MFMA of an FFN1 phase: per group of four, two k-steps from registers (0..15), two from LDS (16..31)
-__host__ __device__ constexpr int a_kstep(int i) { return (i % 4 < 2) ? 2 * (i / 4) + i % 4 : 16 + 2 * (i / 4) + (i % 4 - 2); }
+// k-step of the i-th MFMA of an FFN1 phase: per group of four, three k-steps from registers (0..23), one from LDS (24..31)
+__host__ __device__ constexpr int a_kstep(int i) { return (i % 4 < 3) ? 3 * (i / 4) + i % 4 : 24 + i / 4; }
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ weight stream
@@ -141,6 +143,14 @@ __device__ __forceinline__ void mfma_done_a(f32x16 (&c)[16]) {
                    "+a"(c[10]), "+a"(c[11]), "+a"(c[12]), "+a"(c[13]), "+a"(c[14]), "+a"(c[15]));
 }
 
+// makes the compiler forget the copies it holds of the accumulators: the next reader takes them from the accumulator
+// registers again (one v_accvgpr_read each) instead of keeping 256 values alive through scratch between two passes
+__device__ __forceinline__ void acc_touch(f32x16 (&c)[16]) {
+    asm volatile(""
+                 : "+a"(c[0]), "+a"(c[1]), "+a"(c[2]), "+a"(c[3]), "+a"(c[4]), "+a"(c[5]), "+a"(c[6]), "+a"(c[7]), "+a"(c[8]), "+a"(c[9]),
+                   "+a"(c[10]), "+a"(c[11]), "+a"(c[12]), "+a"(c[13]), "+a"(c[14]), "+a"(c[15]));
+}
+
 // DBG (timing experiments): 1 = no DMA pieces, 2 = no gelu, 3 = clocks per FFN phase kind into p.stamps[8..11],
 // 4 = VALU slice in a region of its own behind its MFMA, 5 = gelu of every second value only, 6 = no s_barrier in the
 // per-stage sync, 7 = weight fragments read once (no LDS reads in the loops).  2, 5, 6, 7 compute wrong results.  p.stamps: phase stamps (shader clocks) of one workgroup
@@ -162,28 +172,30 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
 
     const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream, 0, (unsigned)(FR_TOTAL * 1024), 0x00020000);
     (void)w_rs;
-    // piece pc (0..3) of ring stage st: fragment wu + 4 pc of that stage -> the same position of ring slot st % 4
-    auto piece = [&](int st, int pc) {
+    // piece pc (0..7) of stage st: fragment wu + 4 pc of that stage -> the same position of ring slot `slot` = st % 3
+    auto piece = [&](int st, int slot, int pc) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc does not know this builtin)
         if (DBG == 1) return;
         const int sw = st >= NRS ? st - NRS : st;  // past the end: the head of the stream again (never read)
         const int fo = (wu + 4 * pc) * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lptr_t)(smem + (st & 3) * RS_B + fo), 16, lane16, sw * RS_B + fo, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lptr_t)(smem + slot * RS_B + fo), 16, lane16, sw * RS_B + fo, 0, 0);
 #endif
     };
-    const char* const lbase = smem + lane16;  // (every ring offset fits the 16-bit immediate of ds_read)
-    auto frag = [&](int slot, int f) -> u32x4 { return *(const u32x4*)(lbase + slot * RS_B + f * 1024); };
-    // LayerNorm-2 fragment of k-step 16 + m of this wave
-    char* const abase = smem + ACT_OFF + wu * 16 * 1024 + lane16;
+    // slots 0, 1 and slot 2 are read through two base addresses so that every offset fits the 16-bit immediate of ds_read
+    const char* const lbase0 = smem + lane16;
+    const char* const lbase2 = smem + 2 * RS_B + lane16;
+    auto frag = [&](int slot, int f) -> u32x4 { return *(const u32x4*)((slot == 2 ? lbase2 : lbase0 + slot * RS_B) + f * 1024); };
+    // LayerNorm-2 fragment of k-step 24 + m of this wave
+    char* const abase = smem + ACT_OFF + wu * ACT_LDS * 1024 + lane16;
     auto afrag = [&](int m) -> u32x4 { return *(const u32x4*)(abase + m * 1024); };
     float* const tab = (float*)(smem + TAB_OFF);
 
     // ---- prologue: first stages in flight, parameter tables, accumulators = residual + out-proj bias
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int pc = 0; pc < 4; ++pc) piece(s, pc);
-    piece(3, 0);
+        for (int pc = 0; pc < 8; ++pc) piece(s, s, pc);
+    piece(2, 2, 0);
     {
         for (int i = tid; i < BFF / 4; i += 256) *(f32x4*)(tab + T_B1 + 4 * i) = *(const f32x4*)(p.b1 + 4 * i);
         if (tid < BD / 4) {
@@ -206,18 +218,37 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     }
     f32x16 acc[NT];
     {
+        // residual + out-proj bias -> accumulators, four feature tiles (64 registers of loads) per batch, the next batch's
+        // loads in flight while a batch is added
         const float* rrow = p.rowtab ? p.rowtab + (size_t)(rld % p.rt_mod) * BD : p.res + (size_t)rld * p.ldr;
+        f32x4 xb[2][16];
+        auto loads = [&](int bt) {
 #pragma unroll
-        for (int jn = 0; jn < NT; ++jn)
+            for (int u = 0; u < 16; ++u) xb[bt & 1][u] = *(const f32x4*)(rrow + 32 * (4 * bt + u / 4) + 8 * (u % 4) + 4 * lh);
+        };
+        auto adds = [&](int bt) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = 32 * jn + 8 * q + 4 * lh;
-                const f32x4 x = *(const f32x4*)(rrow + n);
-                const f32x4 b = *(const f32x4*)(p.bo + n);
+            for (int u = 0; u < 16; ++u) {
+                const f32x4 b = *(const f32x4*)(p.bo + 32 * (4 * bt + u / 4) + 8 * (u % 4) + 4 * lh);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[jn][4 * q + i] = x[i] + b[i];
-                if (q == 3 && jn % 4 == 3) __builtin_amdgcn_sched_barrier(0);  // (at most four tiles of loads in registers)
+                for (int i = 0; i < 4; ++i) acc[4 * bt + u / 4][4 * (u % 4) + i] = xb[bt & 1][u][i] + b[i];
             }
+        };
+        loads(0);
+        loads(1);
+        __builtin_amdgcn_sched_barrier(0);
+        adds(0);
+        __builtin_amdgcn_sched_barrier(0);
+        loads(2);
+        __builtin_amdgcn_sched_barrier(0);
+        adds(1);
+        __builtin_amdgcn_sched_barrier(0);
+        loads(3);
+        __builtin_amdgcn_sched_barrier(0);
+        adds(2);
+        __builtin_amdgcn_sched_barrier(0);
+        adds(3);
+        __builtin_amdgcn_sched_barrier(0);
     }
     u32x4 ofr[KS];  // O fragments (B operand of the out-proj): dead after it, the LayerNorm-2 fragments take their place
     {
@@ -229,12 +260,11 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     stamps[1] = __builtin_readcyclecounter();
 
     u32x4 R[2][4];   // weight fragment groups: group g of a ring stage lives in R[g & 1]
-    u32x4 R2[2][2];  // the two LDS-resident LayerNorm-2 fragments of an FFN1 group, same parity
 #pragma unroll
     for (int k = 0; k < 4; ++k) R[0][k] = frag(0, k);
 
-    // one phase = two ring stages = 8 groups of {reads of the next group, one DMA piece, 4 x (MFMA, VALU slice)}
-    //   ph: phase index (runtime); SL: ring slot of its first stage (0 or 2, static)
+    // one phase = one ring stage = 8 groups of {reads of the next group, one DMA piece, 4 x (MFMA, VALU slice)}
+    //   ph: phase index (runtime); SL: its ring slot ph % 3 (static)
     //   extra(gn): further LDS reads for group gn of this phase (gn = 8: group 0 of the next phase)
     //   mma(i, a, g): MFMA i (0..31) with weight fragment a, group g;  valu(g, k): VALU work beside MFMA k of group g
     // Every MFMA slot is its own scheduling region, so the VALU slices stay between the MFMAs they are written beside.
@@ -242,21 +272,18 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
         constexpr int SL = decltype(sl_c)::value;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            const int rs = 2 * ph + g / 4;          // ring stage
-            const int gl = g % 4;                   // group within it
-            const int slot = (SL + g / 4) & 3;
-            if (gl == 3) {  // every read of this ring stage is issued: sync, then on into the next stage's slot
+            if (g == 7) {  // every read of this stage is issued: sync, then on into the next stage's slot
                 if (DBG == 6) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             if (DBG != 7) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) R[(g + 1) & 1][k] = gl < 3 ? frag(slot, 4 * (gl + 1) + k) : frag((slot + 1) & 3, k);
+                for (int k = 0; k < 4; ++k) R[(g + 1) & 1][k] = g < 7 ? frag(SL, 4 * (g + 1) + k) : frag((SL + 1) % 3, k);
             }
             extra(g + 1);
-            // 4 DMA pieces per ring stage: pieces 1..3 of stage rs+3 before the sync, piece 0 of stage rs+4 after it
-            if (gl < 3) piece(rs + 3, 1 + gl);
-            else piece(rs + 4, 0);
+            // 8 DMA pieces per stage: pieces 1..7 of stage ph+2 before the sync, piece 0 of stage ph+3 after it
+            if (g < 7) piece(ph + 2, (SL + 2) % 3, 1 + g);
+            else piece(ph + 3, SL, 0);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 mma(4 * g + k, R[DBG == 7 ? 0 : g & 1][k], g);
@@ -269,19 +296,19 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     auto no_valu = [](int, int) {};
     auto no_extra = [](int) {};
     using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
     using S2 = std::integral_constant<int, 2>;
 
     // ---- out-proj: phase sb = k-steps 2 sb, 2 sb + 1 of all 16 feature tiles (straight-line: the O fragment index is static)
-#define OUTPROJ2(sb)                                                                                                   \
-    phase(sb, S0{}, no_extra, [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], a, ofr[2 * (sb) + i / 16]); }, no_valu);      \
-    phase(sb + 1, S2{}, no_extra, [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], a, ofr[2 * (sb) + 2 + i / 16]); }, no_valu);
-    OUTPROJ2(0) OUTPROJ2(2) OUTPROJ2(4) OUTPROJ2(6) OUTPROJ2(8) OUTPROJ2(10) OUTPROJ2(12) OUTPROJ2(14)
-#undef OUTPROJ2
+#define OUTPROJ(sb, SL) phase(sb, SL{}, no_extra, [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], a, ofr[2 * (sb) + i / 16]); }, no_valu);
+    OUTPROJ(0, S0) OUTPROJ(1, S1) OUTPROJ(2, S2) OUTPROJ(3, S0) OUTPROJ(4, S1) OUTPROJ(5, S2) OUTPROJ(6, S0) OUTPROJ(7, S1)
+    OUTPROJ(8, S2) OUTPROJ(9, S0) OUTPROJ(10, S1) OUTPROJ(11, S2) OUTPROJ(12, S0) OUTPROJ(13, S1) OUTPROJ(14, S2) OUTPROJ(15, S0)
+#undef OUTPROJ
     mfma_done_a(acc);  // (the accumulators are next read by v_accvgpr_read)
     stamps[2] = __builtin_readcyclecounter();
 
     // ---- LayerNorm-2 of X' (in the accumulators) -> act (bf16 B-operand fragments of FFN1)
-    u32x4 act[16];  // k-steps 0..15; k-steps 16..31 go to this wave's LDS region
+    u32x4 act[KS - ACT_LDS];  // k-steps 0..23; k-steps 24..31 go to this wave's LDS region
     {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -298,6 +325,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
         const float mean = s1 * (1.0f / BD);
         const float rstd = rsqrtf(fmaxf(s2 * (1.0f / BD) - mean * mean, 0.f) + 1e-5f);
         const float nmr = -mean * rstd;
+        acc_touch(acc);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             __builtin_amdgcn_sched_barrier(0);
@@ -314,8 +342,8 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
             bf16x8 w;
 #pragma unroll
             for (int j = 0; j < 8; ++j) w[j] = (bf16_t)y[j];
-            if (s < 16) act[s] = __builtin_bit_cast(u32x4, w);
-            else *(u32x4*)(abase + (s - 16) * 1024) = __builtin_bit_cast(u32x4, w);
+            if (s < KS - ACT_LDS) act[s] = __builtin_bit_cast(u32x4, w);
+            else *(u32x4*)(abase + (s - (KS - ACT_LDS)) * 1024) = __builtin_bit_cast(u32x4, w);
         }
     }
     stamps[3] = __builtin_readcyclecounter();
@@ -367,42 +395,52 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
             hb[2 * t + (e >> 3)][(e & 7) >> 1] = __builtin_bit_cast(unsigned, w);
         }
     };
-    // B operand of MFMA i of an FFN1 phase (group g = i / 4): registers for the first two of a group, LDS for the others
-    auto a_operand = [&](int i, int g) -> u32x4 { return i % 4 < 2 ? act[a_kstep(i)] : R2[g & 1][i % 4 - 2]; };
-    auto act_reads = [&](int gn) {  // LDS-resident fragments of group gn (8 = group 0 of the next FFN1 phase)
-        const int g = gn & 7;
-        R2[gn & 1][0] = afrag(2 * g);
-        R2[gn & 1][1] = afrag(2 * g + 1);
-    };
+    // B operand of MFMA i of an FFN1 phase (group g = i / 4): registers for the first three of a group, LDS for the fourth
+    u32x4 R2[2];  // the LDS-resident LayerNorm-2 fragment of an FFN1 group, by group parity
+    auto a_operand = [&](int i, int g) -> u32x4 { return i % 4 < 3 ? act[a_kstep(i)] : R2[g & 1]; };
+    auto act_reads = [&](int gn) { R2[gn & 1] = afrag(gn & 7); };  // (gn = 8: group 0 of the next FFN1 phase)
     bias_init(h0, 0, 0);
     bias_init(h1, 0, 1);
     act_reads(0);
-    for (int c = 0; c < NCH; ++c) {
+    // one chunk = four phases A0 A1 B1 B2 starting in ring slot SL0 (the slot pattern repeats every three chunks)
+    auto chunk = [&](int c, auto s0_c) {
+        constexpr int SL0 = decltype(s0_c)::value;
+        using P0 = std::integral_constant<int, SL0 % 3>;
+        using P1 = std::integral_constant<int, (SL0 + 1) % 3>;
+        using P2 = std::integral_constant<int, (SL0 + 2) % 3>;
         const int ph = 16 + 4 * c;
         const int cn = c + 1 < NCH ? c + 1 : c;
         if (DBG == 3) pt = __builtin_readcyclecounter();
         // A0: hidden tile 0
-        phase(ph, S0{}, act_reads, [&](int i, u32x4 a, int g) { mfma_v(h0, a, a_operand(i, g)); }, no_valu);
+        phase(ph, P0{}, act_reads, [&](int i, u32x4 a, int g) { mfma_v(h0, a, a_operand(i, g)); }, no_valu);
         mfma_done_v(h0);
         if (DBG == 3) { const long long t = __builtin_readcyclecounter(); psum[0] += t - pt; pt = t; }
         // A1: hidden tile 1; gelu of tile 0 (two values per group)
-        phase(ph + 1, S2{}, [&](int gn) { if (gn < 8) act_reads(gn); },
+        phase(ph + 1, P1{}, [&](int gn) { if (gn < 8) act_reads(gn); },
               [&](int i, u32x4 a, int g) { mfma_v(h1, a, a_operand(i, g)); },
               [&](int g, int k) { if (DBG != 5 || g % 2 == 0) gelu_slice(h0, 0, 2 * g, k); });
         mfma_done_v(h1);
         if (DBG == 3) { const long long t = __builtin_readcyclecounter(); psum[1] += t - pt; pt = t; }
         // B1: hidden k-steps 0, 1 into the 16 feature tiles; gelu of tile 1
-        phase(ph + 2, S0{}, no_extra, [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], a, hb[i / 16]); },
+        phase(ph + 2, P2{}, no_extra, [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], a, hb[i / 16]); },
               [&](int g, int k) { if (DBG != 5 || g % 2 == 0) gelu_slice(h1, 1, 2 * g, k); });
         if (DBG == 3) { const long long t = __builtin_readcyclecounter(); psum[2] += t - pt; pt = t; }
         // B2: hidden k-steps 2, 3; the next chunk's linear1 bias goes into the (now free) hidden accumulators
-        phase(ph + 3, S2{}, [&](int gn) { if (gn == 8) act_reads(8); },
+        phase(ph + 3, P0{}, [&](int gn) { if (gn == 8) act_reads(8); },
               [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], a, hb[2 + i / 16]); },
               [&](int g, int k) {
                   if (g == 1 && k == 0) bias_init(h0, cn, 0);
                   if (g == 4 && k == 0) bias_init(h1, cn, 1);
               });
         if (DBG == 3) psum[3] += __builtin_readcyclecounter() - pt;
+    };
+    // phase 16 = slot 1; a chunk advances the slot by 4 = 1 (mod 3)
+    chunk(0, S1{});
+    chunk(1, S2{});
+    for (int c = 2; c < NCH; c += 3) {  // chunks 2..31 = ten rounds of three
+        chunk(c, S0{});
+        chunk(c + 1, S1{});
+        chunk(c + 2, S2{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the pieces issued past the end of the stream
     mfma_done_a(acc);
@@ -419,6 +457,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    acc_touch(acc);
     if (p.Xout && valid) {
         float* xrow = p.Xout + (size_t)rtok * p.ldx;
 #pragma unroll
@@ -433,6 +472,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
             }
     }
     stamps[5] = __builtin_readcyclecounter();
+    acc_touch(acc);
     if (p.Hout) {
         int orow_h = rtok, sel = 0;
         if (p.out_mod > 0) {  // two row groups per out_mod rows: group s rows go to the s-th compact block, LN_B[s] applies
@@ -459,6 +499,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
         };
         float rstd, nmr;
         row_stats(rstd, nmr);
+        acc_touch(acc);
         const bool two = p.lnB_g[0] != nullptr;
         if (two) {  // acc := LN_A(acc), then statistics of that
 #pragma unroll
@@ -472,7 +513,9 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
                     for (int i = 0; i < 4; ++i) acc[jn][4 * q + i] = fmaf(fmaf(acc[jn][4 * q + i], rstd, nmr), g[i], b[i]);
                     if (q == 3) __builtin_amdgcn_sched_barrier(0);
                 }
+            acc_touch(acc);
             row_stats(rstd, nmr);
+            acc_touch(acc);
         }
         const float* const gtab = two ? tab + T_GB + sel * BD : tab + T_GA;
         const float* const btab = two ? tab + T_BB + sel * BD : tab + T_BA;
