@@ -6,8 +6,14 @@
 
 One "step" = one complete plan step of rtg_guiding (research/finetune_omtm/learner.py:271-327): draw eps,
 policy pass (batch 1), sample N candidates, batched candidate pass, TD(lambda) scoring, all-gather of the
-shards (N > 1 GPU), fp32 re-score of the bf16 top-16, softmax / weighted mean / argmax, multinomial draw.
+shards (N > 1 GPU), fp32 re-score of every candidate within 2*delta of the bf16 maximum (the bound-driven set,
+m3pc_amd/planner.py; one 16-byte host read per step), softmax / weighted mean / argmax, multinomial draw.
 Inputs (window, weights) are resident in HBM when the timed region starts.
+
+Besides the contract fields the line carries (rank 0, 1 GPU): `rescore` (set sizes), `fp32_ms_per_step` (the same step
+fp32 end to end: the mode that meets the fp32 tolerance everywhere), `closed_loop` (action_sample with the H2D window
+copy and the action read back every step), `latency_ms_shipped` (the reference's shipped N=625/H=4/T=8 config and the
+zero-shot B=1 call: the launch-latency-bound operating points), `batched` (E windows per launch).
 
 Workload at 1 GPU: BASELINE configs[1] = hopper-medium-v2 shapes (S=11, A=3), rtg_guiding, N=1024
 candidates, H=16, T=32 (=2H, the reference's shipped T/H ratio), bf16 candidate pass, synthetic data.
@@ -56,7 +62,8 @@ def alg_bytes(N, T, S, A, n_params=11_326_995):
 
 
 def cpu_baseline(dims, cfg_kw, hist, rtg):
-    """The oracle (fp32 PyTorch-CPU restatement of the reference path) timed on this host's cores."""
+    """The oracle (fp32 PyTorch-CPU restatement of the reference path) timed on this host's cores: the full
+    N-candidate plan step of the bench workload (value), and BASELINE config 1 (hopper N=64 H=8 T=16) beside it."""
     from m3pc_amd import synth
     from oracle import mtm_oracle as O
     try:
@@ -68,7 +75,7 @@ def cpu_baseline(dims, cfg_kw, hist, rtg):
     sd = synth.make_state_dict(dims, 0)
     stats = O.make_stats(synth.make_tokenizer_stats(dims, 0))
     N = cfg_kw["action_samples"]
-    n_s = min(N, 256)  # bounded sample: a 256-candidate plan step, scaled to the N-candidate unit
+    n_s = N  # the whole plan step (about 5 s on 64 threads at N = 1024): no extrapolation
     cfg = O.PlanCfg(dims.traj_length, cfg_kw["horizon"], n_s, 0.99, 0.01, 0.6)
     win, h = O.assemble_window(cfg, hist, 500, rtg)
     eps = synth.make_eps(N, dims, 1)[:n_s]
@@ -76,13 +83,28 @@ def cpu_baseline(dims, cfg_kw, hist, rtg):
     O.guiding(sd, stats, small, win, h, 0.6, eps[:32], "rtg")  # warm-up (thread pools, allocator)
     t0 = time.perf_counter()
     reps = 0
-    while reps < 1 or (time.perf_counter() - t0 < 10.0 and reps < 8):
+    while reps < 1 or (time.perf_counter() - t0 < 12.0 and reps < 4):
         O.guiding(sd, stats, cfg, win, h, 0.6, eps, "rtg")
         reps += 1
     dt = (time.perf_counter() - t0) / reps
-    return {"value": (n_s / float(N)) / dt, "unit": "plan-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} x plan step at {n_s} of {N} candidates (rtg_guiding H={h} T={dims.traj_length}, fp32 "
-                      f"torch-CPU oracle, {cores} threads, {dt:.2f}s each), scaled by {n_s}/{N}"}
+    # BASELINE configs[0]: hopper rtg_guiding N=64 H=8 T=16 (the reference's own CPU-runnable case)
+    d1 = synth.Dims(dims.state_dim, dims.action_dim, 16)
+    c1 = O.PlanCfg(16, 8, 64, 0.99, 0.01, 0.6)
+    h1 = synth.make_history(d1, 0)
+    w1, hh1 = O.assemble_window(c1, h1, 500, rtg)
+    sd1, st1, e1 = synth.make_state_dict(d1, 0), O.make_stats(synth.make_tokenizer_stats(d1, 0)), synth.make_eps(64, d1, 1)
+    O.guiding(sd1, st1, c1, w1, hh1, 0.6, e1, "rtg")
+    t1 = time.perf_counter()
+    r1 = 0
+    while r1 < 3 or (time.perf_counter() - t1 < 3.0 and r1 < 20):
+        O.guiding(sd1, st1, c1, w1, hh1, 0.6, e1, "rtg")
+        r1 += 1
+    dt1 = (time.perf_counter() - t1) / r1
+    return {"value": 1.0 / dt, "unit": "plan-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x the whole plan step ({N} candidates, rtg_guiding H={h} T={dims.traj_length}, fp32 torch-CPU "
+                      f"oracle, {cores} threads, {dt:.2f}s each)",
+            "config1": {"value": round(1.0 / dt1, 3), "unit": "plan-steps/s",
+                        "sample": f"{r1} x hopper rtg_guiding N=64 H=8 T=16 ({1e3 * dt1:.0f} ms each)"}}
 
 
 def main():
@@ -94,7 +116,10 @@ def main():
     ap.add_argument("--candidates", type=int, default=1024, help="candidates per GPU")
     ap.add_argument("--horizon", type=int, default=16)
     ap.add_argument("--traj-length", type=int, default=32)
+    ap.add_argument("--rescore", default="bound", choices=["bound", "topk"],
+                    help="fp32 re-score set: every candidate within 2*delta of the bf16 maximum (default) or a fixed top-k")
     ap.add_argument("--rescore-topk", type=int, default=16)
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / closed-loop / shipped-config side measurements")
     ap.add_argument("--strong", action="store_true", help="keep the global candidate count fixed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--env", default="hopper", choices=["hopper", "walker2d", "halfcheetah"],
@@ -132,7 +157,8 @@ def main():
     gen.manual_seed(1)  # same seed on every rank: identical eps and multinomial draws
     qsd, om, os_ = synth.make_critic(dims, 0) if critic_mode else (None, None, None)
     planner = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), qsd, om, os_,
-                         precision=args.precision, rescore_topk=args.rescore_topk, device=local_rank, generator=gen)
+                         precision=args.precision, rescore_topk=args.rescore_topk, device=local_rank, generator=gen,
+                         rescore=args.rescore, group=torch.distributed.group.WORLD if world > 1 else None)
     hist = synth.make_history(dims, 0)
     hist["path_length"] = 500
     states, actions, rewards, h, rtg = planner.assemble_window(hist, rtg=3.0)
@@ -150,8 +176,10 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
+    n_re = []
     for _ in range(args.steps):
         step()
+        n_re.append(planner.last.get("n_rescored", args.rescore_topk))
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -190,8 +218,9 @@ def main():
     f_step = alg_flops(n_local, T, H, S, A, mode="critic" if critic_mode else "rtg")
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.precision),
-                "kernel": f"m3pc::gemm_line_kernel / gemm_glds_ring3_kernel / gemm_big_kernel (few-row launches: gemm_kernel), the "
-                          f"{args.precision} MFMA GEMM launches of the candidate pass",
+                "peak_measured": 1800.0 if args.precision == "bf16" else None,  # register-resident v_mfma loop at the 1.75 GHz the chip holds
+                "kernel": f"m3pc::block_fused_kernel (layer tails: out-proj + LN + FFN) / gemm_line_kernel / gemm_glds_ring3_kernel "
+                          f"(few-row launches: gemm_kernel), the {args.precision} MFMA launches of the candidate pass",
                 "all_gemm_ms_per_step": all_ms / args.steps, "all_gemm_launches_per_step": all_launches / args.steps,
                 "flops_per_launch": gemm_flops / max(launches, 1), "avg_launch_us": 1e3 * gemm_ms / max(launches, 1),
                 "launches_per_step": launches / args.steps, "gemm_ms_per_step": gemm_ms / args.steps,
@@ -207,15 +236,83 @@ def main():
                "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.precision,
                "data": "synthetic",
                "config": {"workload": f"{args.env}-medium-v2 shapes (S={S},A={A}) {args.guidance} N={args.candidates}/GPU H={H} "
-                                      f"T={T} {args.precision} candidate pass + fp32 policy pass + fp32 top-{args.rescore_topk} re-score",
+                                      f"T={T} {args.precision} candidate pass + fp32 policy pass + fp32 re-score ("
+                                      + (f"bound-driven set, {sum(n_re) / len(n_re):.1f} candidates on average" if args.rescore == "bound"
+                                         else f"top-{args.rescore_topk}") + "); pipelined throughput, window resident in HBM",
                           "candidates_per_gpu": n_local, "global_candidates": n_global, "horizon": H, "traj_length": T,
                           "parallelism": f"candidate-shard x{world}"},
-               "latency_ms": latency, "roofline": roofline}
+               "latency_ms": latency, "roofline": roofline,
+               "rescore": {"mode": args.rescore, "n_mean": round(sum(n_re) / len(n_re), 2), "n_max": max(n_re),
+                           "delta": planner.last.get("delta"), "min_margin_outside": planner.last.get("min_margin_outside")}}
+        if world == 1 and not args.no_extras:
+            try:
+                out.update(extras(args, dims, cfg, hist, planner, S, A))
+            except Exception as e:  # the side measurements never take the headline down with them
+                out["extras_error"] = repr(e)[:300]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, dict(horizon=H, action_samples=args.candidates), hist, 3.0)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def _time_calls(fn, n, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    ts.sort()
+    return {"p50": round(ts[len(ts) // 2], 4), "min": round(ts[0], 4), "p99": round(ts[min(len(ts) - 1, int(0.99 * len(ts)))], 4), "calls": n}
+
+
+def extras(args, dims, cfg, hist, planner, S, A):
+    """Side measurements on rank 0 at 1 GPU, outside the timed region (each a few hundred milliseconds)."""
+    import types
+
+    from m3pc_amd import capi, synth
+    from m3pc_amd.planner import HipPlanner
+
+    out = {}
+    # closed loop: what a rollout loop sees per env step -- host window assembly + H2D, the plan step, the action read back
+    out["closed_loop"] = {"what": "action_sample(history, eval=True, rtg) incl. window H2D copy and .cpu() of the action, one call at a time",
+                          "ms": _time_calls(lambda: planner.action_sample(hist, plan=True, eval=True, rtg=3.0).cpu(), 40)}
+    out["closed_loop"]["steps_per_s"] = round(1e3 / out["closed_loop"]["ms"]["p50"], 2)
+    if args.precision == "bf16":
+        qsd, om, os_ = synth.make_critic(dims, 0) if "critic" in cfg.plan_guidance else (None, None, None)
+        p32 = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), qsd, om, os_, precision="fp32",
+                         generator=torch.Generator(device="cuda").manual_seed(1))
+        s_, a_, r_, h_, rtg_ = p32.assemble_window(hist, rtg=3.0)
+        mode = capi.MODE_CRITIC if "critic" in cfg.plan_guidance else capi.MODE_RTG
+        for _ in range(2):
+            p32._guide(mode, s_, a_, r_, rtg_, h_, 0.6)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(8):
+            p32._guide(mode, s_, a_, r_, rtg_, h_, 0.6)
+        torch.cuda.synchronize()
+        out["fp32_ms_per_step"] = round(1e3 * (time.perf_counter() - t0) / 8, 4)
+        p32.handle.close()
+    # the reference's shipped planning config (finetune_omtm/config.yaml:5,77-79): N=625, H=4, T=8 -- launch-latency-bound
+    d8 = synth.Dims(S, A, 8)
+    c8 = types.SimpleNamespace(traj_length=8, action_samples=625, horizon=4, discount=0.99, temperature=0.01, lmbda=0.6,
+                               plan_guidance="rtg_guiding")
+    h8 = synth.make_history(d8, 0)
+    h8["path_length"] = 500
+    ship = {}
+    for prec in ("bf16", "fp32"):
+        p8 = HipPlanner(c8, synth.make_state_dict(d8, 0), synth.make_tokenizer_stats(d8, 0), None, precision=prec,
+                        generator=torch.Generator(device="cuda").manual_seed(1))
+        ship[prec] = _time_calls(lambda: p8.action_sample(h8, plan=True, eval=True, rtg=3.0).cpu(), 40)
+        if prec == "fp32":  # zero-shot goal reaching, one env per call (zeroshot_omtm/learner.py:151-261, config_hopper.yaml)
+            ship["zeroshot_piid_B1"] = _time_calls(lambda: p8.action_piid_sample(h8, eval=True, rtg=2.5).cpu(), 40)
+        p8.handle.close()
+    out["latency_ms_shipped"] = {"config": "hopper rtg_guiding N=625 H=4 T=8 (closed loop, per call)", **ship}
+    return out
 
 
 def pmc_traffic(precision):

@@ -163,6 +163,19 @@ int m3pc_rescore_topk(m3pc_handle* h, const m3pc_plan_args* args, const float* s
                       const float* rewards, const float* eps, float* expect_return, int k, int* topk_index,
                       void* stream);
 
+/* Bound-driven re-score set (the arg-max of learner.py:318-325 must not depend on bf16 rounding): if every bf16 score is
+ * within delta of its fp32 value up to a common shift, the fp32 arg-max lies among the candidates whose bf16 score is
+ * within window = 2 delta of the bf16 maximum.  Finds the kmax + 1 best entries of expect_return (descending; ties to the
+ * lower index) and n = clamp(#{E_i >= max E - window}, kmin, kmax).
+ *   topk_index  device out (kmax + 1,) int32
+ *   stats       device out float[4]: {n, max E - (best E not among the n) [inf if none], max E, unclamped count} */
+int m3pc_topk_window(m3pc_handle* h, const float* expect_return, int n_total, int kmax, int kmin, float window,
+                     int* topk_index, float* stats, void* stream);
+/* m3pc_rescore of the n listed candidates (device int32 ids), written back into the full score vector in place. */
+int m3pc_rescore_listed(m3pc_handle* h, const m3pc_plan_args* args, const float* states, const float* actions,
+                        const float* rewards, const float* eps, const int* index, int n, float* expect_return,
+                        void* stream);
+
 /* The cross-candidate tail (learner.py:318-325) over all N candidates (after an all-gather when
  * sharded): p = softmax(temperature * (E - max E)), eval_action = sum p*a0 / sum p, argmax E, and the
  * multinomial draw sample_action = a0[multinomial(p, 1)].

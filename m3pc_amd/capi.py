@@ -25,7 +25,8 @@ ABI_VERSION = 1
 EXPORTS = (
     "m3pc_last_error", "m3pc_abi_version", "m3pc_create", "m3pc_destroy", "m3pc_load_weights",
     "m3pc_set_tokenizer", "m3pc_set_critic", "m3pc_tokenize", "m3pc_detokenize", "m3pc_forward",
-    "m3pc_plan_step", "m3pc_rescore", "m3pc_rescore_topk", "m3pc_select", "m3pc_profile_enable",
+    "m3pc_plan_step", "m3pc_rescore", "m3pc_rescore_topk", "m3pc_topk_window", "m3pc_rescore_listed", "m3pc_select",
+    "m3pc_profile_enable",
     "m3pc_profile_read",
 )
 
@@ -79,6 +80,8 @@ def load_library(path: Optional[str] = None):
         "m3pc_plan_step": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_rescore": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, i, vp, vp, vp],
         "m3pc_rescore_topk": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, i, vp, vp],
+        "m3pc_topk_window": [vp, vp, i, i, i, f, vp, vp, vp],
+        "m3pc_rescore_listed": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, i, vp, vp],
         "m3pc_select": [vp, vp, vp, ll, i, f, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_profile_enable": [vp, i],
         "m3pc_profile_read": [vp, i, C.POINTER(ll), C.POINTER(d), C.POINTER(d), i],
@@ -259,6 +262,27 @@ class Handle:
         check(self.lib.m3pc_rescore_topk(self._h, C.byref(args), _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]),
                                          _ptr(ins[3]), _ptr(expect_return), k, _ptr(top), _stream(self.device)))
         return top
+
+    def topk_window(self, expect_return: torch.Tensor, kmax: int, kmin: int, window: float):
+        """The kmax + 1 best candidates (ids, best first) and stats = [n, margin to the best one outside the n, max, raw
+        count] where n = clamp(#{E >= max E - window}, kmin, kmax).  Both stay on the device."""
+        n = expect_return.numel()
+        assert expect_return.is_contiguous() and expect_return.dtype == torch.float32
+        top = torch.empty((kmax + 1,), dtype=torch.int32, device=self.device)
+        stats = torch.empty((4,), dtype=torch.float32, device=self.device)
+        check(self.lib.m3pc_topk_window(self._h, _ptr(expect_return), n, kmax, kmin, float(window), _ptr(top), _ptr(stats),
+                                        _stream(self.device)))
+        return top, stats
+
+    def rescore_listed(self, mode: int, states, actions, rewards, eps, expect_return: torch.Tensor, index: torch.Tensor,
+                       horizon: int, rtg: float, lmbda: float, discount: float):
+        """Replace the entries ``index`` (int32 cuda) of ``expect_return`` by their fp32 re-scores, in place."""
+        n = expect_return.numel()
+        assert index.dtype == torch.int32 and index.is_contiguous() and expect_return.is_contiguous()
+        args = PlanArgs(mode, PREC_FP32, horizon, n, 0, n, lmbda, discount, rtg)
+        ins = [t.to(torch.float32).contiguous() for t in (states, actions, rewards, eps)]
+        check(self.lib.m3pc_rescore_listed(self._h, C.byref(args), _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), _ptr(ins[3]),
+                                           _ptr(index), index.numel(), _ptr(expect_return), _stream(self.device)))
 
     def select(self, expect_return: torch.Tensor, a0: torch.Tensor, temperature: float,
                expo: Optional[torch.Tensor] = None):

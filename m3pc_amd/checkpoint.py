@@ -38,7 +38,10 @@ def load_iql_qf(path: str) -> Dict[str, torch.Tensor]:
 
 
 def tokenizer_stats(stats: Mapping[str, Any]) -> Dict[str, Dict[str, np.ndarray]]:
-    """Normalise per-key statistics (objects with .mean/.std/.min/.max or dicts) to the dict form ``HipPlanner`` takes."""
+    """Normalise per-key statistics (objects with .mean/.std/.min/.max or dicts) to the dict form ``HipPlanner`` takes.
+    The values stay the RAW dataset statistics (what the reference pickles, sequence_dataset.py:357-395); the clamp
+    ``std[std < 0.1] = 1`` of ``ContinuousTokenizer.create`` (continuous.py:58) is applied where the tokenizer is built
+    (``HipPlanner`` / ``ContinuousTokenizer.create``), exactly once."""
     out = {}
     for k in KEYS:
         s = stats[k]
@@ -47,6 +50,33 @@ def tokenizer_stats(stats: Mapping[str, Any]) -> Dict[str, Dict[str, np.ndarray]
         if not np.all(out[k]["min"] <= out[k]["max"]):
             raise ValueError(f"statistics of '{k}': min > max")
     return out
+
+
+def load_statistics_pickle(path: str) -> Dict[str, Dict[str, np.ndarray]]:
+    """The statistics cache the reference's dataset writes (``/tmp/d4rl/d4rl_statistics_{env}_{T}_{discount}.pkl``,
+    research/omtm/datasets/sequence_dataset.py:357-404): a pickled ``{key: DataStatistics}``.  The pickle refers to the
+    reference's ``research.omtm.datasets.base.DataStatistics`` class, which is not importable here: objects of that one
+    class are rebuilt as plain namespaces, anything else is refused (no arbitrary code runs)."""
+    import pickle
+    import types
+
+    class _Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            if name == "DataStatistics":
+                return _Stats
+            if module.startswith("numpy") and name in ("ndarray", "dtype", "_reconstruct", "scalar", "_frombuffer"):
+                return super().find_class(module, name)
+            raise pickle.UnpicklingError(f"statistics pickle refers to {module}.{name}; only DataStatistics of numpy arrays is accepted")
+
+    class _Stats(types.SimpleNamespace):
+        def __init__(self, mean=None, std=None, min=None, max=None):
+            super().__init__(mean=mean, std=std, min=min, max=max)
+
+    with open(path, "rb") as f:
+        obj = _Unpickler(f).load()
+    if not isinstance(obj, dict) or not all(k in obj for k in KEYS):
+        raise ValueError(f"{path}: not a {{key: DataStatistics}} pickle with keys {KEYS}")
+    return tokenizer_stats(obj)
 
 
 def model_dims(state_dict: Mapping[str, torch.Tensor]) -> Dict[str, int]:

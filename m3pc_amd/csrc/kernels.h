@@ -286,6 +286,8 @@ void launch_select(const SelectP& p, hipStream_t st);
 
 // indices of the k largest values (descending; ties -> lower index first), n <= 16384, k <= n
 void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st);
+// re-score window statistics over the kk best entries idx (best first); stats = {n, margin to the best entry outside, max, raw count}
+void launch_window_stats(const float* v, const int* idx, int kk, int kmin, int kmax, float window, float* stats, hipStream_t st);
 // dst[index[i]] = src[i]
 void launch_scatter(const float* src, const int* index, int n, float* dst, int* index_copy, hipStream_t st);  // + index_copy[i] = index[i]
 

@@ -1399,8 +1399,11 @@ int m3pc_set_critic(m3pc_handle* h, const m3pc_named_tensor* tensors, int n, con
                     void* stream) {
     if (!h || !tensors || !obs_mean || !obs_std) return fail(M3PC_EINVAL, "null argument");
     if (h->dm.critic_hidden <= 0) return fail(M3PC_EINVAL, "handle was created without a critic");
-    (void)stream;
+    hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->device));
+    // device tensors are read after everything already queued on the caller's stream (an optimizer step that has just
+    // updated qf, finetune.py:288-290): the blocking copies below are not ordered behind a non-blocking stream by themselves
+    HIPCHK(hipStreamSynchronize(st));
     const int Hd = h->dm.critic_hidden, SA = h->S + h->A;
     auto fetch = [&](const std::string& name, long long numel, std::vector<float>& out) -> int {
         const int i = find_tensor(tensors, n, name);
@@ -1618,6 +1621,28 @@ int m3pc_rescore_topk(m3pc_handle* h, const m3pc_plan_args* a, const float* stat
     CHK(m3pc_rescore(h, a, states, actions, rewards, eps, h->d_topk, k, nullptr, h->er_top, stream));
     launch_scatter(h->er_top, h->d_topk, k, expect_return, topk_index, st);
     return check_launch("rescore_topk");
+}
+
+int m3pc_topk_window(m3pc_handle* h, const float* expect_return, int n_total, int kmax, int kmin, float window, int* topk_index,
+                     float* stats, void* stream) {
+    if (!h || !expect_return || !topk_index || !stats) return fail(M3PC_EINVAL, "null argument");
+    if (n_total < 1 || n_total > 16384) return fail(M3PC_EINVAL, "top-k supports n_total <= 16384");
+    if (kmax < 1 || kmax > 1023 || kmin < 1 || kmin > kmax || !(window >= 0.f)) return fail(M3PC_EINVAL, "bad kmin/kmax/window");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->device));
+    const int kk = kmax + 1 < n_total ? kmax + 1 : n_total;
+    launch_topk(expect_return, n_total, kk, topk_index, st);
+    launch_window_stats(expect_return, topk_index, kk, kmin, kmax, window, stats, st);
+    return check_launch("topk_window");
+}
+
+int m3pc_rescore_listed(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* actions, const float* rewards,
+                        const float* eps, const int* index, int n, float* expect_return, void* stream) {
+    if (!h || !a || !expect_return || !index) return fail(M3PC_EINVAL, "null argument");
+    if (n < 1 || n > 1024) return fail(M3PC_EINVAL, "n %d outside [1, 1024]", n);
+    CHK(m3pc_rescore(h, a, states, actions, rewards, eps, index, n, nullptr, h->er_top, stream));
+    launch_scatter(h->er_top, index, n, expect_return, nullptr, (hipStream_t)stream);
+    return check_launch("rescore_listed");
 }
 
 int m3pc_select(m3pc_handle* h, const float* expect_return, const float* a0, long long a0_stride, int n, float temperature,

@@ -228,6 +228,30 @@ void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st) {
     hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), (size_t)np * 8, st, v, n, np, k, idx_out);
 }
 
+// idx: the kk best entries of v, best first.  n = clamp(#{i < kk: v[idx[i]] >= v[idx[0]] - window}, kmin, kmax) and the
+// distance from the best entry to the best one NOT among those n (infinity when there is none).
+__global__ __launch_bounds__(64) void window_stats_kernel(const float* v, const int* idx, int kk, int kmin, int kmax, float window,
+                                                          float* stats) {
+    const int lane = threadIdx.x;
+    const float mx = v[idx[0]];
+    int cnt = 0;
+    for (int i = lane; i < kk && i < kmax; i += 64) cnt += v[idx[i]] >= mx - window ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    int n = cnt < kmin ? kmin : cnt;
+    if (n > kmax) n = kmax;
+    if (n > kk) n = kk;
+    if (lane == 0) {
+        stats[0] = (float)n;
+        stats[1] = n < kk ? mx - v[idx[n]] : INFINITY;
+        stats[2] = mx;
+        stats[3] = (float)cnt;
+    }
+}
+void launch_window_stats(const float* v, const int* idx, int kk, int kmin, int kmax, float window, float* stats, hipStream_t st) {
+    hipLaunchKernelGGL(window_stats_kernel, dim3(1), dim3(64), 0, st, v, idx, kk, kmin, kmax, window, stats);
+}
+
 __global__ void scatter_kernel(const float* src, const int* index, int n, float* dst, int* index_copy) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {

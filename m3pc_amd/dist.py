@@ -30,6 +30,25 @@ def world_info(group=None) -> Tuple[int, int]:
     return 0, 1
 
 
+def check_same_generator(generator: torch.Generator, group=None) -> None:
+    """Every rank draws the candidate noise and the multinomial variates from its own generator; the sharded planner is
+    only correct when those streams are identical.  Compares seed and state over the group and raises on a mismatch."""
+    rank, world = world_info(group)
+    if world == 1:
+        return
+    st = generator.get_state()
+    h = int(torch.sum(st.to(torch.int64) * (torch.arange(st.numel(), dtype=torch.int64) % 65521 + 1)).item()) & 0x7FFFFFFFFFFFFFFF
+    mine = torch.tensor([generator.initial_seed() & 0x7FFFFFFFFFFFFFFF, h], dtype=torch.int64)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    mine = mine.to(dev)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    for r, o in enumerate(out):
+        if not torch.equal(o.cpu(), mine.cpu()):
+            raise RuntimeError(f"rank {rank}: torch.Generator seed/state differs from rank {r}; seed the planner's generator "
+                               "identically on every rank")
+
+
 def gather_candidates(er_shard: torch.Tensor, a0_shard: torch.Tensor, n_total: int, group=None):
     """All-gather per-shard scores (n_r,) and first actions (n_r, A) into full (N,) / (N, A) tensors in
     candidate order.  One collective: scores and actions travel in a single packed (n_r, 1+A) buffer,
@@ -37,6 +56,10 @@ def gather_candidates(er_shard: torch.Tensor, a0_shard: torch.Tensor, n_total: i
     rank, world = world_info(group)
     if world == 1:
         return er_shard, a0_shard
+    if er_shard.is_cuda and dist.get_backend(group) != "nccl":
+        # a CPU-only backend (gloo in the tests): the packed buffer travels through the host
+        er_h, a0_h = gather_candidates(er_shard.cpu(), a0_shard.cpu(), n_total, group)
+        return er_h.to(er_shard.device), a0_h.to(er_shard.device)
     A = a0_shard.shape[1]
     if n_total % world == 0:
         # equal shards (the usual case): pack with one cat, gather, one copy for the scores (the re-score writes into

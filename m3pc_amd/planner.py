@@ -37,12 +37,21 @@ class HipPlanner:
     def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], tokenizer_manager, q_state_dict=None,
                  obs_mean=None, obs_std=None, n_embd: int = 512, n_head: int = 4, n_enc_layer: int = 2,
                  n_dec_layer: int = 1, precision: str = "fp32", rescore_topk: int = 16, device: Optional[int] = None,
-                 group=None, generator: Optional[torch.Generator] = None, max_batch: int = 1):
+                 group=None, generator: Optional[torch.Generator] = None, max_batch: int = 1,
+                 rescore: str = "bound", rescore_min: int = 4, rescore_max: int = 64, rescore_delta: Optional[float] = None):
         """cfg: any object with traj_length, action_samples, horizon, discount, temperature, lmbda,
         plan_guidance (finetune.py RunConfig fields read at learner.py:276,319,342).
         tokenizer_manager: a TokenizerManager (this package's) or {key: {"mean","std","min","max"}}.
-        precision: "fp32" (reference-accurate) or "bf16" (bf16 MFMA candidate pass; the top
-        ``rescore_topk`` candidates are re-scored in fp32 so the arg-max does not depend on bf16 rounding)."""
+        precision: "fp32" (reference-accurate) or "bf16" (bf16 MFMA candidate pass followed by an fp32 re-score of the
+        candidates that can still be the arg-max, so that the arg-max does not depend on bf16 rounding):
+          rescore="bound" (default): every candidate whose bf16 score lies within 2*delta of the bf16 maximum is
+            re-scored (at least ``rescore_min``, at most ``rescore_max``).  delta bounds the bf16 error of score
+            DIFFERENCES: |(b_i - f_i) - median(b - f)| <= delta; then f_argmax >= f_j for all j implies
+            b_argmax >= b_max - 2 delta.  delta is calibrated per weight load on 64 candidates scored in both
+            arithmetics (1.5 x the largest deviation seen), or fixed by ``rescore_delta``.  ``planner.last`` reports
+            n_rescored, min_margin_outside (distance from the bf16 maximum to the best candidate NOT re-scored: the
+            bound held with room when it exceeds 2*delta) and delta.  One 16-byte device-to-host read per step.
+          rescore="topk": the fixed ``rescore_topk`` best candidates (round-1 behaviour, no host read)."""
         self.cfg = cfg
         self.group = group
         self.rank, self.world = mdist.world_info(group)
@@ -55,21 +64,28 @@ class HipPlanner:
         _, n_local = mdist.shard_range(N, 0, self.world)
         hidden = 0 if q_state_dict is None else q_state_dict["q1.net.0.weight"].shape[0]
         self.handle = capi.Handle(S, A, T, n_embd, n_head, n_enc_layer, n_dec_layer,
-                                  max_candidates=max(n_local, rescore_topk, 1), max_batch=max(int(max_batch), 1),
+                                  max_candidates=max(n_local, rescore_topk, int(rescore_max) if precision == "bf16" else 1, 1),
+                                  max_batch=max(int(max_batch), 1),
                                   critic_hidden=hidden,
                                   device=device)
         self.device = self.handle.device
         self.S, self.A, self.T = S, A, T
         self.precision = {"fp32": capi.PREC_FP32, "bf16": capi.PREC_BF16}[precision]
         self.rescore_topk = int(rescore_topk) if self.precision == capi.PREC_BF16 else 0
+        assert rescore in ("bound", "topk")
+        self.rescore = rescore if self.precision == capi.PREC_BF16 else "none"
+        self.rescore_min, self.rescore_max = int(rescore_min), int(rescore_max)
+        self._delta_fixed = None if rescore_delta is None else float(rescore_delta)
+        self._delta: Optional[float] = self._delta_fixed
         self.generator = generator
+        if self.world > 1:
+            # every rank draws eps / the multinomial variates itself: the streams must be the same ones
+            if generator is None:
+                raise ValueError("a sharded planner needs an explicit torch.Generator seeded identically on every rank")
+            mdist.check_same_generator(generator, group)
         if isinstance(tokenizer_manager, dict):
-            toks = {}
-            for k in KEYS:
-                s = tokenizer_manager[k]
-                toks[k] = ContinuousTokenizer(s["mean"], s["std"], DataStatistics(s["mean"], s["std"], s["min"], s["max"]),
-                                              normalize=(k != "actions"))
-            tokenizer_manager = TokenizerManager(toks)
+            # raw dataset statistics: build the tokenizers as ContinuousTokenizer.create does (std < 0.1 -> 1)
+            tokenizer_manager = TokenizerManager({k: ContinuousTokenizer.from_statistics(k, tokenizer_manager[k]) for k in KEYS})
         self.tokenizer_manager = tokenizer_manager.bind(self.handle)
         self.load_state_dict(state_dict)
         if q_state_dict is not None:
@@ -80,6 +96,7 @@ class HipPlanner:
     # ---------------------------------------------------------------------------------------- weights
     def load_state_dict(self, state_dict):
         self.handle.load_weights(state_dict)
+        self._delta = getattr(self, "_delta_fixed", None)  # the bf16 error bound belongs to the weights: re-calibrate
 
     def load_critic(self, q_state_dict, obs_mean, obs_std):
         self.handle.set_critic(q_state_dict, obs_mean, obs_std)
@@ -128,25 +145,54 @@ class HipPlanner:
         er, a0 = res["expect_return"], res["sample_actions"][:, 0]
         er, a0 = mdist.gather_candidates(er, a0, N, self.group)
         top = None
-        if self.rescore_topk > 0:
-            # replicated on every rank (identical inputs => identical result): top-k of the gathered scores,
-            # fp32 candidate pass on those k, scores written back in place
+        extra = {}
+        # the re-score is replicated on every rank (identical inputs => identical result): candidates chosen from the
+        # gathered scores, fp32 candidate pass on them, scores written back in place
+        if self.rescore == "topk" and self.rescore_topk > 0:
             top = self.handle.rescore_topk(mode, states, actions, rewards, eps, er, min(self.rescore_topk, N), h, rtg,
                                            float(lmbda), float(cfg.discount))
+        elif self.rescore == "bound":
+            rs = (mode, states, actions, rewards, eps)
+            tail = (h, rtg, float(lmbda), float(cfg.discount))
+            if self._delta is None:
+                self._delta = self._calibrate(er, rs, tail, N)
+            kmax, kmin = min(self.rescore_max, N - 1 if N > 1 else 1), min(self.rescore_min, N)
+            cand, stats = self.handle.topk_window(er, max(kmax, 1), max(min(kmin, kmax), 1), 2.0 * self._delta)
+            st = stats.cpu()  # the one host read of the step: how many candidates are inside the window
+            n_re = int(st[0])
+            top = cand[:n_re].contiguous()
+            self.handle.rescore_listed(mode, states, actions, rewards, eps, er, top, *tail)
+            extra = dict(n_rescored=n_re, n_in_window=int(st[3]), min_margin_outside=float(st[1]), delta=self._delta)
         # torch.multinomial(p, 1) == argmax(p / q), q ~ Exp(1) from the same generator (ATen's
         # multinomial fast path); drawing q here and finishing inside the select kernel gives the same index
         expo = torch.empty((N,), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
         p, eval_action, argmax, sample_idx, sample_action = self.handle.select(er, a0, float(cfg.temperature), expo)
         self.last = dict(expect_return=er, p=p, argmax=argmax, sample_idx=sample_idx, loc=res["loc"], std=res["std"],
-                         sample_actions=res["sample_actions"], eps=eps, topk=top)
+                         sample_actions=res["sample_actions"], eps=eps, topk=top, **extra)
         return sample_action, eval_action
+
+    def _calibrate(self, er_bf16, rs, tail, N, n_cal: int = 64) -> float:
+        """delta of the bound-driven re-score: fp32 scores of n_cal candidates (a fixed pseudo-random subset, the same
+        on every rank) against their bf16 scores; 1.5 x the largest deviation of (bf16 - fp32) from its median."""
+        g = torch.Generator().manual_seed(0x5eed)
+        ids = torch.randperm(N, generator=g)[: min(n_cal, N)].to(torch.int32).to(self.device)
+        f32, _ = self.handle.rescore(*rs, ids, tail[0], tail[1], tail[2], tail[3], N)
+        d = er_bf16[ids.long()] - f32
+        dev = float((d - d.median()).abs().max())
+        return max(1.5 * dev, 1e-6 * float(f32.abs().max()), 1e-30)
 
     @staticmethod
     def _split(trajectory):
         s, a, r = trajectory["states"][0], trajectory["actions"][0], trajectory["rewards"][0]
         rtg = trajectory.get("_rtg")
         if rtg is None:
-            rtg = float(trajectory["returns"].reshape(-1)[0])  # device sync; action_sample passes _rtg
+            ret = trajectory["returns"].reshape(-1)  # device sync; action_sample passes _rtg
+            rtg = float(ret[0])
+            # the library conditions on ONE return-to-go (what action_sample builds, learner.py:368-385); a window with
+            # varying returns is legal in the reference but not representable here: refuse it instead of mis-planning
+            if not bool((ret == ret[0]).all()):
+                raise ValueError("trajectory['returns'] must be constant over the window (rtg_guiding is called by "
+                                 "action_sample with a constant return-to-go, learner.py:368-385)")
         return s.float().contiguous(), a.float().contiguous(), r.float().contiguous(), float(rtg)
 
     @torch.no_grad()

@@ -57,6 +57,18 @@ class ContinuousTokenizer:
             return cls(data_mean, data_std, stats, normalize=False)
         return cls(data_mean, data_std, stats, normalize=normalize)
 
+    @classmethod
+    def from_statistics(cls, key: str, stats) -> "ContinuousTokenizer":
+        """The tokenizer ``create`` builds, from RAW dataset statistics given as a dict or an object with
+        mean / std / min / max (what the reference caches in /tmp/d4rl/d4rl_statistics_*.pkl,
+        sequence_dataset.py:357-395): std < 0.1 -> 1 (continuous.py:58), actions never normalised (59-61)."""
+        get = (lambda n: stats[n]) if isinstance(stats, dict) else (lambda n: getattr(stats, n))
+        mean = np.array(get("mean"), dtype=np.float32)
+        std = np.array(get("std"), dtype=np.float32)
+        std[std < 0.1] = 1
+        ds = DataStatistics(mean, std, np.asarray(get("min"), dtype=np.float32), np.asarray(get("max"), dtype=np.float32))
+        return cls(mean, std, ds, normalize=(key != "actions"))
+
     @property
     def discrete(self) -> bool:
         return False

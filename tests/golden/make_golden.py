@@ -146,9 +146,9 @@ def npf(x):
     return np.ascontiguousarray(x.detach().cpu().numpy()) if torch.is_tensor(x) else np.asarray(x)
 
 
-def run_guiding(L, dims, mode, path_length, rtg, eps=None, seed_sel=77, noise_seed=None, taps=None):
+def run_guiding(L, dims, mode, path_length, rtg, eps=None, seed_sel=77, noise_seed=None, taps=None, hist_seed=0):
     """Call action_sample -> <mode> on the reference and return the captured locals."""
-    hist = hist_with_len(dims, 0, path_length)
+    hist = hist_with_len(dims, hist_seed, path_length)
     fname = {"rtg": "rtg_guiding", "critic": "critic_lambda_guiding", "noise": "noise_adding_lambda"}[mode]
     L.cfg.plan_guidance = fname
     handles = []
@@ -286,6 +286,46 @@ def g2(which=None):
         print(f"g2 {name} written in {time.time() - t0:.1f}s")
 
 
+G5_CASES = [(env, mode, wseed, hseed, pl) for env, mode in (("hopper", "rtg"), ("walker2d", "critic"))
+            for wseed in (0, 1, 2) for hseed, pl in ((10, 200), (11, 237), (12, 31), (13, 998))]
+
+
+def g5():
+    """Arg-max pins for the bf16 + fp32-re-score path: 2 envs x 3 weight seeds x 4 windows at
+    N=256, H=16, T=32, full-size model, plus one exact tie (two candidates with the same noise)."""
+    N, H, T = 256, 16, 32
+    out = dict(meta=str(META), cases=np.array([f"{e}:{m}:{w}:{hs}:{pl}" for e, m, w, hs, pl in G5_CASES]), cfg=np.array([N, H, T]))
+    t0 = time.time()
+    for ci, (env, mode, wseed, hseed, pl) in enumerate(G5_CASES):
+        S, A = synth.ENV_DIMS[env]
+        dims = synth.Dims(S, A, T)
+        temp = 0.01 if mode == "rtg" else 1.0
+        L = build_reference(dims, dict(action_samples=N, horizon=H, discount=0.99, temperature=temp, lmbda=0.6, plan_guidance=""),
+                            seed=wseed)
+        eps = synth.make_eps(N, dims, seed=100 + ci)
+        loc = run_guiding(L, dims, mode, pl, rtg=3.0, eps=eps, hist_seed=hseed)
+        er = loc["expect_return"]
+        out[f"er_{ci}"] = npf(er)
+        out[f"argmax_{ci}"] = np.array(int(torch.argmax(er)))
+        out[f"eval_action_{ci}"] = npf(loc["eval_action"])
+        out[f"horizon_{ci}"] = np.array(int(loc["_horizon"]))
+        if ci == 0:  # the tie: copy the winner's noise onto a later candidate -> two equal maxima, torch.argmax takes the first
+            am = int(torch.argmax(er))
+            j = (am + 57) % N
+            eps2 = eps.clone()
+            eps2[j] = eps2[am]
+            loc2 = run_guiding(L, dims, mode, pl, rtg=3.0, eps=eps2, hist_seed=hseed)
+            er2 = loc2["expect_return"]
+            assert float(er2[j]) == float(er2[am]) == float(er2.max())
+            out["tie_pair"] = np.array([am, j])
+            out["tie_er"] = npf(er2)
+            out["tie_argmax"] = np.array(int(torch.argmax(er2)))
+            out["tie_eval_action"] = npf(loc2["eval_action"])
+        print(f"g5 case {ci} {env} w{wseed} h{hseed} pl{pl}: argmax {int(out[f'argmax_{ci}'])} ({time.time() - t0:.0f}s)", flush=True)
+    np.savez_compressed(os.path.join(HERE, "g5_argmax.npz"), **out)
+    print("g5 written")
+
+
 def g3():
     """Zero-shot goal reaching, two-pass piid + single-pass id, E=4 windows."""
     dims = synth.Dims(11, 3, 8)
@@ -343,7 +383,7 @@ def g4():
 
 if __name__ == "__main__":
     check_normal_identity()
-    todo = sys.argv[1:] or ["g1", "g4", "g3", "g2"]
+    todo = sys.argv[1:] or ["g1", "g4", "g3", "g2", "g5"]
     for t in todo:
         if t == "g1":
             g1()
@@ -351,6 +391,8 @@ if __name__ == "__main__":
             g3()
         elif t == "g4":
             g4()
+        elif t == "g5":
+            g5()
         elif t == "g2":
             g2()
         elif t.startswith("g2:"):

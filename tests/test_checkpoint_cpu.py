@@ -55,3 +55,65 @@ def test_statistics_accept_dataclass_like_objects_and_dicts():
     bad["states"]["min"] = bad["states"]["max"] + 1.0
     with pytest.raises(ValueError):
         checkpoint.tokenizer_stats(bad)
+
+
+def test_small_std_is_clamped_like_the_reference_create():
+    """continuous.py:58: a dimension whose dataset std is below 0.1 is tokenized with std 1."""
+    from m3pc_amd.tokenizers import ContinuousTokenizer
+    from oracle import mtm_oracle as O
+
+    dims = synth.Dims(11, 3, 8)
+    st = synth.make_tokenizer_stats(dims, 0)
+    st["states"]["std"] = st["states"]["std"].copy()
+    st["states"]["std"][[1, 7]] = [0.05, 0.0999]
+    st["rewards"]["std"] = np.array([0.01], dtype=np.float32)
+    raw = {k: {n: np.array(v[n]) for n in v} for k, v in st.items()}
+    toks = {k: ContinuousTokenizer.from_statistics(k, checkpoint.tokenizer_stats(raw)[k]) for k in synth.KEYS}
+    assert toks["states"]._data_std[1] == 1 and toks["states"]._data_std[7] == 1 and toks["states"]._data_std[0] == st["states"]["std"][0]
+    assert float(toks["rewards"]._data_std[0]) == 1.0 and not toks["actions"].normalize and toks["returns"].normalize
+    assert raw["states"]["std"][1] == np.float32(0.05)  # the caller's arrays are left alone
+    # the oracle's tokenizer with the clamped std is what the reference computes: (x - mean) / 1
+    x = torch.randn(2, 8, 11)
+    ost = O.Stats(toks["states"]._data_mean.numpy(), toks["states"]._data_std.numpy(), st["states"]["min"], st["states"]["max"], True)
+    enc = O.tok_encode(x, ost)
+    assert torch.allclose(enc[..., 0, 1], x[..., 1] - float(st["states"]["mean"][1]))
+
+
+def test_statistics_pickle_reader(tmp_path):
+    """sequence_dataset.py:357-404 caches {key: DataStatistics} with pickle; the reader rebuilds it without importing
+    the reference and refuses anything else."""
+    import pickle
+    import sys as _sys
+    import types as _types
+
+    dims = synth.Dims(11, 3, 8)
+    st = synth.make_tokenizer_stats(dims, 0)
+    # a stand-in module with the reference's class path, only to WRITE a pickle shaped like the reference's
+    mod = _types.ModuleType("research.omtm.datasets.base")
+
+    class DataStatistics:
+        def __init__(self, mean, std, min, max):
+            self.mean, self.std, self.min, self.max = mean, std, min, max
+
+    DataStatistics.__module__ = "research.omtm.datasets.base"
+    DataStatistics.__qualname__ = "DataStatistics"
+    mod.DataStatistics = DataStatistics
+    for name in ("research", "research.omtm", "research.omtm.datasets"):
+        _sys.modules.setdefault(name, _types.ModuleType(name))
+    _sys.modules["research.omtm.datasets.base"] = mod
+    try:
+        path = tmp_path / "d4rl_statistics_hopper-medium-v2_8_0.99.pkl"
+        with open(path, "wb") as f:
+            pickle.dump({k: DataStatistics(v["mean"], v["std"], v["min"], v["max"]) for k, v in st.items()}, f)
+    finally:
+        for name in ("research.omtm.datasets.base", "research.omtm.datasets", "research.omtm", "research"):
+            _sys.modules.pop(name, None)
+    got = checkpoint.load_statistics_pickle(str(path))
+    for k in synth.KEYS:
+        for n in ("mean", "std", "min", "max"):
+            assert np.array_equal(got[k][n], st[k][n].astype(np.float32))
+    evil = tmp_path / "evil.pkl"
+    with open(evil, "wb") as f:
+        pickle.dump({k: os.system for k in synth.KEYS}, f)
+    with pytest.raises(Exception):
+        checkpoint.load_statistics_pickle(str(evil))

@@ -190,3 +190,27 @@ def test_g3_zeroshot(pl):
     _close(loc2, g[pre + "loc"], 1e-5, 1e-5, "id loc")
     _close(std2, g[pre + "std"], 1e-5, 1e-6, "id std")
     _close(torch.tanh(loc2)[0, 8 - h], g[pre + "eval_action"], 1e-5, 1e-5, "id eval_action")
+
+
+# ------------------------------------------------------------------------------------- G5 arg-max pins (other weights / windows)
+@pytest.mark.parametrize("ci", [1, 10, 15, 20])  # one case per (env, weight seed) corner incl. an early and a late window
+def test_g5_other_weights_and_windows(ci):
+    """The oracle against the reference on weight seeds / history seeds / path lengths other than G2's (g5_argmax.npz,
+    tests/golden/make_golden.py g5): scores to 2e-5 of scale, identical arg-max, eval_action."""
+    g = _load("g5_argmax.npz")
+    N, H, T = [int(v) for v in g["cfg"]]
+    env, mode, wseed, hseed, pl = str(g["cases"][ci]).split(":")
+    wseed, hseed, pl = int(wseed), int(hseed), int(pl)
+    S, A = synth.ENV_DIMS[env]
+    dims = synth.Dims(S, A, T)
+    cfg = O.PlanCfg(T, H, N, 0.99, 0.01 if mode == "rtg" else 1.0, 0.6)
+    win, h = O.assemble_window(cfg, synth.make_history(dims, hseed), pl, 3.0)
+    assert h == int(g[f"horizon_{ci}"])
+    r = O.guiding(synth.make_state_dict(dims, wseed), O.make_stats(synth.make_tokenizer_stats(dims, wseed)), cfg, win, h, 0.6,
+                  synth.make_eps(N, dims, 100 + ci), mode, critic=synth.make_critic(dims, wseed),
+                  generator=torch.Generator().manual_seed(77))
+    er = (r["expect_return"] - r["expect_return"].max()).numpy()
+    scale = max(1.0, float(np.abs(r["expect_return"].numpy()).max()))
+    _close(er, g[f"er_{ci}"], rtol=0, atol=2e-5 * scale, what="expect_return")
+    assert r["argmax"] == int(g[f"argmax_{ci}"])
+    _close(r["eval_action"], g[f"eval_action_{ci}"], rtol=1e-4, atol=1e-5, what="eval_action")
