@@ -144,6 +144,29 @@ int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* args, const float* stat
                    const float* rewards, const float* eps, float* loc, float* std, float* sample_actions,
                    float* expect_return, float* pred_rewards, float* pred_boot, void* stream);
 
+/* Score caller-supplied candidate action sequences: learner.py:288-316 (from the overwrite of the window's future actions
+ * on), without the policy pass and without sampling.  Serves the fp32 re-score of batched plans, CEM-style refinement
+ * (sequence_dataset.py:919-1000) and any caller that brings its own candidates.
+ *   n_windows E >= 1 history windows: states (E,T,S), actions (E,T,A), rewards (E,T,1) device, raw (un-normalised)
+ *   cand            device (n_count,h,A): the candidates' actions of the last h steps (rows < T-h come from the window)
+ *   window_index    device (n_count,) int32: the window each candidate continues; NULL = all window 0 (E == 1)
+ *   args            mode (RTG or CRITIC scoring), precision, horizon, n_count, lmbda, discount are read
+ *   expect_return   device out (n_count,); pred_rewards / pred_boot device out (n_count,h), optional */
+int m3pc_score_actions(m3pc_handle* h, const m3pc_plan_args* args, int n_windows, const float* states,
+                       const float* actions, const float* rewards, const float* cand, const int* window_index,
+                       float* expect_return, float* pred_rewards, float* pred_boot, void* stream);
+
+/* m3pc_plan_step for E independent windows in one pass of the kernels (the counterpart of a rollout loop that steps E
+ * environments: replay_buffer.py:204-232 / learner.py:681-691 plan one window per call): policy pass at batch E,
+ * args->n_total candidates per window, one candidate pass over all E * n_total rows.  All windows share the horizon.
+ *   states (E,T,S), actions (E,T,A), rewards (E,T,1) device;  rtg host (E,) doubles
+ *   eps device (E, n_total, T, A) [RTG/CRITIC] or (E, n_total, h, A) [NOISE];  window_index device (E*n_total,) int32 = c / n_total
+ *   loc, std device out (E,T,A), optional;  sample_actions device out (E*n_total,h,A);  expect_return device out (E*n_total,) */
+int m3pc_plan_step_batch(m3pc_handle* h, const m3pc_plan_args* args, int n_windows, const float* states,
+                         const float* actions, const float* rewards, const double* rtg, const float* eps,
+                         const int* window_index, float* loc, float* std, float* sample_actions, float* expect_return,
+                         void* stream);
+
 /* fp32 re-scoring of an arbitrary subset of the candidates of the LAST m3pc_plan_step on this handle
  * (its policy-pass loc/std are reused; same window, eps and args as that call, args->precision ignored).
  * Used after a bf16 candidate pass to make the reported arg-max independent of bf16 rounding: the same

@@ -25,7 +25,8 @@ ABI_VERSION = 1
 EXPORTS = (
     "m3pc_last_error", "m3pc_abi_version", "m3pc_create", "m3pc_destroy", "m3pc_load_weights",
     "m3pc_set_tokenizer", "m3pc_set_critic", "m3pc_tokenize", "m3pc_detokenize", "m3pc_forward",
-    "m3pc_plan_step", "m3pc_rescore", "m3pc_rescore_topk", "m3pc_topk_window", "m3pc_rescore_listed", "m3pc_select",
+    "m3pc_plan_step", "m3pc_plan_step_batch", "m3pc_score_actions", "m3pc_rescore", "m3pc_rescore_topk", "m3pc_topk_window",
+    "m3pc_rescore_listed", "m3pc_select",
     "m3pc_profile_enable",
     "m3pc_profile_read",
 )
@@ -78,6 +79,8 @@ def load_library(path: Optional[str] = None):
         "m3pc_detokenize": [vp, i, vp, vp, ll, vp],
         "m3pc_forward": [vp, i, C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp, vp, i, vp],
         "m3pc_plan_step": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "m3pc_plan_step_batch": [vp, C.POINTER(PlanArgs), i, vp, vp, vp, C.POINTER(d), vp, vp, vp, vp, vp, vp, vp],
+        "m3pc_score_actions": [vp, C.POINTER(PlanArgs), i, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_rescore": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, i, vp, vp, vp],
         "m3pc_rescore_topk": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, i, vp, vp],
         "m3pc_topk_window": [vp, vp, i, i, i, f, vp, vp, vp],
@@ -235,6 +238,43 @@ class Handle:
         if want_debug:
             res["pred_rewards"], res["pred_boot"] = pr, pb
         return res
+
+    def plan_step_batch(self, mode: int, states, actions, rewards, rtg, eps, horizon: int, lmbda: float, discount: float,
+                        n_total: int, precision: int = PREC_FP32):
+        """E windows x n_total candidates in one pass: states (E,T,S), actions (E,T,A), rewards (E,T,1), rtg (E,) floats,
+        eps (E, n_total, T|h, A).  Returns expect_return (E, n_total), sample_actions (E, n_total, h, A), loc/std (E,T,A)."""
+        E = states.shape[0]
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        loc = torch.empty((E, self.T, self.A), **f32)
+        std = torch.empty((E, self.T, self.A), **f32)
+        acts = torch.empty((E, n_total, horizon, self.A), **f32)
+        er = torch.empty((E, n_total), **f32)
+        widx = torch.arange(E, dtype=torch.int32, device=dev).repeat_interleave(n_total).contiguous()
+        args = PlanArgs(mode, precision, horizon, n_total, 0, n_total, lmbda, discount, 0.0)
+        ins = [t.to(torch.float32).contiguous() for t in (states, actions, rewards, eps)]
+        assert ins[3].numel() == E * n_total * (horizon if mode == MODE_NOISE else self.T) * self.A
+        rt = (C.c_double * E)(*[float(v) for v in rtg])
+        check(self.lib.m3pc_plan_step_batch(self._h, C.byref(args), E, _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), rt, _ptr(ins[3]),
+                                            _ptr(widx), _ptr(loc), _ptr(std), _ptr(acts), _ptr(er), _stream(dev)))
+        return dict(loc=loc, std=std, sample_actions=acts, expect_return=er, window_index=widx)
+
+    def score_actions(self, mode: int, states, actions, rewards, cand: torch.Tensor, window_index: Optional[torch.Tensor],
+                      horizon: int, lmbda: float, discount: float, precision: int = PREC_FP32, want_debug: bool = False):
+        """TD(lambda) scores of caller-supplied candidates cand (n,h,A); states/actions/rewards (E,T,.) or (T,.) windows,
+        window_index (n,) int32 (None: one window)."""
+        dev = self.device
+        n = cand.shape[0]
+        ins = [t.to(torch.float32).contiguous() for t in (states, actions, rewards, cand)]
+        E = 1 if ins[0].dim() == 2 else ins[0].shape[0]
+        er = torch.empty((n,), dtype=torch.float32, device=dev)
+        pr = torch.empty((n, horizon), dtype=torch.float32, device=dev) if want_debug else None
+        pb = torch.empty((n, horizon), dtype=torch.float32, device=dev) if want_debug else None
+        wi = None if window_index is None else window_index.to(torch.int32).contiguous()
+        args = PlanArgs(mode, precision, horizon, n, 0, n, lmbda, discount, 0.0)
+        check(self.lib.m3pc_score_actions(self._h, C.byref(args), E, _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), _ptr(ins[3]),
+                                          _ptr(wi), _ptr(er), _ptr(pr), _ptr(pb), _stream(dev)))
+        return (er, pr, pb) if want_debug else er
 
     def rescore(self, mode: int, states, actions, rewards, eps, index: torch.Tensor, horizon: int, rtg: float,
                 lmbda: float, discount: float, n_total: int):

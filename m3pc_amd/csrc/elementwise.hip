@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedP p) {
     const int2 kt = p.tokmap[j];
     const int key = kt.x, t = kt.y;
     const int D = p.feat[key];
-    const float* x = p.tok[key] + (long long)b * p.bstride[key] + (long long)t * D;
+    const float* x = p.tok[key] + (long long)b * p.bstride[key] + (p.widx ? (long long)p.widx[b] * p.wstride[key] : 0) + (long long)t * D;
     __shared__ float xs[32];
     if (threadIdx.x < D) {
         float v = x[threadIdx.x];
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(EmbedP p, int CB, int n
     float4 x[NV], y[NV];
     for (int b = b0; b < b1; ++b) {
         if (b == b0 || !indep) {
-            const float* xin = p.tok[key] + (long long)b * p.bstride[key] + (long long)t * D;
+            const float* xin = p.tok[key] + (long long)b * p.bstride[key] + (p.widx ? (long long)p.widx[b] * p.wstride[key] : 0) + (long long)t * D;
 #pragma unroll
             for (int i = 0; i < NV; ++i) x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int f = 0; f < D; ++f) {
@@ -556,8 +556,8 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleP p) {
     const long long tot = (long long)p.n_count * p.T * p.A;
     if (blockIdx.x == 0) {
         for (int x = threadIdx.x; x < p.T * p.A; x += blockDim.x) {
-            if (p.loc_out) p.loc_out[x] = p.loc[x];
-            if (p.sd_out) p.sd_out[x] = p.sd[x];
+            if (p.loc_out && p.loc) p.loc_out[x] = p.loc[x];
+            if (p.sd_out && p.sd) p.sd_out[x] = p.sd[x];
         }
     }
     for (long long x = blockIdx.x * (long long)blockDim.x + threadIdx.x; x < tot; x += (long long)gridDim.x * blockDim.x) {
@@ -566,11 +566,13 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleP p) {
         const long long n = x / ((long long)p.A * p.T);
         float v;
         if (t < p.idx) {
-            v = p.hist_actions[t * p.A + a];
+            v = p.hist_actions[(p.widx ? (long long)p.widx[n] * p.T * p.A : 0) + t * p.A + a];
         } else {
             const int ta = t * p.A + a;
             const long long src = p.index ? (long long)p.index[n] : p.n_begin + n;
-            if (p.mode == 0) {
+            if (p.mode == 2) {
+                v = p.eps[(src * p.h + (t - p.idx)) * p.A + a];
+            } else if (p.mode == 0) {
                 const float e = p.eps[(src * p.T + t) * p.A + a];
                 v = tanhf(__fadd_rn(__fmul_rn(e, p.sd[ta]), p.loc[ta]));
             } else {
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleP p) {
                 v = __fadd_rn(tanhf(p.loc[ta]), __fmul_rn(e, 0.09f));
                 v = fminf(fmaxf(v, -0.99999f), 0.99999f);
             }
-            p.sample_actions[(n * p.h + (t - p.idx)) * p.A + a] = v;
+            if (p.sample_actions) p.sample_actions[(n * p.h + (t - p.idx)) * p.A + a] = v;
         }
         p.cand[x] = v;
     }

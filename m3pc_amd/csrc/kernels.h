@@ -159,6 +159,8 @@ void launch_attention_bf16(const AttnP& p, hipStream_t st);
 struct EmbedP {
     const float* tok[4];     // per key: (.., T, D_k) inputs
     long long bstride[4];    // batch stride in floats (0 = shared by the batch)
+    const int* widx;         // optional (batch,): batch element b reads window widx[b] of the inputs ...
+    long long wstride[4];    // ... at tok[k] + widx[b] * wstride[k] (+ b * bstride[k])
     int normalize[4];        // apply (x - mean) / std
     const float* mean[4];
     const float* stdv[4];
@@ -228,8 +230,9 @@ struct SampleP {
     const float* hist_actions;  // (T, A)
     const float* loc;           // (T, A)
     const float* sd;            // (T, A)
-    const float* eps;           // mode 0: (n_total, T, A); mode 1: (n_total, h, A)
+    const float* eps;           // mode 0: (n_total, T, A); mode 1: (n_total, h, A); mode 2: the candidates themselves (n_total, h, A)
     int mode, T, A, idx, h, n_begin, n_count;
+    const int* widx;            // optional (n_count,): candidate n takes its history rows from window widx[n] of hist_actions (., T, A)
     const int* index;           // optional (n_count,): candidate n reads eps row index[n] instead of n_begin+n
     float* cand;                // (n_count, T, A)
     float* sample_actions;      // (n_count, h, A)

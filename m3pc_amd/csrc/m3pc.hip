@@ -560,6 +560,8 @@ struct TokIn {
     const float* ptr[4];
     long long bstride[4];
     int normalize[4];
+    const int* widx = nullptr;  // optional per-batch-element window index into ptr[k] (stride wstride[k])
+    long long wstride[4] = {0, 0, 0, 0};
 };
 
 // embed + encoder stack + encoder.norm -> EncOut (fp32) [and bf16 copy in Z when dt == bf16 and want_b]
@@ -579,6 +581,7 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
     for (int k = 0; k < 4; ++k) {
         e.tok[k] = in.ptr[k];
         e.bstride[k] = in.bstride[k];
+        e.wstride[k] = in.wstride[k];
         e.normalize[k] = in.normalize[k];
         e.mean[k] = h->tok_mean[k];
         e.stdv[k] = h->tok_std[k];
@@ -586,6 +589,7 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
         e.E[k] = h->Eenc[k];
         e.feat[k] = h->feat[k];
     }
+    e.widx = in.widx;
     e.tokmap = pl->d_tokmap;
     e.batch = batch;
     e.L = pl->Le;
@@ -904,9 +908,11 @@ int build_tables(m3pc_handle* h, Plan* pl, int qi, int dt, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------- candidate pass
+// widx (optional, device (n,)): candidate c belongs to history window widx[c] of states (., T, S) / rewards (., T, 1);
+// without it all candidates share window 0 and the history tokens are computed once (first-layer sharing).
 int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* rewards, int n,
                    const float* sample_actions, float* expect_return, float* pred_rewards, float* pred_boot, int dt,
-                   hipStream_t st) {
+                   hipStream_t st, const int* widx = nullptr) {
     const int T = h->T, d = h->d, hh = a->horizon, idx = T - hh;
     const size_t es = dtype_size(dt);
     std::vector<unsigned char> m[4];
@@ -933,8 +939,12 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     in.normalize[M3PC_ACTIONS] = h->tok_norm[M3PC_ACTIONS];
     in.ptr[M3PC_REWARDS] = rewards;
     in.ptr[M3PC_RETURNS] = h->rtok;
+    in.widx = widx;
+    in.wstride[M3PC_STATES] = (long long)T * h->S;
+    in.wstride[M3PC_REWARDS] = T;
     // encoder order is states 0..idx, actions 0..T-1: everything before actions[idx] is history, shared by all candidates
-    CHK(run_encoder(h, pl, in, n, dt, st, dt == DT_BF16, (idx + 1) + idx));
+    // of one window
+    CHK(run_encoder(h, pl, in, n, dt, st, dt == DT_BF16, widx ? 0 : (idx + 1) + idx));
 
     // decoder inputs of the un-masked tokens (kept sets are prefixes 0..kept-1 for the fd mask)
     const void* enc_op = dt == DT_BF16 ? h->Z : (const void*)h->EncOut;
@@ -1242,7 +1252,7 @@ int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out) {
     CHK(dmalloc(&h->cand, (size_t)D.max_candidates * T * h->A));
     CHK(dmalloc(&h->loc, (size_t)D.max_batch * T * h->A + 64));
     CHK(dmalloc(&h->sd, (size_t)D.max_batch * T * h->A + 64));
-    CHK(dmalloc(&h->rtok, (size_t)T));
+    CHK(dmalloc(&h->rtok, (size_t)D.max_batch * T));
     CHK(dmalloc(&h->pred[0], (size_t)D.max_candidates * T * 32));
     CHK(dmalloc(&h->pred[1], (size_t)D.max_candidates * T * 32));
     CHK(dmalloc(&h->qv, (size_t)D.max_candidates * T));
@@ -1573,6 +1583,125 @@ int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         return rc;
     }
     return candidate_pass(h, a, states, rewards, n, sample_actions, expect_return, pred_rewards, pred_boot, dt, st);
+}
+
+// fills h->rtok[w * T + t] with window w's normalised return-to-go (float64 normalisation then cast: learner.py:371-374,
+// continuous.py:74-79)
+static int fill_rtok(m3pc_handle* h, const double* rtg, int n_windows, hipStream_t st) {
+    for (int w = 0; w < n_windows; ++w) {
+        double rt = rtg[w];
+        if (h->tok_norm[M3PC_RETURNS]) rt = (rt - (double)h->h_mean[M3PC_RETURNS][0]) / (double)h->h_std[M3PC_RETURNS][0];
+        launch_fill(h->rtok + (size_t)w * h->T, (float)rt, h->T, st);
+    }
+    return 0;
+}
+
+int m3pc_score_actions(m3pc_handle* h, const m3pc_plan_args* a, int n_windows, const float* states, const float* actions,
+                       const float* rewards, const float* cand, const int* window_index, float* expect_return,
+                       float* pred_rewards, float* pred_boot, void* stream) {
+    if (!h || !a || !states || !actions || !rewards || !cand || !expect_return) return fail(M3PC_EINVAL, "null argument");
+    if (!h->weights_loaded) return fail(M3PC_ESTATE, "weights not loaded");
+    for (int k = 0; k < 4; ++k)
+        if (!h->tok_set[k]) return fail(M3PC_ESTATE, "tokenizer '%s' not set", KEYN[k]);
+    const int T = h->T, n = a->n_count;
+    if (a->horizon < 1 || a->horizon > T) return fail(M3PC_EINVAL, "horizon %d outside [1, T=%d]", a->horizon, T);
+    if (a->mode != M3PC_MODE_RTG && a->mode != M3PC_MODE_CRITIC) return fail(M3PC_EINVAL, "mode must be RTG or CRITIC scoring");
+    if (a->precision != M3PC_PREC_FP32 && a->precision != M3PC_PREC_BF16) return fail(M3PC_EINVAL, "bad precision");
+    if (n < 1 || n > h->dm.max_candidates) return fail(M3PC_ENOMEM, "n_count %d outside [1, max_candidates=%d]", n, h->dm.max_candidates);
+    if (n_windows < 1 || (n_windows > 1 && !window_index)) return fail(M3PC_EINVAL, "n_windows > 1 needs window_index");
+    if (a->mode == M3PC_MODE_CRITIC && !h->critic_set) return fail(M3PC_ESTATE, "critic weights not set");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->device));
+    SampleP sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.hist_actions = actions;
+    sp.eps = cand;
+    sp.mode = 2;
+    sp.T = T;
+    sp.A = h->A;
+    sp.idx = T - a->horizon;
+    sp.h = a->horizon;
+    sp.n_count = n;
+    sp.widx = window_index;
+    sp.cand = h->cand;
+    launch_sample(sp, st);
+    const int dt = a->precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32;
+    // (split-K is row-count dependent: only where the caller does not rely on sharding exactness, i.e. the fp32 re-scores)
+    h->allow_splitk = dt == DT_F32;
+    const int rc = candidate_pass(h, a, states, rewards, n, cand, expect_return, pred_rewards, pred_boot, dt, st, window_index);
+    h->allow_splitk = false;
+    return rc;
+}
+
+int m3pc_plan_step_batch(m3pc_handle* h, const m3pc_plan_args* a, int n_windows, const float* states, const float* actions,
+                         const float* rewards, const double* rtg, const float* eps, const int* window_index, float* loc,
+                         float* std_, float* sample_actions, float* expect_return, void* stream) {
+    if (!h || !a || !states || !actions || !rewards || !rtg || !eps || !window_index || !sample_actions || !expect_return)
+        return fail(M3PC_EINVAL, "null argument");
+    if (!h->weights_loaded) return fail(M3PC_ESTATE, "weights not loaded");
+    for (int k = 0; k < 4; ++k)
+        if (!h->tok_set[k]) return fail(M3PC_ESTATE, "tokenizer '%s' not set", KEYN[k]);
+    const int T = h->T, E = n_windows, N = a->n_total;
+    if (E < 1 || E > h->dm.max_batch) return fail(M3PC_ENOMEM, "n_windows %d outside [1, max_batch=%d]", E, h->dm.max_batch);
+    if (a->horizon < 1 || a->horizon > T) return fail(M3PC_EINVAL, "horizon %d outside [1, T=%d]", a->horizon, T);
+    if (a->mode < 0 || a->mode > 2) return fail(M3PC_EINVAL, "bad mode %d", a->mode);
+    if (a->precision != M3PC_PREC_FP32 && a->precision != M3PC_PREC_BF16) return fail(M3PC_EINVAL, "bad precision");
+    if (N < 1 || (long long)E * N > h->dm.max_candidates)
+        return fail(M3PC_ENOMEM, "n_windows * n_total = %lld > max_candidates %d", (long long)E * N, h->dm.max_candidates);
+    if (a->mode != M3PC_MODE_RTG && !h->critic_set) return fail(M3PC_ESTATE, "critic weights not set");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->device));
+    const int hh = a->horizon, idx = T - hh, A = h->A;
+    CHK(fill_rtok(h, rtg, E, st));
+    // PASS 1 for all windows at once: return-conditioned policy, batch E, rcbc mask, fp32
+    std::vector<unsigned char> m[4];
+    for (int k = 0; k < 4; ++k) m[k].assign(T, 0);
+    for (int t = 0; t <= idx; ++t) m[M3PC_STATES][t] = 1;
+    for (int t = 0; t < idx; ++t) m[M3PC_ACTIONS][t] = 1;
+    for (int t = 0; t < T; ++t) m[M3PC_RETURNS][t] = 1;
+    const unsigned char* mp[4] = {m[0].data(), m[1].data(), m[2].data(), m[3].data()};
+    Plan* pl = nullptr;
+    CHK(get_plan(h, mp, &pl));
+    TokIn in;
+    memset(&in, 0, sizeof(in));
+    in.ptr[M3PC_STATES] = states;
+    in.bstride[M3PC_STATES] = (long long)T * h->S;
+    in.normalize[M3PC_STATES] = h->tok_norm[M3PC_STATES];
+    in.ptr[M3PC_ACTIONS] = actions;
+    in.bstride[M3PC_ACTIONS] = (long long)T * A;
+    in.normalize[M3PC_ACTIONS] = h->tok_norm[M3PC_ACTIONS];
+    in.ptr[M3PC_REWARDS] = rewards;
+    in.bstride[M3PC_REWARDS] = T;
+    in.normalize[M3PC_REWARDS] = h->tok_norm[M3PC_REWARDS];
+    in.ptr[M3PC_RETURNS] = h->rtok;
+    in.bstride[M3PC_RETURNS] = T;
+    h->allow_splitk = true;
+    CHK(forward_impl(h, pl, in, E, nullptr, nullptr, nullptr, h->loc, h->sd, DT_F32, st));
+    h->allow_splitk = false;
+    h->policy_valid = false;  // (m3pc_rescore works on the single-window state; batched callers re-score with m3pc_score_actions)
+    // candidates of window w: rows [w N, (w+1) N) of cand / sample_actions, drawn from window w's policy head and eps block
+    for (int w = 0; w < E; ++w) {
+        SampleP sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.hist_actions = actions + (size_t)w * T * A;
+        sp.loc = h->loc + (size_t)w * T * A;
+        sp.sd = h->sd + (size_t)w * T * A;
+        const size_t per = a->mode == M3PC_MODE_NOISE ? (size_t)hh * A : (size_t)T * A;
+        sp.eps = eps + (size_t)w * N * per;
+        sp.mode = a->mode == M3PC_MODE_NOISE ? 1 : 0;
+        sp.T = T;
+        sp.A = A;
+        sp.idx = idx;
+        sp.h = hh;
+        sp.n_count = N;
+        sp.cand = h->cand + (size_t)w * N * T * A;
+        sp.sample_actions = sample_actions + (size_t)w * N * hh * A;
+        sp.loc_out = loc ? loc + (size_t)w * T * A : nullptr;
+        sp.sd_out = std_ ? std_ + (size_t)w * T * A : nullptr;
+        launch_sample(sp, st);
+    }
+    const int dt = a->precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32;
+    return candidate_pass(h, a, states, rewards, E * N, sample_actions, expect_return, nullptr, nullptr, dt, st, window_index);
 }
 
 int m3pc_rescore(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* actions, const float* rewards,

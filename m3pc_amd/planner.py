@@ -38,7 +38,8 @@ class HipPlanner:
                  obs_mean=None, obs_std=None, n_embd: int = 512, n_head: int = 4, n_enc_layer: int = 2,
                  n_dec_layer: int = 1, precision: str = "fp32", rescore_topk: int = 16, device: Optional[int] = None,
                  group=None, generator: Optional[torch.Generator] = None, max_batch: int = 1,
-                 rescore: str = "bound", rescore_min: int = 4, rescore_max: int = 64, rescore_delta: Optional[float] = None):
+                 rescore: str = "bound", rescore_min: int = 4, rescore_max: int = 64, rescore_delta: Optional[float] = None,
+                 max_windows: int = 1):
         """cfg: any object with traj_length, action_samples, horizon, discount, temperature, lmbda,
         plan_guidance (finetune.py RunConfig fields read at learner.py:276,319,342).
         tokenizer_manager: a TokenizerManager (this package's) or {key: {"mean","std","min","max"}}.
@@ -64,8 +65,9 @@ class HipPlanner:
         _, n_local = mdist.shard_range(N, 0, self.world)
         hidden = 0 if q_state_dict is None else q_state_dict["q1.net.0.weight"].shape[0]
         self.handle = capi.Handle(S, A, T, n_embd, n_head, n_enc_layer, n_dec_layer,
-                                  max_candidates=max(n_local, rescore_topk, int(rescore_max) if precision == "bf16" else 1, 1),
-                                  max_batch=max(int(max_batch), 1),
+                                  max_candidates=max(n_local * max(int(max_windows), 1), rescore_topk,
+                                                     int(rescore_max) * max(int(max_windows), 1) if precision == "bf16" else 1, 1),
+                                  max_batch=max(int(max_batch), int(max_windows), 1),
                                   critic_hidden=hidden,
                                   device=device)
         self.device = self.handle.device
@@ -347,6 +349,134 @@ class HipPlanner:
                 infer[i] = inferred[j]
         self.last = dict(state_inference=infer)
         return out
+
+    # ---------------------------------------------------------------------------------------- batched planning
+    @torch.no_grad()
+    def action_sample_batch(self, sequence_histories, percentage=1.0, eval=False, rtg=None):
+        """``action_sample(history, plan=True)`` for E environments in ONE pass of the kernels.  The
+        reference steps one environment at a time (replay_buffer.py:204-232, learner.py:681-691: one action_sample per env
+        step); here the E windows share the policy pass (batch E), one candidate pass over E x N rows, one fp32 re-score
+        pass over every window's re-score set, and E select calls.  Per window the arithmetic is that of the single-window
+        call (same kernels on more rows; split-K decisions of the fp32 policy pass may differ in the last bits).
+        ``rtg``: None, a float, or one value per window.  Windows are grouped by effective horizon (early-episode windows
+        plan with horizon T - end_idx, learner.py:342-345).  Returns (E, A).  Needs max_batch >= E and
+        max_candidates >= E * N at construction (``HipPlanner(..., max_batch=E, max_windows=E)``)."""
+        cfg = self.cfg
+        guidance = cfg.plan_guidance
+        assert guidance in _MODES, guidance
+        mode = _MODES[guidance]
+        lmbda = 0.6 if guidance == "rtg_guiding" else float(cfg.lmbda)  # learner.py:405-407
+        E, T, A, N = len(sequence_histories), self.T, self.A, int(cfg.action_samples)
+        rtgs = [rtg] * E if (rtg is None or np.isscalar(rtg)) else list(rtg)
+        if eval:
+            assert all(r is not None for r in rtgs)
+        host = np.empty((E, T, self.S + self.A + 1), dtype=np.float32)
+        meta = []
+        for i, hst in enumerate(sequence_histories):
+            meta.append(self._window_host(hst, rtgs[i], percentage, host[i]))
+        dev = torch.from_numpy(host).to(self.device)  # one packed H2D copy for all windows
+        out = torch.empty((E, A), dtype=torch.float32, device=self.device)
+        info = [None] * E
+        for h in sorted({m[0] for m in meta}):
+            ids = [i for i, m in enumerate(meta) if m[0] == h]
+            sel = dev if len(ids) == E else dev[torch.tensor(ids, device=self.device)]
+            s = sel[:, :, : self.S].contiguous()
+            a = sel[:, :, self.S : self.S + self.A].contiguous()
+            r = sel[:, :, self.S + self.A :].contiguous()
+            Eg = len(ids)
+            eps = self._eps((Eg, N, h, A)) if mode == capi.MODE_NOISE else self._eps((Eg, N, T, A))
+            res = self.handle.plan_step_batch(mode, s, a, r, [meta[i][1] for i in ids], eps, h, lmbda, float(cfg.discount), N,
+                                              precision=self.precision)
+            er, acts = res["expect_return"], res["sample_actions"]
+            stats_h = None
+            if self.rescore != "none":
+                smode = capi.MODE_RTG if mode == capi.MODE_RTG else capi.MODE_CRITIC
+                if self.rescore == "bound":
+                    if self._delta is None:  # calibrate on window 0 of the group: 64 of its candidates in fp32
+                        g = torch.Generator().manual_seed(0x5eed)
+                        cid = torch.randperm(N, generator=g)[: min(64, N)].to(self.device)
+                        f32 = self.handle.score_actions(smode, s[0], a[0], r[0], acts[0, cid], None, h, lmbda, float(cfg.discount))
+                        d = er[0, cid] - f32
+                        self._delta = max(1.5 * float((d - d.median()).abs().max()), 1e-6 * float(f32.abs().max()), 1e-30)
+                    kmax, kmin = max(min(self.rescore_max, N - 1), 1), max(min(self.rescore_min, N), 1)
+                    tops, stats = zip(*[self.handle.topk_window(er[w], kmax, min(kmin, kmax), 2.0 * self._delta) for w in range(Eg)])
+                    stats_h = torch.stack(stats).cpu()  # the one host read of the group
+                    counts = [int(stats_h[w, 0]) for w in range(Eg)]
+                else:
+                    k = min(self.rescore_topk, N)
+                    tops = [torch.topk(er[w], k).indices.to(torch.int32) for w in range(Eg)]
+                    counts = [k] * Eg
+                pick = torch.cat([tops[w][: counts[w]].long() for w in range(Eg)])
+                wsel = torch.cat([torch.full((counts[w],), w, dtype=torch.int32, device=self.device) for w in range(Eg)])
+                f32 = self.handle.score_actions(smode, s, a, r, acts[wsel.long(), pick], wsel, h, lmbda, float(cfg.discount))
+                er[wsel.long(), pick] = f32
+            for j, i in enumerate(ids):
+                expo = torch.empty((N,), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
+                p, ev, am, si, sa = self.handle.select(er[j], acts[j, :, 0], float(cfg.temperature), expo)
+                out[i] = ev if eval else sa[0]
+                info[i] = dict(expect_return=er[j], argmax=am, sample_idx=si, eval_action=ev, sample_action=sa, horizon=h,
+                               n_rescored=None if stats_h is None else int(stats_h[j, 0]),
+                               min_margin_outside=None if stats_h is None else float(stats_h[j, 1]))
+        self.last = dict(windows=info, delta=self._delta)
+        return out
+
+    def _window_host(self, sequence_history, rtg, percentage, buf):
+        """Host half of ``assemble_window`` into ``buf`` (T, S+A+1); returns (horizon, rtg)."""
+        T = self.T
+        horizon = int(self.cfg.horizon)
+        end_idx = int(sequence_history["path_length"])
+        if end_idx + horizon < T:
+            horizon = T - end_idx
+        hl = T - horizon + 1
+        buf[:] = 0.0
+        lo, hi = end_idx - hl + 1, end_idx + 1
+        buf[:hl, : self.S] = sequence_history["observations"][lo:hi]
+        buf[:hl, self.S : self.S + self.A] = sequence_history["actions"][lo:hi]
+        buf[:hl, self.S + self.A :] = np.asarray(sequence_history["rewards"][lo:hi]).reshape(hl, 1)
+        if rtg is not None:
+            return horizon, float(rtg)
+        st = self.tokenizer_manager.tokenizers["returns"].stats
+        return horizon, float(np.asarray(st.min + (st.max - st.min) * percentage).reshape(-1)[0])
+
+    # ---------------------------------------------------------------------------------------- CEM refinement
+    @torch.no_grad()
+    def cem_guiding(self, trajectory: Dict[str, torch.Tensor], h: int, iterations: int = 2, top_k: int = 128, init_std: float = 0.1,
+                    noise=None):
+        """Cross-entropy refinement of the plan (the legacy ``sample_action_cem`` of
+        research/omtm/datasets/sequence_dataset.py:919-1000 -- N=1024, top_k=128, 2 iterations -- restated on this model's
+        plan step: that function predates the four-key omtm model and cannot run on it, so parity is pinned on the oracle's
+        restatement of the same algorithm (tests/test_batch_gpu.py), not on the reference).
+          candidates_0 = clamp(tanh(policy loc) + init_std * noise_0, -1, 1) over the last h steps
+          repeat: score (TD(lambda) as rtg_guiding / critic_lambda_guiding) -> top_k -> mean / std per (t, a)
+                  candidates = clamp(mean + std * noise_i, -1, 1)
+        Returns (sample_action (1,A): first action of candidate 0 after the last refit, as the legacy code returns;
+                 eval_action (A,): first action of the final mean).  ``noise``: optional (iterations+1, N, h, A) normals."""
+        s, a, r, rtg = self._split(trajectory)
+        cfg = self.cfg
+        N, T, A = int(cfg.action_samples), self.T, self.A
+        mode = capi.MODE_CRITIC if cfg.plan_guidance == "critic_lambda_guiding" else capi.MODE_RTG
+        lmbda = 0.6 if mode == capi.MODE_RTG else float(cfg.lmbda)
+        toks = [self.handle.tokenize(capi.STATES, s[None]), a[None], None,
+                self.handle.tokenize(capi.RETURNS, torch.full((1, T, 1), rtg, dtype=torch.float64, device=self.device))]
+        from .masks import create_rcbc_mask, mask_rows
+        mu, _ = self.handle.forward(toks, mask_rows(create_rcbc_mask(T, "cpu", T - h)), want=("actions",))["actions"]
+        mean = torch.tanh(mu[0, T - h :])  # (h, A)
+        std = torch.full_like(mean, float(init_std))
+        if noise is None:
+            noise = self._eps((iterations + 1, N, h, A))
+        k = min(int(top_k), N)
+        cand = torch.clamp(mean[None] + std[None] * noise[0], -1.0, 1.0)
+        trace = []
+        for it in range(iterations):
+            er = self.handle.score_actions(mode, s, a, r, cand, None, h, lmbda, float(cfg.discount), precision=self.precision)
+            top = torch.topk(er, k).indices
+            elite = cand[top]
+            mean = elite.mean(dim=0)
+            std = elite.std(dim=0) if k > 1 else torch.zeros_like(mean)
+            trace.append(dict(expect_return=er, top=top, mean=mean, std=std))
+            cand = torch.clamp(mean[None] + std[None] * noise[it + 1], -1.0, 1.0)
+        self.last = dict(cem=trace, candidates=cand)
+        return cand[0, 0][None], mean[0]
 
     @torch.no_grad()
     def action_sample(self, sequence_history, percentage=1.0, horizon=4, plan=True, eval=False, rtg=None):

@@ -421,3 +421,28 @@ def goal_id(sd, stats, cfg: PlanCfg, traj, h: int):
     T = cfg.traj_length
     out = mtm_forward(sd, encode_all(traj, stats), gid_mask(T, T - h), cfg.n_head, want=("actions",))
     return out["actions"]
+
+
+def cem_guiding(sd, stats, cfg: PlanCfg, traj, h: int, lmbda: float, noise: torch.Tensor, mode: str = "rtg", critic=None,
+                iterations: int = 2, top_k: int = 128, init_std: float = 0.1):
+    """Cross-entropy refinement of the plan: the algorithm of the legacy ``sample_action_cem``
+    (research/omtm/datasets/sequence_dataset.py:919-1000: noisy copies of the policy mean, score, keep top_k, refit mean
+    and std, resample, clamp to [-1, 1]) on this model's own pieces -- policy_pass for the mean, plan_candidates
+    (learner.py:288-316) for the score.  The legacy function itself predates the four-key model and does not run on it:
+    this restatement is the parity pin of HipPlanner.cem_guiding.  noise: (iterations+1, N, h, A) standard normals."""
+    T = cfg.traj_length
+    loc, _ = policy_pass(sd, stats, cfg, traj, h)
+    mean = torch.tanh(loc[0, T - h :, 0, :])
+    std = torch.full_like(mean, init_std)
+    cand = torch.clamp(mean[None] + std[None] * noise[0], -1.0, 1.0)
+    trace = []
+    k = min(top_k, cand.shape[0])
+    for it in range(iterations):
+        er = plan_candidates(sd, stats, cfg, traj, h, cand, mode, lmbda, critic)
+        top = torch.topk(er, k).indices
+        elite = cand[top]
+        mean = elite.mean(dim=0)
+        std = elite.std(dim=0) if k > 1 else torch.zeros_like(mean)
+        trace.append(dict(expect_return=er, top=top, mean=mean, std=std))
+        cand = torch.clamp(mean[None] + std[None] * noise[it + 1], -1.0, 1.0)
+    return dict(sample_action=cand[0, 0][None], eval_action=mean[0], trace=trace, candidates=cand)

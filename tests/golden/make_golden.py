@@ -331,13 +331,14 @@ def g3():
     dims = synth.Dims(11, 3, 8)
     wp = np.loadtxt("/root/reference/research/zeroshot_omtm/waypoint_gen/hopper-wiggle-f2.txt")
     assert wp.shape == (1000, 11)
+    raw = wp.astype(np.float32).copy()  # the reference's way-point data file as read (a data fixture for the hold test)
     # index_jump hold (zeroshot learner.py:530-539, config_hopper.yaml index_jump: 4)
     jump, father = 4, 4
     while father < 999:
         for i in range(jump):
             wp[father - 1 - i] = wp[father]
         father += jump + 1
-    out = dict(meta=str(META), waypoints_held=wp.astype(np.float32))
+    out = dict(meta=str(META), waypoints_held=wp.astype(np.float32), waypoints_raw=raw)
     L = build_reference(dims, dict(action_samples=1, horizon=4, discount=0.99, temperature=1.0, lmbda=0.6,
                                    plan_guidance="", index_jump=4), zeroshot=True)
     base = synth.make_history(dims, 0)

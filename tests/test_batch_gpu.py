@@ -1,0 +1,329 @@
+"""GPU tests of what sits around the single-window plan step (SURVEY 8 f1 / f3 / f4 and the coverage items of VERDICT r1):
+batched guided planning, caller-supplied candidates, CEM refinement, the way-point follower, zero-shot batches, the
+planner-level noise / critic / C4 paths, a full 2048-candidate C4 shard, checkpoints against the oracle."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from m3pc_amd import capi, synth
+from m3pc_amd.planner import HipPlanner
+from oracle import mtm_oracle as O
+
+pytestmark = pytest.mark.gpu
+GD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _cfg(T, N, H, temp, guidance, **kw):
+    return types.SimpleNamespace(traj_length=T, action_samples=N, horizon=H, discount=0.99, temperature=temp, lmbda=0.6,
+                                 plan_guidance=guidance, device="cuda", **kw)
+
+
+def _tiny(N=16, guidance="rtg_guiding", temp=0.01, **kw):
+    dims = synth.Dims(11, 3, 8, n_embd=64, n_head=2)
+    qsd, om, os_ = synth.make_critic(dims, 0)
+    p = HipPlanner(_cfg(8, N, 4, temp, guidance), synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), qsd, om, os_,
+                   n_embd=64, n_head=2, **kw)
+    return dims, p
+
+
+# ------------------------------------------------------------------------------------------------ batched planning (f1)
+@pytest.mark.parametrize("guidance,mode,temp", [("rtg_guiding", "rtg", 0.01), ("critic_lambda_guiding", "critic", 1.0)])
+def test_batched_planning_equals_single_window_calls_and_the_reference(guidance, mode, temp):
+    """E = 4 windows with mixed horizons (path_length 0 and 3 plan with horizon T - end_idx) on the tiny config, fp32: every
+    window of the batch reproduces the reference golden of its single-window call (G1) and the single-window planner."""
+    g = np.load(os.path.join(GD, "g1_tiny.npz"))
+    dims, pb = _tiny(guidance=guidance, temp=temp, max_windows=4)
+    _, ps = _tiny(guidance=guidance, temp=temp)
+    eps = torch.from_numpy(g["eps"]).cuda()  # (N,1,T,1,A): the reference's draw for every window of the fixture
+    N, T, A = 16, 8, 3
+    pls = [0, 3, 100, 998]
+    hists = []
+    for pl in pls:
+        h = synth.make_history(dims, 0)
+        h["path_length"] = pl
+        hists.append(h)
+    pb._eps = lambda shape: eps.reshape(1, N, T, A).expand(shape[0], N, T, A).contiguous()
+    ps._eps = lambda shape: eps
+    ev = pb.action_sample_batch(hists, eval=True, rtg=3.0)
+    assert ev.shape == (4, 3)
+    for i, pl in enumerate(pls):
+        pre = f"{mode}_pl{pl}_"
+        w = pb.last["windows"][i]
+        assert np.abs(ev[i].cpu().numpy() - g[pre + "eval_action"]).max() < 2e-5
+        er = w["expect_return"]
+        got = (er - er.max()).cpu().numpy()
+        assert np.abs(got - g[pre + "expect_return"]).max() <= 2e-5 * max(1.0, float(np.abs(g[pre + "expect_return"]).max()))
+        assert int(w["argmax"].item()) == int(np.argmax(g[pre + "expect_return"]))
+        e1 = ps.action_sample(hists[i], plan=True, eval=True, rtg=3.0)
+        assert float((e1 - ev[i]).abs().max()) < 1e-5 and int(ps.last["argmax"].item()) == int(w["argmax"].item())
+    sa = pb.action_sample_batch(hists, eval=False, rtg=[3.0, 2.0, 3.0, 1.0])
+    assert sa.shape == (4, 3) and float(sa.abs().max()) <= 1.0
+    pb.handle.close()
+    ps.handle.close()
+
+
+def test_batched_bf16_planning_keeps_the_reference_argmax():
+    """Full-size model, bf16 candidate pass + bound-driven fp32 re-score, E = 4 windows x N = 256: the four hopper / weight
+    seed 0 cases of g5_argmax.npz (captured from the reference) in one batch."""
+    g5 = np.load(os.path.join(GD, "g5_argmax.npz"))
+    N, H, T = (int(v) for v in g5["cfg"])
+    dims = synth.Dims(11, 3, T)
+    p = HipPlanner(_cfg(T, N, H, 0.01, "rtg_guiding"), synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None,
+                   precision="bf16", max_windows=4)
+    hists, epss = [], []
+    for ci in range(4):
+        env, mode, wseed, hseed, pl = str(g5["cases"][ci]).split(":")
+        assert env == "hopper" and wseed == "0"
+        h = synth.make_history(dims, int(hseed))
+        h["path_length"] = int(pl)
+        hists.append(h)
+        epss.append(synth.make_eps(N, dims, 100 + ci).reshape(N, T, 3))
+    stack = torch.stack(epss).cuda()
+    p._eps = lambda shape: stack
+    ev = p.action_sample_batch(hists, eval=True, rtg=3.0)
+    for ci in range(4):
+        w = p.last["windows"][ci]
+        assert int(w["argmax"].item()) == int(g5[f"argmax_{ci}"]), ci
+        assert 4 <= w["n_rescored"] <= 64
+        assert np.abs(ev[ci].cpu().numpy() - g5[f"eval_action_{ci}"]).max() < 2e-2
+    p.handle.close()
+
+
+# ------------------------------------------------------------------------------------------------ caller-supplied candidates
+def test_score_actions_reproduces_plan_step_scores():
+    dims = synth.Dims(11, 3, 32)
+    N, H, T = 256, 16, 32
+    p = HipPlanner(_cfg(T, N, H, 0.01, "rtg_guiding"), synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None,
+                   precision="bf16", max_windows=2)
+    eps = synth.make_eps(N, dims, 7)[:, 0, :, 0, :].cuda()
+    wins = []
+    for hs, pl in ((0, 500), (5, 321)):
+        hist = synth.make_history(dims, hs)
+        hist["path_length"] = pl
+        wins.append(p.assemble_window(hist, rtg=3.0)[:3])
+        wins[-1] = tuple(t.clone() for t in wins[-1])
+    for prec, tol in ((capi.PREC_BF16, 0.0), (capi.PREC_FP32, 2e-5)):
+        outs = []
+        for s, a, r in wins:
+            res = p.handle.plan_step(capi.MODE_RTG, s, a, r, eps, H, 3.0, 0.6, 0.99, N, precision=prec, want_debug=True)
+            er = p.handle.score_actions(capi.MODE_RTG, s, a, r, res["sample_actions"], None, H, 0.6, 0.99, precision=prec)
+            scale = float(res["expect_return"].abs().max())
+            if tol == 0.0:
+                assert torch.equal(er, res["expect_return"])  # same kernels, same rows: same bits
+            else:
+                assert float((er - res["expect_return"]).abs().max()) <= tol * scale
+            outs.append((res["sample_actions"].clone(), res["expect_return"].clone()))
+        # two windows in one call, candidates interleaved
+        S = torch.stack([w[0] for w in wins])
+        A_ = torch.stack([w[1] for w in wins])
+        R = torch.stack([w[2] for w in wins])
+        cand = torch.stack([outs[0][0], outs[1][0]], dim=1).reshape(2 * N, H, 3)
+        widx = torch.tensor([0, 1], dtype=torch.int32, device="cuda").repeat(N)
+        er2 = p.handle.score_actions(capi.MODE_RTG, S, A_, R, cand, widx, H, 0.6, 0.99, precision=prec).reshape(N, 2)
+        for w in range(2):
+            ref = outs[w][1]
+            lim = (2e-2 if prec == capi.PREC_BF16 else 2e-5) * float(ref.abs().max())
+            assert float((er2[:, w] - ref).abs().max()) <= lim
+    p.handle.close()
+
+
+# ------------------------------------------------------------------------------------------------ CEM (f4)
+@pytest.mark.parametrize("guidance,mode", [("rtg_guiding", "rtg"), ("critic_lambda_guiding", "critic")])
+def test_cem_guiding_matches_the_oracle(guidance, mode):
+    dims, p = _tiny(N=64, guidance=guidance, temp=1.0)
+    hist = synth.make_history(dims, 0)
+    hist["path_length"] = 100
+    s, a, r, h, rtg = p.assemble_window(hist, rtg=3.0)
+    noise = torch.randn(3, 64, h, 3, generator=torch.Generator().manual_seed(11))
+    traj = {"states": s[None], "actions": a[None], "rewards": r[None], "_rtg": rtg}
+    sa, ev = p.cem_guiding(traj, h, iterations=2, top_k=16, noise=noise.cuda())
+    ocfg = O.PlanCfg(8, 4, 64, n_head=2)
+    win, hh = O.assemble_window(ocfg, hist, 100, 3.0)
+    ref = O.cem_guiding(synth.make_state_dict(dims, 0), O.make_stats(synth.make_tokenizer_stats(dims, 0)), ocfg, win, hh, 0.6, noise,
+                        mode, critic=synth.make_critic(dims, 0), iterations=2, top_k=16)
+    for it in range(2):
+        got, exp = p.last["cem"][it], ref["trace"][it]
+        scale = max(1.0, float(exp["expect_return"].abs().max()))
+        assert float((got["expect_return"].cpu() - exp["expect_return"]).abs().max()) <= 5e-5 * scale
+        assert set(got["top"].cpu().tolist()) == set(exp["top"].tolist())
+        assert float((got["mean"].cpu() - exp["mean"]).abs().max()) < 1e-5 and float((got["std"].cpu() - exp["std"]).abs().max()) < 1e-5
+    assert float((ev.cpu() - ref["eval_action"]).abs().max()) < 1e-5 and float((sa.cpu() - ref["sample_action"]).abs().max()) < 1e-5
+    assert sa.shape == (1, 3) and ev.shape == (3,)
+    p.handle.close()
+
+
+# ------------------------------------------------------------------------------------------------ way-point follower (f3)
+def test_waypoint_follower_reproduces_the_reference_calls(tmp_path):
+    from m3pc_amd.zeroshot import WaypointFollower
+    g = np.load(os.path.join(GD, "g3_zeroshot.npz"))
+    path = tmp_path / "hopper-wiggle-f2.txt"
+    np.savetxt(path, g["waypoints_raw"])
+    dims = synth.Dims(11, 3, 8)
+    cfg = _cfg(8, 1, 4, 1.0, "rtg_guiding", index_jump=4)
+    p = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None, max_batch=4)
+    base = synth.make_history(dims, 0)
+    for gm, fn in (("piid", "action_piid_sample"), ("id", "action_id_sample")):
+        f = WaypointFollower(p, str(path), goal_mask=gm)
+        assert np.array_equal(f.waypoints.astype(np.float32), g["waypoints_held"])
+        trajs = []
+        for pl in (int(v) for v in g["path_lengths"]):
+            tr = f.new_trajectory()
+            tr["observations"][:pl] = base["observations"][:pl]  # what the episode has seen so far
+            tr["actions"][:] = base["actions"]
+            tr["rewards"][:] = np.asarray(base["rewards"]).reshape(1000, 1)
+            act = f.act(tr, base["observations"][pl], pl, rtg=2.5)
+            ref = np.clip(g[f"{fn}_pl{pl}_eval_action"], -1, 1)
+            assert act.shape == (1, 3) and np.abs(act.reshape(-1) - ref.reshape(-1)).max() < 2e-5, (gm, pl)  # (1, A) as the reference
+            trajs.append(tr)
+        if gm == "piid":  # the same four environments in one call
+            pls = [int(v) for v in g["path_lengths"]]
+            acts = f.act_batch(trajs, [base["observations"][pl] for pl in pls], pls, [2.5] * 4)
+            for i, pl in enumerate(pls):
+                assert np.abs(acts[i] - np.clip(g[f"action_piid_sample_pl{pl}_eval_action"], -1, 1).reshape(-1)).max() < 2e-5
+    p.handle.close()
+
+
+def test_zeroshot_batch_of_64_windows():
+    """BASELINE config 5 shape: 64 environments per call; each row equals the single-window call."""
+    dims = synth.Dims(11, 3, 8)
+    cfg = _cfg(8, 1, 4, 1.0, "rtg_guiding", index_jump=4)
+    p = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None, max_batch=64)
+    rng = np.random.RandomState(0)
+    hists = []
+    for i in range(64):
+        h = synth.make_history(dims, i % 5)
+        h["path_length"] = int(rng.choice([0, 1, 2, 3, 50, 400, 996, 997, 998]))
+        hists.append(h)
+    acts = p.action_piid_sample_batch(hists, percentage=1.0, eval=True, rtg=2.5)
+    assert acts.shape == (64, 3)
+    for i in (0, 7, 13, 31, 63):
+        one = p.action_piid_sample(hists[i], eval=True, rtg=2.5)
+        assert float((one - acts[i]).abs().max()) < 1e-5
+    p.handle.close()
+
+
+# ------------------------------------------------------------------------------------------------ planner-level modes
+def test_planner_noise_adding_lambda_matches_the_oracle():
+    """cfg.plan_guidance = "noise_adding_lambda" through action_sample (learner.py:389-395 dispatch, 142-208)."""
+    dims, p = _tiny(N=16, guidance="noise_adding_lambda", temp=1.0)
+    hist = synth.make_history(dims, 0)
+    hist["path_length"] = 100
+    eps = torch.randn(16, 4, 3, generator=torch.Generator().manual_seed(5))
+    p._eps = lambda shape: eps.cuda()
+    ev = p.action_sample(hist, plan=True, eval=True, rtg=3.0)
+    ocfg = O.PlanCfg(8, 4, 16, 0.99, 1.0, 0.6, n_head=2)
+    win, hh = O.assemble_window(ocfg, hist, 100, 3.0)
+    ref = O.guiding(synth.make_state_dict(dims, 0), O.make_stats(synth.make_tokenizer_stats(dims, 0)), ocfg, win, hh, 0.6, eps, "noise",
+                    critic=synth.make_critic(dims, 0))
+    scale = max(1.0, float(ref["expect_return"].abs().max()))
+    assert float((p.last["expect_return"].cpu() - ref["expect_return"]).abs().max()) <= 5e-5 * scale
+    assert int(p.last["argmax"].item()) == ref["argmax"]
+    assert float((ev.cpu() - ref["eval_action"]).abs().max()) < 1e-4
+    p.handle.close()
+
+
+def test_c3_planner_bf16_rescore_keeps_reference_argmax():
+    """BASELINE config 3 (walker2d, critic_lambda_guiding, N=4096) through the planner in bf16 + bound-driven re-score."""
+    g = np.load(os.path.join(GD, "g2_c3.npz"))
+    dims = synth.Dims(17, 6, 32)
+    qsd, om, os_ = synth.make_critic(dims, 0)
+    p = HipPlanner(_cfg(32, 4096, 16, 1.0, "critic_lambda_guiding"), synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0),
+                   qsd, om, os_, precision="bf16")
+    eps = synth.make_eps(4096, dims, 1).cuda()
+    p._eps = lambda shape: eps
+    hist = synth.make_history(dims, 0)
+    hist["path_length"] = 500
+    ev = p.action_sample(hist, plan=True, eval=True, rtg=3.0)
+    assert int(p.last["argmax"].item()) == int(g["argmax"])
+    assert int(g["argmax"]) in p.last["topk"].cpu().numpy()
+    assert np.abs(ev.cpu().numpy() - g["eval_action"]).max() < 2e-2
+    p.handle.close()
+
+
+def test_c4_blocks_planner_bf16_rescore_keeps_reference_argmax():
+    """BASELINE config 4 (halfcheetah, N=16384, H=32, T=64): the three 512-candidate blocks the reference was run on."""
+    g = np.load(os.path.join(GD, "g2_c4.npz"))
+    dims = synth.Dims(17, 6, 64)
+    eps_all = synth.make_eps(16384, dims, 1)
+    p = HipPlanner(_cfg(64, 512, 32, 0.01, "rtg_guiding"), synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None,
+                   precision="bf16")
+    hist = synth.make_history(dims, 0)
+    hist["path_length"] = 500
+    for bi, (b0, b1) in enumerate(g["blocks"]):
+        eps = eps_all[int(b0):int(b1)].cuda()
+        p._eps = lambda shape: eps
+        p.action_sample(hist, plan=True, eval=True, rtg=3.0)
+        ref = g["expect_return_shifted_blocks"][bi]
+        assert int(p.last["argmax"].item()) == int(np.argmax(ref)), bi
+    p.handle.close()
+
+
+def test_c4_full_shard_properties():
+    """One rank's share of BASELINE config 4: 2048 of 16384 candidates at H=32, T=64 (no reference run exists at this
+    size: size-independent properties).  (a) the shard scored in one call == scored in two calls, bit for bit, both
+    arithmetics; (b) the fp32 arg-max of the shard lies inside the bf16 re-score window."""
+    dims = synth.Dims(17, 6, 64)
+    h = capi.Handle(17, 6, 64, 512, 4, 2, 1, max_candidates=2048, max_batch=1, critic_hidden=0)
+    h.load_weights(synth.make_state_dict(dims, 0))
+    st = synth.make_tokenizer_stats(dims, 0)
+    for k, name in enumerate(synth.KEYS):
+        h.set_tokenizer(k, st[name]["mean"], st[name]["std"], normalize=(name != "actions"))
+    cfg = O.PlanCfg(64, 32, 16384)
+    win, hh = O.assemble_window(cfg, synth.make_history(dims, 0), 500, 3.0)
+    s, a, r = win["states"][0].cuda(), win["actions"][0].cuda(), win["rewards"][0].cuda()
+    eps = synth.make_eps(16384, dims, 1)[:, 0, :, 0, :].cuda()
+    b0 = 6144  # the shard of rank 3 of 8
+    full = {}
+    for prec in (capi.PREC_BF16, capi.PREC_FP32):
+        one = h.plan_step(capi.MODE_RTG, s, a, r, eps, 32, 3.0, 0.6, 0.99, 16384, n_begin=b0, n_count=2048, precision=prec)["expect_return"].clone()
+        two = torch.cat([h.plan_step(capi.MODE_RTG, s, a, r, eps, 32, 3.0, 0.6, 0.99, 16384, n_begin=b0 + o, n_count=1024,
+                                     precision=prec)["expect_return"].clone() for o in (0, 1024)])
+        assert torch.equal(one, two)
+        assert torch.isfinite(one).all()
+        full[prec] = one
+    f, b = full[capi.PREC_FP32], full[capi.PREC_BF16]
+    d = b - f
+    delta = 1.5 * float((d - d.median()).abs().max())  # what the calibration measures (on 64 of them)
+    am = int(torch.argmax(f))
+    assert float(b[am]) >= float(b.max()) - 2 * delta
+    assert float((d - d.median()).abs().max()) <= 5e-2 * float(f.abs().max())
+    h.close()
+
+
+# ------------------------------------------------------------------------------------------------ checkpoints (f2)
+def test_planner_from_checkpoint_files_matches_the_oracle(tmp_path):
+    """{"model": ...} / {"qf": ...} files + a DataStatistics-shaped statistics mapping with a small-std dimension -> planner;
+    compared with the ORACLE fed from the same files (not with another planner)."""
+    from m3pc_amd import checkpoint
+    dims = synth.Dims(11, 3, 8, n_embd=64, n_head=2)
+    sd = synth.make_state_dict(dims, 0)
+    st = {k: {n: np.array(v[n]) for n in v} for k, v in synth.make_tokenizer_stats(dims, 0).items()}
+    st["states"]["std"][3] = 0.02  # continuous.py:58 turns this into 1
+    qsd, om, os_ = synth.make_critic(dims, 0)
+    torch.save({"model": sd, "optimizer": {}, "step": 3, "eval_max": {}}, tmp_path / "m.pt")
+    torch.save({"qf": qsd, "vf": {}, "actor": {}, "total_it": 1}, tmp_path / "iql_3.pt")
+    cfg = _cfg(8, 16, 4, 1.0, "critic_lambda_guiding")
+    objs = {k: types.SimpleNamespace(**v) for k, v in st.items()}
+    p = checkpoint.planner_from_checkpoints(cfg, str(tmp_path / "m.pt"), objs, str(tmp_path / "iql_3.pt"), om, os_, n_head=2)
+    hist = synth.make_history(dims, 0)
+    hist["path_length"] = 500
+    eps = synth.make_eps(16, dims, 1)
+    p._eps = lambda shape: eps.cuda()
+    ev = p.action_sample(hist, plan=True, eval=True, rtg=3.0)
+    # the oracle from the same files, with the reference's tokenizer construction (std < 0.1 -> 1)
+    sd_f = checkpoint.load_mtm_state_dict(str(tmp_path / "m.pt"))
+    q_f = checkpoint.load_iql_qf(str(tmp_path / "iql_3.pt"))
+    st_o = {k: dict(v) for k, v in checkpoint.tokenizer_stats(objs).items()}
+    for k in st_o:
+        st_o[k]["std"] = np.where(st_o[k]["std"] < 0.1, 1.0, st_o[k]["std"]).astype(np.float32)
+    ocfg = O.PlanCfg(8, 4, 16, 0.99, 1.0, 0.6, n_head=2)
+    win, hh = O.assemble_window(ocfg, hist, 500, 3.0)
+    ref = O.guiding(sd_f, O.make_stats(st_o), ocfg, win, hh, 0.6, eps, "critic", critic=(q_f, om, os_))
+    scale = max(1.0, float(ref["expect_return"].abs().max()))
+    assert float((p.last["expect_return"].cpu() - ref["expect_return"]).abs().max()) <= 5e-5 * scale
+    assert int(p.last["argmax"].item()) == ref["argmax"]
+    assert float((ev.cpu() - ref["eval_action"]).abs().max()) < 1e-4
+    p.handle.close()
