@@ -191,9 +191,11 @@ int m3pc_rescore_topk(m3pc_handle* h, const m3pc_plan_args* args, const float* s
  * within window = 2 delta of the bf16 maximum.  Finds the kmax + 1 best entries of expect_return (descending; ties to the
  * lower index) and n = clamp(#{E_i >= max E - window}, kmin, kmax).
  *   topk_index  device out (kmax + 1,) int32
- *   stats       device out float[4]: {n, max E - (best E not among the n) [inf if none], max E, unclamped count} */
+ *   stats       device out float[4]: {n, max E - (best E not among the n) [inf if none], max E, unclamped count}
+ *   host_stats  optional: host-mapped (pinned) float[5] the kernel also writes -- the four stats, then `seq` into [4] with
+ *               system scope; a caller that spins on host_stats[4] == seq reads n without a stream synchronisation */
 int m3pc_topk_window(m3pc_handle* h, const float* expect_return, int n_total, int kmax, int kmin, float window,
-                     int* topk_index, float* stats, void* stream);
+                     int* topk_index, float* stats, float* host_stats, float seq, void* stream);
 /* m3pc_rescore of the n listed candidates (device int32 ids), written back into the full score vector in place. */
 int m3pc_rescore_listed(m3pc_handle* h, const m3pc_plan_args* args, const float* states, const float* actions,
                         const float* rewards, const float* eps, const int* index, int n, float* expect_return,

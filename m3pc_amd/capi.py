@@ -83,7 +83,7 @@ def load_library(path: Optional[str] = None):
         "m3pc_score_actions": [vp, C.POINTER(PlanArgs), i, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_rescore": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, i, vp, vp, vp],
         "m3pc_rescore_topk": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, i, vp, vp],
-        "m3pc_topk_window": [vp, vp, i, i, i, f, vp, vp, vp],
+        "m3pc_topk_window": [vp, vp, i, i, i, f, vp, vp, vp, f, vp],
         "m3pc_rescore_listed": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, i, vp, vp],
         "m3pc_select": [vp, vp, vp, ll, i, f, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_profile_enable": [vp, i],
@@ -311,8 +311,34 @@ class Handle:
         top = torch.empty((kmax + 1,), dtype=torch.int32, device=self.device)
         stats = torch.empty((4,), dtype=torch.float32, device=self.device)
         check(self.lib.m3pc_topk_window(self._h, _ptr(expect_return), n, kmax, kmin, float(window), _ptr(top), _ptr(stats),
-                                        _stream(self.device)))
+                                        None, 0.0, _stream(self.device)))
         return top, stats
+
+    def topk_window_host(self, expect_return: torch.Tensor, kmax: int, kmin: int, window: float):
+        """``topk_window`` whose statistics arrive on the host without a stream synchronisation: the kernel also writes them
+        into a pinned, host-mapped buffer followed by a sequence number, and this call spins on that number (a few
+        microseconds after the kernel ends, where a blocking device-to-host copy costs tens).  Returns (top ids on the
+        device, [n, margin_outside, max, raw count] as python floats)."""
+        import time as _t
+        n = expect_return.numel()
+        if not hasattr(self, "_hs"):
+            self._hs = torch.zeros(8, dtype=torch.float32).pin_memory()
+            self._hs_np = self._hs.numpy()
+            self._hs_seq = 0
+        self._hs_seq = self._hs_seq % 1000000 + 1
+        seq = float(self._hs_seq)
+        top = torch.empty((kmax + 1,), dtype=torch.int32, device=self.device)
+        stats = torch.empty((4,), dtype=torch.float32, device=self.device)
+        check(self.lib.m3pc_topk_window(self._h, _ptr(expect_return), n, kmax, kmin, float(window), _ptr(top), _ptr(stats),
+                                        self._hs.data_ptr(), seq, _stream(self.device)))
+        hs = self._hs_np
+        t0 = _t.perf_counter()
+        spins = 0
+        while hs[4] != seq:
+            spins += 1
+            if (spins & 1023) == 0 and _t.perf_counter() - t0 > 0.25:  # never hang on the mapped buffer: the ordinary copy
+                return top, [float(x) for x in stats.cpu()]
+        return top, [float(hs[0]), float(hs[1]), float(hs[2]), float(hs[3])]
 
     def rescore_listed(self, mode: int, states, actions, rewards, eps, expect_return: torch.Tensor, index: torch.Tensor,
                        horizon: int, rtg: float, lmbda: float, discount: float):

@@ -25,23 +25,72 @@ __device__ __forceinline__ int map_row_d(const RowMap& m, int r) {
 }
 __device__ __forceinline__ float gelu_exact_d(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+__device__ __forceinline__ float wave_sum_d(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
 // TQ = 32x32 sub-tiles per workgroup tile (4: 64x64 tile, 1: 32x32 tile), KS = K slices; TQ * KS = 16 waves
 template <int TQ, int KS>
-__global__ __launch_bounds__(1024) void gemm_f32_direct_kernel(GemmP p) {
+__device__ __forceinline__ void gemm_f32_direct_body(const GemmP& p, int bid, float* part, float (*lnst)[2]) {
     static_assert(TQ * KS == 16, "16 waves per workgroup");
     constexpr int BT = TQ == 4 ? 64 : 32;
-    __shared__ float part[16 * 1024];  // [ks][q][reg][lane]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int q = wid % TQ, ks = wid / TQ;
     const int l31 = lane & 31, lh = lane >> 5;
     const int ntn = p.N / BT;
-    const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
+    const int tm = bid / ntn, tn = bid % ntn;
     const int rq = TQ == 4 ? 32 * (q >> 1) : 0, cq = TQ == 4 ? 32 * (q & 1) : 0;
     const int kslice = p.K / KS;
     int gr = tm * BT + rq + l31;
     if (gr >= p.M) gr = p.M - 1;
     const float* a = (const float*)p.A + (long long)map_row_d(p.amap, gr) * p.lda + ks * kslice + 4 * lh;
     const float* w = (const float*)p.W + (long long)(tn * BT + cq + l31) * p.ldw + ks * kslice + 4 * lh;
+
+    // optional LayerNorm of the A rows (TQ == 1): wave w computes the statistics of tile rows 2w, 2w+1 exactly as
+    // layernorm_vec_kernel does (same loads per lane, same summation order), the K loop normalises what it loads
+    const bool a_ln = TQ == 1 && p.a_ln_g != nullptr;
+    float mean = 0.f, rstd = 1.f;
+    if (a_ln) {
+        const int nsl = p.K >> 8;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            int r = tm * BT + 2 * wid + rr;
+            if (r >= p.M) r = p.M - 1;
+            const float* x = (const float*)p.A + (long long)map_row_d(p.amap, r) * p.lda;
+            f32x4 v[8];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < nsl) {
+                    v[i] = *(const f32x4*)(x + i * 256 + lane * 4);
+                    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+                }
+            const float inv_d = 1.0f / (float)p.K;
+            const float m = wave_sum_d(s) * inv_d;
+            float qq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < nsl) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float c = v[i][e] - m;
+                        qq += c * c;
+                    }
+                }
+            const float rs = rsqrtf(wave_sum_d(qq) * inv_d + 1e-5f);
+            if (lane == 0) {
+                lnst[2 * wid + rr][0] = m;
+                lnst[2 * wid + rr][1] = rs;
+            }
+        }
+        __syncthreads();
+        mean = lnst[l31][0];
+        rstd = lnst[l31][1];
+    }
+    const float* lg = a_ln ? p.a_ln_g + ks * kslice + 4 * lh : nullptr;
+    const float* lb = a_ln ? p.a_ln_b + ks * kslice + 4 * lh : nullptr;
 
     f32x16 acc;
 #pragma unroll
@@ -53,6 +102,12 @@ __global__ __launch_bounds__(1024) void gemm_f32_direct_kernel(GemmP p) {
         for (int s = 0; s < 4; ++s) {
             fa[s] = *(const f32x4*)(a + b * 32 + 8 * s);
             fw[s] = *(const f32x4*)(w + b * 32 + 8 * s);
+            if (a_ln) {
+                const f32x4 g = *(const f32x4*)(lg + b * 32 + 8 * s);
+                const f32x4 bb = *(const f32x4*)(lb + b * 32 + 8 * s);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fa[s][e] = (fa[s][e] - mean) * rstd * g[e] + bb[e];
+            }
         }
     };
     auto mul = [&](const f32x4* fa, const f32x4* fw) {
@@ -92,25 +147,62 @@ __global__ __launch_bounds__(1024) void gemm_f32_direct_kernel(GemmP p) {
     }
 }
 
-// returns false when the problem is not a few-row fp32 GEMM this kernel covers (the caller falls back to gemm.hip)
-bool launch_gemm_f32_direct(const GemmP& p, hipStream_t st) {
+template <int TQ, int KS>
+__global__ __launch_bounds__(1024) void gemm_f32_direct_kernel(GemmP p) {
+    __shared__ float part[16 * 1024];  // [ks][q][reg][lane]
+    __shared__ float lnst[32][2];
+    gemm_f32_direct_body<TQ, KS>(p, blockIdx.x, part, lnst);
+}
+
+// up to four independent problems in one launch: blockIdx.y picks the problem (the four decoder-embedding GEMMs of a
+// forward, one per modality, are 4 launches of ~7 us each otherwise)
+struct GemmGroupP {
+    GemmP p[4];
+};
+__global__ __launch_bounds__(1024) void gemm_f32_direct_group_kernel(GemmGroupP g) {
+    __shared__ float part[16 * 1024];
+    __shared__ float lnst[32][2];
+    const GemmP& p = g.p[blockIdx.y];
+    const int tiles = ((p.M + 31) / 32) * (p.N / 32);
+    if ((int)blockIdx.x >= tiles) return;
+    gemm_f32_direct_body<1, 16>(p, blockIdx.x, part, lnst);
+}
+
+bool gemm_f32_direct_covers(const GemmP& p) {
     if (!p.Cf || p.Cb || p.M > 1024 || p.M < 1) return false;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || (p.lda % 4) || (p.ldw % 4)) return false;
     const long long tiles64 = (long long)((p.M + 63) / 64) * (p.N / 64);
     // Measured (tools/gemm_bench_f32.py, variants 0 / 2): wins where the problem is tiny -- K = 512 with fewer than
     // 128 64x64 tiles (policy pass 6.4 vs 9.6 us, re-score out-proj 11.9 vs 15.7 us); loses to the LDS-shared tile
-    // once operands are re-read by many workgroups (M = 784, N >= 1024: 39 vs 25 us) and on K = 2048.
+    // once operands are re-read by many workgroups (M = 784, N >= 1024: 39 vs 25 us) and on K = 2048 (one launch with
+    // 128-deep slices: 20.6 us against 7.2 + 7.4 us for split-K slabs + the row-wise reduce, which also applies the
+    // LayerNorm that follows).
     if (p.K > 512 || tiles64 >= 128) return false;
-    const bool deep = true;  // 32x32 tiles, 16 K slices (the 64x64 / 4-slice shape is kept for experiments)
-    if (deep) {
-        if (p.N % 32 != 0 || p.K % (16 * 32) != 0) return false;
-        const int grid = ((p.M + 31) / 32) * (p.N / 32);
-        hipLaunchKernelGGL((gemm_f32_direct_kernel<1, 16>), dim3(grid), dim3(1024), 0, st, p);
-    } else {
-        if (p.N % 64 != 0 || p.K % (4 * 32) != 0) return false;
-        const int grid = ((p.M + 63) / 64) * (p.N / 64);
-        hipLaunchKernelGGL((gemm_f32_direct_kernel<4, 4>), dim3(grid), dim3(1024), 0, st, p);
+    if (p.N % 32 != 0 || p.K % (16 * 32) != 0) return false;
+    if (p.a_ln_g && (!p.a_ln_b || p.K % 256 != 0 || p.K > 2048 || ((uintptr_t)p.a_ln_g & 15) || ((uintptr_t)p.a_ln_b & 15))) return false;
+    return true;
+}
+
+// returns false when the problem is not a few-row fp32 GEMM this kernel covers (the caller falls back to gemm.hip)
+bool launch_gemm_f32_direct(const GemmP& p, hipStream_t st) {
+    if (!gemm_f32_direct_covers(p)) return false;
+    const int grid = ((p.M + 31) / 32) * (p.N / 32);
+    hipLaunchKernelGGL((gemm_f32_direct_kernel<1, 16>), dim3(grid), dim3(1024), 0, st, p);
+    return true;
+}
+
+bool launch_gemm_f32_direct_group(const GemmP* ps, int n, hipStream_t st) {
+    if (n < 1 || n > 4) return false;
+    GemmGroupP g;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!gemm_f32_direct_covers(ps[i])) return false;
+        g.p[i] = ps[i];
+        const int t = ((ps[i].M + 31) / 32) * (ps[i].N / 32);
+        tiles = t > tiles ? t : tiles;
     }
+    for (int i = n; i < 4; ++i) g.p[i] = ps[0];
+    hipLaunchKernelGGL(gemm_f32_direct_group_kernel, dim3(tiles, n), dim3(1024), 0, st, g);
     return true;
 }
 

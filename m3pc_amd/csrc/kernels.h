@@ -51,8 +51,14 @@ struct GemmP {
     const float* ln_g;
     const float* ln_b;
     float* ln_out;
+    // optional (few-row fp32 kernel only, K == the row length, K % 256 == 0): A is LayerNorm(A rows) * a_ln_g + a_ln_b,
+    // normalised on the fly while the operand is loaded (the arithmetic of layernorm_vec_kernel, bit for bit)
+    const float* a_ln_g;
+    const float* a_ln_b;
 };
 int launch_gemm(const GemmP& p, int dtype, hipStream_t st);
+bool gemm_f32_direct_covers(const GemmP& p);             // would launch_gemm_f32_direct take this problem (incl. a_ln_*)?
+bool launch_gemm_f32_direct_group(const GemmP* ps, int n, hipStream_t st);  // n <= 4 covered problems in ONE launch
 bool launch_gemm_ring(const GemmP& p, hipStream_t st);  // bf16, many rows: 256x256 tile, 4-slot LDS-DMA ring (gemm_ring.hip)
 bool launch_gemm_persist(const GemmP& p, hipStream_t st);  // bf16, many rows: persistent 256x256 tiles (gemm_persist.hip)
 bool launch_gemm_rs(const GemmP& p, hipStream_t st);    // bf16, many rows: register-staged 128x128 ring (gemm_rs.hip)
@@ -290,7 +296,8 @@ void launch_select(const SelectP& p, hipStream_t st);
 // indices of the k largest values (descending; ties -> lower index first), n <= 16384, k <= n
 void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st);
 // re-score window statistics over the kk best entries idx (best first); stats = {n, margin to the best entry outside, max, raw count}
-void launch_window_stats(const float* v, const int* idx, int kk, int kmin, int kmax, float window, float* stats, hipStream_t st);
+void launch_window_stats(const float* v, const int* idx, int kk, int kmin, int kmax, float window, float* stats, float* host_stats,
+                         float seq, hipStream_t st);
 // dst[index[i]] = src[i]
 void launch_scatter(const float* src, const int* index, int n, float* dst, int* index_copy, hipStream_t st);  // + index_copy[i] = index[i]
 

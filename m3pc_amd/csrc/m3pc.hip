@@ -285,6 +285,17 @@ int gemm(m3pc_handle* h, const GemmP& p_in, int dt, hipStream_t st) {
     return launch_gemm(p, dt, st);
 }
 
+// Few-row fp32 passes: can the LayerNorm in front of GEMM `p` ride on its operand load (gemm_f32_direct.hip: a_ln_*)?
+// `p` must already read the un-normalised rows (A = X, lda = d) and carry a_ln_g / a_ln_b.
+// Measured on the policy pass: the folded GEMM takes 11-12.5 us where GEMM 6.8 + LayerNorm launch 4.3-5
+// took 11-12 -- every workgroup recomputes its rows' statistics behind a barrier before its K loop starts, which costs what
+// the launch cost.  Neutral, so OFF by default (M3PC_LN_FOLD=1 turns it on for A/B runs); the GPU tests pass either way.
+bool can_fold_ln(m3pc_handle* h, const GemmP& p, int dt) {
+    static const bool on = getenv("M3PC_LN_FOLD") != nullptr && getenv("M3PC_NO_F32_DIRECT") == nullptr &&
+                           getenv("M3PC_GEMM_VARIANT") == nullptr;  // A/B switch
+    return dt == DT_F32 && on && h->allow_splitk && h->splitk_ws && gemm_f32_direct_covers(p);
+}
+
 GemmP gemm_basic(const void* A, int lda, const void* Wp, int ldw, int M, int N, int K, const float* bias) {
     GemmP p;
     memset(&p, 0, sizeof(p));
@@ -402,6 +413,20 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
         ln.Yb = (bf16_t*)h->Hn;
     else
         ln.Yf = (float*)h->Hn;
+    // norm1 in front of the Q|K|V projection: folded into that GEMM's operand load in the few-row fp32 passes
+    GemmP pqkv = gemm_basic(h->Hn, d, Wop(h, pfx + ".self_attn.in_proj_weight", dt), d, rows, 3 * d, d,
+                            W(h, pfx + ".self_attn.in_proj_bias").f);
+    gemm_out(pqkv, dt, h->QKV, 3 * d);
+    if (!ln1_done && n_sh == 0) {
+        GemmP t = pqkv;
+        t.A = X;
+        t.a_ln_g = ln.g1;
+        t.a_ln_b = ln.b1;
+        if (can_fold_ln(h, t, dt)) {
+            pqkv = t;
+            ln1_done = true;
+        }
+    }
     if (!ln1_done) launch_layernorm(ln, st);  // the embedding kernel already wrote norm1(X) of the first layer
     if (n_sh > 0) {
         // First layer of a candidate pass: the first n_sh tokens are the same for every candidate (history), so
@@ -455,12 +480,7 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
         a.scale = 1.0f / sqrtf((float)h->hd);
         launch_attention(a, dt, st);
     } else {
-    {
-        GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".self_attn.in_proj_weight", dt), d, rows, 3 * d, d,
-                             W(h, pfx + ".self_attn.in_proj_bias").f);
-        gemm_out(p, dt, h->QKV, 3 * d);
-        gemm(h, p, dt, st);
-    }
+    gemm(h, pqkv, dt, st);
     {
         AttnP a;
         memset(&a, 0, sizeof(a));
@@ -526,18 +546,26 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
         gemm_out(p, DT_F32, X, d);
         ln.g1 = W(h, pfx + ".norm2.weight").f;
         ln.b1 = W(h, pfx + ".norm2.bias").f;
-        if (dt == DT_F32) {  // few-row fp32 passes: norm2 rides on the split-K reduce when there is one
-            p.ln_g = ln.g1;
-            p.ln_b = ln.b1;
-            p.ln_out = ln.Yf;
+        // norm2: folded into linear1's operand load (few-row fp32), else on the split-K reduce of this GEMM, else a launch
+        GemmP p1 = gemm_basic(h->Hn, d, Wop(h, pfx + ".linear1.weight", dt), d, rows, ff, d, W(h, pfx + ".linear1.bias").f);
+        p1.gelu = 1;
+        gemm_out(p1, dt, h->F, ff);
+        GemmP t = p1;
+        t.A = X;
+        t.a_ln_g = ln.g1;
+        t.a_ln_b = ln.b1;
+        if (can_fold_ln(h, t, dt)) {
+            gemm(h, p, dt, st);
+            gemm(h, t, dt, st);
+        } else {
+            if (dt == DT_F32) {
+                p.ln_g = ln.g1;
+                p.ln_b = ln.b1;
+                p.ln_out = ln.Yf;
+            }
+            if (!gemm(h, p, dt, st)) launch_layernorm(ln, st);
+            gemm(h, p1, dt, st);
         }
-        if (!gemm(h, p, dt, st)) launch_layernorm(ln, st);
-    }
-    {
-        GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".linear1.weight", dt), d, rows, ff, d, W(h, pfx + ".linear1.bias").f);
-        p.gelu = 1;
-        gemm_out(p, dt, h->F, ff);
-        gemm(h, p, dt, st);
     }
     {
         GemmP p = gemm_basic(h->F, ff, Wop(h, pfx + ".linear2.weight", dt), ff, rows, d, ff, W(h, pfx + ".linear2.bias").f);
@@ -651,8 +679,26 @@ void dec_embed(m3pc_handle* h, int k, const void* Zop, RowMap amap, float* Yout,
 
 // Full (un-pruned) decoder on `batch` sequences: Z (4T rows each, operand dtype) -> Y (fp32) after all layers.
 int run_decoder_full(m3pc_handle* h, const void* Zop, int batch, int dt, hipStream_t st) {
-    const int T = h->T;
-    for (int k = 0; k < 4; ++k) {
+    const int T = h->T, d = h->d;
+    bool grouped = false;
+    static const bool no_group = getenv("M3PC_NO_GEMM_GROUP") != nullptr || getenv("M3PC_NO_F32_DIRECT") != nullptr ||
+                                 getenv("M3PC_GEMM_VARIANT") != nullptr;  // A/B switches
+    if (dt == DT_F32 && !no_group && h->allow_splitk) {  // few-row fp32 pass: the four modality GEMMs as one launch
+        GemmP ps[4];
+        for (int k = 0; k < 4; ++k) {
+            RowMap m{T, 4 * T, k * T};
+            ps[k] = gemm_basic(Zop, d, Wop(h, std::string("decoder_embed_dict.") + KEYN[k] + ".weight", dt), d, batch * T, d, d, nullptr);
+            ps[k].amap = m;
+            ps[k].cmap = m;
+            ps[k].rowtab = h->Edec[k];
+            ps[k].rt_mod = T;
+            ps[k].rt_ld = d;
+            gemm_out(ps[k], DT_F32, h->Y, d);
+        }
+        GemmTimer t(h, st, 4 * 2.0 * batch * T * (double)d * d, dt);
+        grouped = launch_gemm_f32_direct_group(ps, 4, st);
+    }
+    for (int k = 0; k < 4 && !grouped; ++k) {
         RowMap m{T, 4 * T, k * T};
         dec_embed(h, k, Zop, m, h->Y, m, batch * T, T, dt, st);
     }
@@ -966,11 +1012,19 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         ln.Yb = (bf16_t*)h->Hn;
     else
         ln.Yf = (float*)h->Hn;
-    launch_layernorm(ln, st);
-    {  // K|V of the un-masked tokens: in_proj rows [d, 3d)
+    {  // K|V of the un-masked tokens: in_proj rows [d, 3d); norm1 rides on the operand load in the few-row fp32 pass
         const char* wkv = (const char*)Wop(h, pfx + ".self_attn.in_proj_weight", dt) + (size_t)d * d * es;
         GemmP p = gemm_basic(h->Hn, d, wkv, d, n * Le, 2 * d, d, W(h, pfx + ".self_attn.in_proj_bias").f + d);
         gemm_out(p, dt, h->QKV, 2 * d);
+        GemmP t = p;
+        t.A = h->Y;
+        t.a_ln_g = ln.g1;
+        t.a_ln_b = ln.b1;
+        if (can_fold_ln(h, t, dt)) {
+            p = t;
+        } else {
+            launch_layernorm(ln, st);
+        }
         gemm(h, p, dt, st);
     }
     // queries
@@ -1105,18 +1159,25 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         ln.rows = n * nq;
         ln.g1 = W(h, pfx + ".norm2.weight").f;
         ln.b1 = W(h, pfx + ".norm2.bias").f;
-        if (dt == DT_F32) {  // re-score: norm2 rides on the split-K reduce when there is one
-            p.ln_g = ln.g1;
-            p.ln_b = ln.b1;
-            p.ln_out = ln.Yf;
+        GemmP p1 = gemm_basic(h->Hn, d, Wop(h, pfx + ".linear1.weight", dt), d, n * nq, h->ff, d, W(h, pfx + ".linear1.bias").f);
+        p1.gelu = 1;
+        gemm_out(p1, dt, h->F, h->ff);
+        GemmP t = p1;
+        t.A = Y1;
+        t.a_ln_g = ln.g1;
+        t.a_ln_b = ln.b1;
+        if (can_fold_ln(h, t, dt)) {  // re-score: norm2 rides on linear1's operand load ...
+            gemm(h, p, dt, st);
+            gemm(h, t, dt, st);
+        } else {
+            if (dt == DT_F32) {       // ... or on the split-K reduce when there is one
+                p.ln_g = ln.g1;
+                p.ln_b = ln.b1;
+                p.ln_out = ln.Yf;
+            }
+            if (!gemm(h, p, dt, st)) launch_layernorm(ln, st);
+            gemm(h, p1, dt, st);
         }
-        if (!gemm(h, p, dt, st)) launch_layernorm(ln, st);
-    }
-    {
-        GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".linear1.weight", dt), d, n * nq, h->ff, d, W(h, pfx + ".linear1.bias").f);
-        p.gelu = 1;
-        gemm_out(p, dt, h->F, h->ff);
-        gemm(h, p, dt, st);
     }
     {
         GemmP p = gemm_basic(h->F, h->ff, Wop(h, pfx + ".linear2.weight", dt), h->ff, n * nq, d, h->ff, W(h, pfx + ".linear2.bias").f);
@@ -1753,7 +1814,7 @@ int m3pc_rescore_topk(m3pc_handle* h, const m3pc_plan_args* a, const float* stat
 }
 
 int m3pc_topk_window(m3pc_handle* h, const float* expect_return, int n_total, int kmax, int kmin, float window, int* topk_index,
-                     float* stats, void* stream) {
+                     float* stats, float* host_stats, float seq, void* stream) {
     if (!h || !expect_return || !topk_index || !stats) return fail(M3PC_EINVAL, "null argument");
     if (n_total < 1 || n_total > 16384) return fail(M3PC_EINVAL, "top-k supports n_total <= 16384");
     if (kmax < 1 || kmax > 1023 || kmin < 1 || kmin > kmax || !(window >= 0.f)) return fail(M3PC_EINVAL, "bad kmin/kmax/window");
@@ -1761,7 +1822,7 @@ int m3pc_topk_window(m3pc_handle* h, const float* expect_return, int n_total, in
     HIPCHK(hipSetDevice(h->device));
     const int kk = kmax + 1 < n_total ? kmax + 1 : n_total;
     launch_topk(expect_return, n_total, kk, topk_index, st);
-    launch_window_stats(expect_return, topk_index, kk, kmin, kmax, window, stats, st);
+    launch_window_stats(expect_return, topk_index, kk, kmin, kmax, window, stats, host_stats, seq, st);
     return check_launch("topk_window");
 }
 

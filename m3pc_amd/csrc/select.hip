@@ -1,6 +1,8 @@
 // The cross-candidate tail of a plan step (learner.py:318-325) and the top-k used by the fp32 re-score.
 // Everything here is one workgroup: N <= 16384 scores live in registers / LDS, reductions are 64-lane
 // shuffles + one LDS hop.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace m3pc {
@@ -176,6 +178,34 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float* v, int n
 // distinct, so rank = #(greater keys) is a permutation and the elements of rank < k write themselves out.  No shuffle
 // chains, no rounds: ~5 us at n = 1024 where the k-round selection below takes 33 (16 rounds x 12 dependent shuffles,
 // twice).
+// Many-block form of the same ranking (n <= 2048): 256 threads per block, thread t of block b ranks element 64 b + (t & 63)
+// against a quarter of the keys (t >> 6), the four partial ranks meet in LDS.  16 blocks at n = 1024 instead of one:
+// the n^2 / 2 key comparisons spread over 16 CUs (20 us -> a few).
+__global__ __launch_bounds__(256) void topk_rank_blocks_kernel(const float* v, int n, int k, int* idx_out) {
+    __shared__ __attribute__((aligned(16))) unsigned long long keys[2048];
+    __shared__ int part[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+    for (int e = tid; e < 2048; e += 256) keys[e] = e < n ? ((unsigned long long)orderable(v[e]) << 32) | (unsigned int)(~e) : 0ull;
+    __syncthreads();
+    const int e = blockIdx.x * 64 + lane;
+    const unsigned long long mine = e < n ? keys[e] : 0ull;
+    const int n4 = (((n + 3) / 4) + 1) & ~1;  // keys per quarter, even (keys past n are 0: never greater than a real key)
+    int rank = 0;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const int j0 = q * n4, j1 = j0 + n4 < 2048 ? j0 + n4 : 2048;
+#pragma unroll 8
+    for (int j = j0; j < j1; j += 2) {
+        const u64x2 kj = *(const u64x2*)&keys[j];
+        rank += (kj.x > mine) + (kj.y > mine);
+    }
+    part[q][lane] = rank;
+    __syncthreads();
+    if (q == 0 && e < n) {
+        rank = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+        if (rank < k) idx_out[rank] = e;
+    }
+}
+
 __global__ __launch_bounds__(1024) void topk_rank_kernel(const float* v, int n, int k, int* idx_out) {
     __shared__ __attribute__((aligned(16))) unsigned long long keys[2048];
     const int tid = threadIdx.x;
@@ -211,7 +241,9 @@ __global__ __launch_bounds__(1024) void topk_rank_kernel(const float* v, int n, 
 void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st) {
     if (n <= 0 || k <= 0) return;
     if (n <= 2048 && k <= n) {
-        hipLaunchKernelGGL(topk_rank_kernel, dim3(1), dim3(1024), 0, st, v, n, k, idx_out);
+        static const bool one_block = getenv("M3PC_TOPK_ONE_BLOCK") != nullptr;  // A/B switch
+        if (one_block) hipLaunchKernelGGL(topk_rank_kernel, dim3(1), dim3(1024), 0, st, v, n, k, idx_out);
+        else hipLaunchKernelGGL(topk_rank_blocks_kernel, dim3((n + 63) / 64), dim3(256), 0, st, v, n, k, idx_out);
         return;
     }
     if (k <= 64 && n <= 16384) {
@@ -231,7 +263,7 @@ void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st) {
 // idx: the kk best entries of v, best first.  n = clamp(#{i < kk: v[idx[i]] >= v[idx[0]] - window}, kmin, kmax) and the
 // distance from the best entry to the best one NOT among those n (infinity when there is none).
 __global__ __launch_bounds__(64) void window_stats_kernel(const float* v, const int* idx, int kk, int kmin, int kmax, float window,
-                                                          float* stats) {
+                                                          float* stats, float* host_stats, float seq) {
     const int lane = threadIdx.x;
     const float mx = v[idx[0]];
     int cnt = 0;
@@ -246,10 +278,19 @@ __global__ __launch_bounds__(64) void window_stats_kernel(const float* v, const 
         stats[1] = n < kk ? mx - v[idx[n]] : INFINITY;
         stats[2] = mx;
         stats[3] = (float)cnt;
+        if (host_stats) {  // host-mapped (pinned) copy the caller spins on: payload first, then the sequence number
+            host_stats[0] = (float)n;
+            host_stats[1] = n < kk ? mx - v[idx[n]] : INFINITY;
+            host_stats[2] = mx;
+            host_stats[3] = (float)cnt;
+            __threadfence_system();
+            __hip_atomic_store(host_stats + 4, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
-void launch_window_stats(const float* v, const int* idx, int kk, int kmin, int kmax, float window, float* stats, hipStream_t st) {
-    hipLaunchKernelGGL(window_stats_kernel, dim3(1), dim3(64), 0, st, v, idx, kk, kmin, kmax, window, stats);
+void launch_window_stats(const float* v, const int* idx, int kk, int kmin, int kmax, float window, float* stats, float* host_stats,
+                         float seq, hipStream_t st) {
+    hipLaunchKernelGGL(window_stats_kernel, dim3(1), dim3(64), 0, st, v, idx, kk, kmin, kmax, window, stats, host_stats, seq);
 }
 
 __global__ void scatter_kernel(const float* src, const int* index, int n, float* dst, int* index_copy) {

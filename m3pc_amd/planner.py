@@ -159,8 +159,8 @@ class HipPlanner:
             if self._delta is None:
                 self._delta = self._calibrate(er, rs, tail, N)
             kmax, kmin = min(self.rescore_max, N - 1 if N > 1 else 1), min(self.rescore_min, N)
-            cand, stats = self.handle.topk_window(er, max(kmax, 1), max(min(kmin, kmax), 1), 2.0 * self._delta)
-            st = stats.cpu()  # the one host read of the step: how many candidates are inside the window
+            # the one host read of the step: how many candidates are inside the window (pinned-memory spin, no stream sync)
+            cand, st = self.handle.topk_window_host(er, max(kmax, 1), max(min(kmin, kmax), 1), 2.0 * self._delta)
             n_re = int(st[0])
             top = cand[:n_re].contiguous()
             self.handle.rescore_listed(mode, states, actions, rewards, eps, er, top, *tail)
