@@ -14,7 +14,7 @@ from typing import Dict, Optional, Sequence
 import torch  # noqa: F401  (must precede the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libm3pc_hip.so")
+LIB_PATH = os.environ.get("M3PC_LIB") or os.path.join(_HERE, "libm3pc_hip.so")  # (M3PC_LIB: tools/ point at the lab build)
 
 STATES, ACTIONS, REWARDS, RETURNS = 0, 1, 2, 3
 KEYS = ("states", "actions", "rewards", "returns")

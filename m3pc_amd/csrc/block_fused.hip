@@ -554,6 +554,7 @@ bool launch_block_fused(const BlockP& p, hipStream_t st) {
     if (p.Hout && (((uintptr_t)p.Hout & 7) || (p.ldh % 4))) return false;
     if (p.out_mod > 0 && (p.M % p.out_mod != 0 || p.out_mod != 2 * p.out_grp)) return false;
     const dim3 grid((p.M + 127) / 128), block(256);
+#ifdef M3PC_LAB  // timing experiments (tools/block_bench.py): the lab build only
     if (p.variant == 1) hipLaunchKernelGGL(block_fused_kernel<1>, grid, block, 0, st, p);
     else if (p.variant == 2) hipLaunchKernelGGL(block_fused_kernel<2>, grid, block, 0, st, p);
     else if (p.variant == 3) hipLaunchKernelGGL(block_fused_kernel<3>, grid, block, 0, st, p);
@@ -561,7 +562,9 @@ bool launch_block_fused(const BlockP& p, hipStream_t st) {
     else if (p.variant == 5) hipLaunchKernelGGL(block_fused_kernel<5>, grid, block, 0, st, p);
     else if (p.variant == 6) hipLaunchKernelGGL(block_fused_kernel<6>, grid, block, 0, st, p);
     else if (p.variant == 7) hipLaunchKernelGGL(block_fused_kernel<7>, grid, block, 0, st, p);
-    else hipLaunchKernelGGL(block_fused_kernel<0>, grid, block, 0, st, p);
+    else
+#endif
+        hipLaunchKernelGGL(block_fused_kernel<0>, grid, block, 0, st, p);
     return true;
 }
 

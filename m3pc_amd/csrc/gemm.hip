@@ -373,8 +373,10 @@ int launch_gemm(const GemmP& p, int dtype, hipStream_t st) {
     if (p.M <= 0) return 0;
     // default (variant 0): many-row bf16 problems on the LDS-DMA kernel (gemm_glds.hip, 128x128 tiles),
     // few-row problems on the register-staged kernel below; variants 4-9 are the experimental tilings
+#ifdef M3PC_LAB  // experimental tilings kept for tools/gemm_bench.py: compiled into libm3pc_hip_lab.so only
     if (dtype == DT_BF16 && p.variant == 9 && launch_gemm_persist(p, st)) return 0;
     if (dtype == DT_BF16 && p.variant == 36 && launch_gemm_rs(p, st)) return 0;
+#endif
     // long-K many-row problems (this step's FFN2, K = 2048): 256x256 tiles at one wave per SIMD (gemm_big.hip).  Same
     // MFMA instruction, k order and epilogue arithmetic as the 128x128 ring kernel, so results are bit-identical and the
     // choice may depend on the row count.  It needs about one tile per CU to pay (one workgroup per CU, no overlap).
@@ -391,7 +393,9 @@ int launch_gemm(const GemmP& p, int dtype, hipStream_t st) {
     if (dtype == DT_BF16 && p.variant == 0 && !no_big && p.K >= 1024 && (long long)((p.M + 255) / 256) * (p.N / 256) >= 224 &&
         launch_gemm_big(p, st))
         return 0;
+#ifdef M3PC_LAB
     if (dtype == DT_BF16 && p.variant >= 7 && p.variant != 9 && p.variant < 20 && launch_gemm_ring(p, st)) return 0;
+#endif
     if (dtype == DT_BF16 && (p.variant == 0 || (p.variant >= 2 && p.variant < 7) || (p.variant >= 20 && p.variant <= 32)) &&
         launch_gemm_glds(p, st))
         return 0;

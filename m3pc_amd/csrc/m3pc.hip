@@ -279,8 +279,10 @@ int gemm(m3pc_handle* h, const GemmP& p_in, int dt, hipStream_t st) {
     // same row count (policy pass, generic forward, top-k re-score): sharded candidate scores stay bit-identical
     p.ws = h->allow_splitk ? h->splitk_ws : nullptr;
     p.ws_bytes = h->splitk_ws_bytes;
+#ifdef M3PC_LAB  // (the lab build only: an environment variable must not change which kernels the product runs)
     static const int env_variant = getenv("M3PC_GEMM_VARIANT") ? atoi(getenv("M3PC_GEMM_VARIANT")) : 0;  // A/B runs
     if (env_variant) p.variant = env_variant;
+#endif
     GemmTimer t(h, st, 2.0 * p.M * (double)p.N * p.K, dt);
     return launch_gemm(p, dt, st);
 }

@@ -1,4 +1,6 @@
-"""Time the fused layer tail (block_fused.hip) alone on the plan step's row counts.
+"""(Timing variants other than the product kernels live in the lab build: `python -m m3pc_amd.build --lab`, then
+run with M3PC_LIB=m3pc_amd/libm3pc_hip_lab.so.)
+Time the fused layer tail (block_fused.hip) alone on the plan step's row counts.
 usage: python tools/block_bench.py [rows ...]     variants: 0 product, 1 no DMA pieces, 2 no gelu"""
 import ctypes as C
 import os

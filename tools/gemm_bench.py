@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Time the library's MFMA GEMM on the shapes of one C2 plan step (N=1024, H=16, T=32) -- a kernel
+"""(Timing variants other than the product kernels live in the lab build: `python -m m3pc_amd.build --lab`, then
+run with M3PC_LIB=m3pc_amd/libm3pc_hip_lab.so.)
+Time the library's MFMA GEMM on the shapes of one C2 plan step (N=1024, H=16, T=32) -- a kernel
 iteration tool, not part of the product.  Usage on the GPU box:  python tools/gemm_bench.py [variants...]"""
 import ctypes as C
 import os

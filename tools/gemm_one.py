@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Time ONE bf16 GEMM shape on chosen kernel variants (kernel iteration tool, not part of the product).
+"""(Timing variants other than the product kernels live in the lab build: `python -m m3pc_amd.build --lab`, then
+run with M3PC_LIB=m3pc_amd/libm3pc_hip_lab.so.)
+Time ONE bf16 GEMM shape on chosen kernel variants (kernel iteration tool, not part of the product).
 Usage on the GPU box:  python tools/gemm_one.py M N K gelu res f32out variant [variant...]"""
 import ctypes as C
 import os
