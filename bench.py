@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--rescore", default="bound", choices=["bound", "topk"],
                     help="fp32 re-score set: every candidate within 2*delta of the bf16 maximum (default) or a fixed top-k")
     ap.add_argument("--rescore-topk", type=int, default=16)
+    ap.add_argument("--rescore-min", type=int, default=None, help="smallest bound-driven re-score set (default: the planner's)")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / closed-loop / shipped-config side measurements")
     ap.add_argument("--strong", action="store_true", help="keep the global candidate count fixed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -158,7 +159,7 @@ def main():
     qsd, om, os_ = synth.make_critic(dims, 0) if critic_mode else (None, None, None)
     planner = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), qsd, om, os_,
                          precision=args.precision, rescore_topk=args.rescore_topk, device=local_rank, generator=gen,
-                         rescore=args.rescore, group=torch.distributed.group.WORLD if world > 1 else None)
+                         rescore=args.rescore, **({"rescore_min": args.rescore_min} if args.rescore_min else {}), group=torch.distributed.group.WORLD if world > 1 else None)
     hist = synth.make_history(dims, 0)
     hist["path_length"] = 500
     states, actions, rewards, h, rtg = planner.assemble_window(hist, rtg=3.0)

@@ -314,12 +314,9 @@ class Handle:
                                         None, 0.0, _stream(self.device)))
         return top, stats
 
-    def topk_window_host(self, expect_return: torch.Tensor, kmax: int, kmin: int, window: float):
-        """``topk_window`` whose statistics arrive on the host without a stream synchronisation: the kernel also writes them
-        into a pinned, host-mapped buffer followed by a sequence number, and this call spins on that number (a few
-        microseconds after the kernel ends, where a blocking device-to-host copy costs tens).  Returns (top ids on the
-        device, [n, margin_outside, max, raw count] as python floats)."""
-        import time as _t
+    def topk_window_issue(self, expect_return: torch.Tensor, kmax: int, kmin: int, window: float):
+        """Launch ``topk_window`` with its statistics also written to a pinned, host-mapped buffer followed by a sequence
+        number.  Returns (top ids on the device, ticket for ``topk_window_wait``); one ticket outstanding at a time."""
         n = expect_return.numel()
         if not hasattr(self, "_hs"):
             self._hs = torch.zeros(8, dtype=torch.float32).pin_memory()
@@ -331,14 +328,27 @@ class Handle:
         stats = torch.empty((4,), dtype=torch.float32, device=self.device)
         check(self.lib.m3pc_topk_window(self._h, _ptr(expect_return), n, kmax, kmin, float(window), _ptr(top), _ptr(stats),
                                         self._hs.data_ptr(), seq, _stream(self.device)))
+        return top, (seq, stats)
+
+    def topk_window_wait(self, ticket):
+        """The statistics of ``topk_window_issue`` on the host without a stream synchronisation: spins on the sequence
+        number in the mapped buffer (visible a few microseconds after the kernel ends, where a blocking device-to-host
+        copy costs tens).  [n, margin_outside, max, raw count] as python floats."""
+        import time as _t
+        seq, stats = ticket
         hs = self._hs_np
         t0 = _t.perf_counter()
         spins = 0
         while hs[4] != seq:
             spins += 1
             if (spins & 1023) == 0 and _t.perf_counter() - t0 > 0.25:  # never hang on the mapped buffer: the ordinary copy
-                return top, [float(x) for x in stats.cpu()]
-        return top, [float(hs[0]), float(hs[1]), float(hs[2]), float(hs[3])]
+                return [float(x) for x in stats.cpu()]
+        return [float(hs[0]), float(hs[1]), float(hs[2]), float(hs[3])]
+
+    def topk_window_host(self, expect_return: torch.Tensor, kmax: int, kmin: int, window: float):
+        """``topk_window_issue`` + ``topk_window_wait``: (top ids on the device, statistics on the host)."""
+        top, ticket = self.topk_window_issue(expect_return, kmax, kmin, window)
+        return top, self.topk_window_wait(ticket)
 
     def rescore_listed(self, mode: int, states, actions, rewards, eps, expect_return: torch.Tensor, index: torch.Tensor,
                        horizon: int, rtg: float, lmbda: float, discount: float):

@@ -546,6 +546,286 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ decoder input
+// kv_fused_kernel: decoder embedding of the un-masked tokens -> norm1 -> K|V projection, the same machinery (transposed
+// products, one wave = 32 token rows with the 512 embedding features in its accumulators, packed fragment stream
+// through the three-slot ring).  Stream of a key: 512 embedding fragments (phase sb = k-steps 2 sb, 2 sb + 1 of the 16
+// feature tiles, natural k: the operand is loaded from Z), then for K and for V 512 fragments in the same phase order
+// (permuted k: the operand is the LayerNorm of an accumulator).  48 phases.  The K half is stored (bf16) before the V
+// half starts: stores and the DMA pieces share vmcnt and may complete out of order with respect to each other, so the
+// stream is drained once there (s_waitcnt vmcnt(0)) instead of counting pieces across the stores.
+namespace {
+constexpr int KV_FR = FR_OUT + 2 * FR_OUT;   // 1536
+constexpr int KV_NRS = KV_FR / RS_FR;        // 48
+constexpr int KT_G = 0, KT_B = KT_G + BD, KT_BKV = KT_B + BD, KT_END = KT_BKV + 2 * BD;
+constexpr int KV_TAB_OFF = NSLOT * RS_B;
+constexpr int KV_LDS_BYTES = KV_TAB_OFF + KT_END * 4;
+}  // namespace
+
+__global__ __launch_bounds__(256) void pack_kv_stream_kernel(const bf16_t* __restrict__ We, const bf16_t* __restrict__ Wkv,
+                                                             bf16_t* __restrict__ out) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= KV_FR * 64) return;
+    const int f = gid >> 6, lane = gid & 63, r = lane & 31, h = lane >> 5;
+    bf16_t v[8];
+    const int g = f % FR_OUT, sb = g / 32, kk = (g % 32) / 16, jn = g % 16, s = 2 * sb + kk;
+    if (f < FR_OUT) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = We[(size_t)(32 * jn + r) * BD + 16 * s + 8 * h + j];
+    } else {
+        const int hf = f / FR_OUT - 1;
+        const size_t row = (size_t)(BD * hf + 32 * jn + r) * BD;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = Wkv[row + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
+    }
+    bf16_t* o = out + (size_t)gid * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = v[j];
+}
+
+size_t kv_stream_bytes() { return (size_t)KV_FR * 1024; }
+void launch_pack_kv_stream(const bf16_t* Wemb, const bf16_t* Wkv, bf16_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(pack_kv_stream_kernel, dim3(KV_FR * 64 / 256), dim3(256), 0, st, Wemb, Wkv, out);
+}
+
+namespace {
+
+__global__ __launch_bounds__(256, 1) void kv_fused_kernel(KvFusedP p) {
+    __shared__ __attribute__((aligned(1024))) char smem[KV_LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int tiles0 = (p.M[0] + 127) / 128;
+    const int grp = (int)blockIdx.x >= tiles0 ? 1 : 0;
+    const int tile = (int)blockIdx.x - grp * tiles0;
+    const int Mg = p.M[grp];
+    const RowMap map = p.map[grp];
+    const int rtok = tile * 128 + 32 * wu + l31;   // this lane's row of the group
+    const bool valid = rtok < Mg;
+    const int rld = valid ? rtok : Mg - 1;
+    const long long mrow = map.rpg ? (long long)(rld / map.rpg) * map.gstride + rld % map.rpg + map.off : rld;
+    const int lane16 = lane * 16;
+    long long stamps[6];
+    stamps[0] = __builtin_readcyclecounter();
+
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream[grp], 0, (unsigned)(KV_FR * 1024), 0x00020000);
+    (void)w_rs;
+    auto piece = [&](int st, int slot, int pc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int sw = st >= KV_NRS ? st - KV_NRS : st;
+        const int fo = (wu + 4 * pc) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lptr_t)(smem + slot * RS_B + fo), 16, lane16, sw * RS_B + fo, 0, 0);
+#endif
+    };
+    const char* const lbase0 = smem + lane16;
+    const char* const lbase2 = smem + 2 * RS_B + lane16;
+    auto frag = [&](int slot, int f) -> u32x4 { return *(const u32x4*)((slot == 2 ? lbase2 : lbase0 + slot * RS_B) + f * 1024); };
+    float* const tab = (float*)(smem + KV_TAB_OFF);
+
+    // ---- prologue
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) piece(s, s, pc);
+    piece(2, 2, 0);
+    if (tid < BD / 4) {
+        const int i = 4 * tid;
+        *(f32x4*)(tab + KT_G + i) = *(const f32x4*)(p.ln_g + i);
+        *(f32x4*)(tab + KT_B + i) = *(const f32x4*)(p.ln_b + i);
+        *(f32x4*)(tab + KT_BKV + i) = *(const f32x4*)(p.bkv + i);
+        *(f32x4*)(tab + KT_BKV + BD + i) = *(const f32x4*)(p.bkv + BD + i);
+    }
+    // Z fragments (B operand of the embedding; the LayerNorm fragments take their place) first: they come from HBM, the
+    // position-table rows (L2) follow in four batches behind them
+    u32x4 ofr[KS];
+    {
+        const bf16_t* const zrow = p.Z + (size_t)mrow * p.ldz + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) ofr[s] = *(const u32x4*)(zrow + 16 * s);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc[NT];
+    {
+        const float* rrow = p.rowtab[grp] + (size_t)(rld % p.rt_mod[grp]) * BD;
+        f32x4 xb[16];
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) xb[u] = *(const f32x4*)(rrow + 32 * (4 * bt + u / 4) + 8 * (u % 4) + 4 * lh);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[4 * bt + u / 4][4 * (u % 4) + i] = xb[u][i];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    stamps[1] = __builtin_readcyclecounter();
+
+    u32x4 R[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) R[0][k] = frag(0, k);
+    // one phase = one ring stage (see block_fused_kernel): 8 groups of {reads of the next group, one DMA piece, 4 MFMAs}
+    auto phase = [&](int ph, auto sl_c, auto&& mma) {
+        constexpr int SL = decltype(sl_c)::value;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g == 7) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) R[(g + 1) & 1][k] = g < 7 ? frag(SL, 4 * (g + 1) + k) : frag((SL + 1) % 3, k);
+            if (g < 7) piece(ph + 2, (SL + 2) % 3, 1 + g);
+            else piece(ph + 3, SL, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mma(4 * g + k, R[g & 1][k]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+
+    // ---- embedding: phase sb = k-steps 2 sb, 2 sb + 1 of all 16 feature tiles
+#define KV_PH(base, sb, SL, opnd) phase((base) + (sb), SL{}, [&](int i, u32x4 a) { mfma_a(acc[i % 16], a, opnd[2 * (sb) + i / 16]); });
+    KV_PH(0, 0, S0, ofr) KV_PH(0, 1, S1, ofr) KV_PH(0, 2, S2, ofr) KV_PH(0, 3, S0, ofr) KV_PH(0, 4, S1, ofr) KV_PH(0, 5, S2, ofr)
+    KV_PH(0, 6, S0, ofr) KV_PH(0, 7, S1, ofr) KV_PH(0, 8, S2, ofr) KV_PH(0, 9, S0, ofr) KV_PH(0, 10, S1, ofr) KV_PH(0, 11, S2, ofr)
+    KV_PH(0, 12, S0, ofr) KV_PH(0, 13, S1, ofr) KV_PH(0, 14, S2, ofr) KV_PH(0, 15, S0, ofr)
+    mfma_done_a(acc);
+    stamps[2] = __builtin_readcyclecounter();
+
+    // ---- norm1 of the embedded rows -> act (bf16 B-operand fragments)
+    u32x4 act[KS];
+    {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float x = acc[jn][e];
+                s1 += x;
+                s2 = fmaf(x, x, s2);
+                if (e == 15) __builtin_amdgcn_sched_barrier(0);
+            }
+        s1 = half_swap_sum(s1);
+        s2 = half_swap_sum(s2);
+        const float mean = s1 * (1.0f / BD);
+        float rstd = rsqrtf(fmaxf(s2 * (1.0f / BD) - mean * mean, 0.f) + 1e-5f);
+        float nmr = -mean * rstd;
+        acc_touch(acc);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            // (volatile asm statements keep their order: the table reads of fragment s stay behind this one, its arithmetic
+            // in front of the one that closes the iteration -- left alone, the compiler issues all 64 reads first and spills them)
+            asm volatile("" : "+v"(rstd), "+v"(nmr) : : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const int jn = s >> 1;
+            float y[8];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int q = 2 * (s & 1) + k, n = 32 * jn + 8 * q + 4 * lh;
+                const f32x4 g = *(const f32x4*)(tab + KT_G + n);
+                const f32x4 b = *(const f32x4*)(tab + KT_B + n);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[4 * k + i] = fmaf(fmaf(acc[jn][4 * q + i], rstd, nmr), g[i], b[i]);
+            }
+            bf16x8 w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = (bf16_t)y[j];
+            act[s] = __builtin_bit_cast(u32x4, w);
+            asm volatile("" : "+v"(act[s]));
+        }
+    }
+    stamps[3] = __builtin_readcyclecounter();
+
+    // The K|V products run with the operands SWAPPED (activations = A operand, weights = B operand: the register images
+    // are the same), so an accumulator holds  lane & 31 = feature, registers = token rows: one store instruction then
+    // writes 64 contiguous bytes of two rows, where the transposed form would scatter 8 bytes into each of 32 rows.
+    // Row byte offsets of the 16 token rows this lane stores (rows past the group's end: out of the buffer's range, dropped)
+    const __amdgpu_buffer_rsrc_t kv_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.KV, 0, p.kv_bytes, 0x00020000);
+    unsigned rowoff[16];
+    const float inv_rpg = 1.0f / (float)(map.rpg ? map.rpg : 1);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int rr = tile * 128 + 32 * wu + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        long long mr = rr;
+        if (map.rpg) {  // rr / rpg through the reciprocal (rr < 2^22), corrected by one either way
+            int qd = (int)((float)rr * inv_rpg), rm = rr - qd * map.rpg;
+            if (rm < 0) { --qd; rm += map.rpg; }
+            if (rm >= map.rpg) { ++qd; rm -= map.rpg; }
+            mr = (long long)qd * map.gstride + rm + map.off;
+        }
+        rowoff[e] = rr < Mg ? (unsigned)(mr * p.ldkv * 2 + l31 * 2) : 0x80000000u;
+    }
+    auto bias_init = [&](int hf) {
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn) {
+            const float b = tab[KT_BKV + BD * hf + 32 * jn + l31];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[jn][e] = b;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto store_half = [&](int hf) {
+        acc_touch(acc);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const bf16_t w = (bf16_t)acc[jn][e];
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, w), kv_rs, rowoff[e] + (BD * hf + 32 * jn) * 2, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+    };
+#define KV_PHS(base, sb, SL) phase((base) + (sb), SL{}, [&](int i, u32x4 a) { mfma_a(acc[i % 16], act[2 * (sb) + i / 16], a); });
+    // ---- K: phases 16..31 (phase 16 = slot 1)
+    bias_init(0);
+    KV_PHS(16, 0, S1) KV_PHS(16, 1, S2) KV_PHS(16, 2, S0) KV_PHS(16, 3, S1) KV_PHS(16, 4, S2) KV_PHS(16, 5, S0)
+    KV_PHS(16, 6, S1) KV_PHS(16, 7, S2) KV_PHS(16, 8, S0) KV_PHS(16, 9, S1) KV_PHS(16, 10, S2) KV_PHS(16, 11, S0)
+    KV_PHS(16, 12, S1) KV_PHS(16, 13, S2) KV_PHS(16, 14, S0) KV_PHS(16, 15, S1)
+    mfma_done_a(acc);
+    stamps[4] = __builtin_readcyclecounter();
+    store_half(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see the header: stores and DMA pieces share the counter)
+    // ---- V: phases 32..47 (phase 32 = slot 2)
+    bias_init(1);
+    KV_PHS(32, 0, S2) KV_PHS(32, 1, S0) KV_PHS(32, 2, S1) KV_PHS(32, 3, S2) KV_PHS(32, 4, S0) KV_PHS(32, 5, S1)
+    KV_PHS(32, 6, S2) KV_PHS(32, 7, S0) KV_PHS(32, 8, S1) KV_PHS(32, 9, S2) KV_PHS(32, 10, S0) KV_PHS(32, 11, S1)
+    KV_PHS(32, 12, S2) KV_PHS(32, 13, S0) KV_PHS(32, 14, S1) KV_PHS(32, 15, S2)
+#undef KV_PHS
+#undef KV_PH
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the pieces issued past the end of the stream
+    mfma_done_a(acc);
+    store_half(1);
+    stamps[5] = __builtin_readcyclecounter();
+    if (p.stamps && (int)blockIdx.x == p.stamp_block && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p.stamps[wu * 16 + k] = stamps[k];
+    }
+}
+
+}  // namespace
+
+bool launch_kv_fused(const KvFusedP& p, hipStream_t st) {
+    if (((uintptr_t)p.Z & 15) || (p.ldz % 8) || ((uintptr_t)p.KV & 7) || (p.ldkv % 4)) return false;
+    if (p.kv_bytes == 0 || p.kv_bytes >= 0x80000000u) return false;
+    int tiles = 0;
+    for (int g = 0; g < 2; ++g) {
+        if (p.M[g] < 0) return false;
+        if (p.M[g] == 0) continue;
+        if (!p.rowtab[g] || p.rt_mod[g] < 1 || ((uintptr_t)p.rowtab[g] & 15) || ((uintptr_t)p.wstream[g] & 1023) || !p.wstream[g]) return false;
+        tiles += (p.M[g] + 127) / 128;
+    }
+    if (p.M[0] == 0 && p.M[1] > 0) return false;  // (group 1 alone: pass it as group 0)
+    if (tiles == 0) return true;
+    hipLaunchKernelGGL(kv_fused_kernel, dim3(tiles), dim3(256), 0, st, p);
+    return true;
+}
+
 bool launch_block_fused(const BlockP& p, hipStream_t st) {
     if (p.M <= 0) return true;
     if (((uintptr_t)p.O & 15) || (p.ldo % 8) || ((uintptr_t)p.wstream & 1023)) return false;

@@ -105,6 +105,31 @@ size_t block_stream_bytes();
 void launch_pack_block_stream(const bf16_t* Wo, const bf16_t* W1, const bf16_t* W2, bf16_t* out, hipStream_t st);
 bool launch_block_fused(const BlockP& p, hipStream_t st);  // false: arguments not covered (caller takes the unfused path)
 
+// Decoder input of the un-masked tokens as one launch (block_fused.hip: kv_fused_kernel; d = 512, bf16 operands):
+//     y = Z W_k^T + rowtab_k[r % rt_mod]      decoder embedding of key k (mtm_model.py:665-676)
+//     K|V = LayerNorm(y) Wkv^T + bkv          norm1 + the K|V rows of the decoder layer's in_proj (bf16 out)
+// Two row groups (keys) per launch, each with its own embedding weights; tiles are key-pure.
+struct KvFusedP {
+    const bf16_t* Z;          // encoder output rows
+    int ldz;
+    int M[2];                 // rows of each group (0: group absent)
+    RowMap map[2];            // group row -> row of Z and of KV
+    const float* rowtab[2];   // (rt_mod, d) fp32
+    int rt_mod[2];
+    const bf16_t* wstream[2]; // launch_pack_kv_stream: embedding fragments, then the K|V fragments
+    const float* ln_g;
+    const float* ln_b;
+    const float* bkv;         // (2 d)
+    bf16_t* KV;               // (., 2 d) rows
+    int ldkv;
+    unsigned kv_bytes;        // size of the KV buffer in bytes (< 2 GiB): stores past it are dropped
+    long long* stamps;        // optional (4 waves, 16) shader-clock phase stamps of workgroup stamp_block
+    int stamp_block;
+};
+size_t kv_stream_bytes();
+void launch_pack_kv_stream(const bf16_t* Wemb, const bf16_t* Wkv, bf16_t* out, hipStream_t st);
+bool launch_kv_fused(const KvFusedP& p, hipStream_t st);  // false: arguments not covered
+
 // LayerNorm over the last dim (eps 1e-5), one wave per row; optional second LayerNorm applied to
 // the result (decoder.norm followed by an output head's LayerNorm).  d <= 1024, d % 64 == 0.
 struct LnP {

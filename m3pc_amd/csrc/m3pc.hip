@@ -142,9 +142,14 @@ struct m3pc_handle {
     bool allow_splitk = true;     // see gemm(): off while sharded candidates are scored
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipStream_t> auxs;   // auxs[0] == aux
+    std::vector<hipEvent_t> ev_joins;
+    std::vector<int> stream_split;
     std::map<std::string, std::unique_ptr<Plan>> plans;
     // packed MFMA-fragment weight streams of the fused layer tails (block_fused.hip), by block prefix
     std::map<std::string, bf16_t*> wstream;
+    // packed streams of the fused decoder input (kv_fused_kernel), by key: embedding of key k + K|V rows of decoder layer 0
+    bf16_t* kvstream[4] = {nullptr, nullptr, nullptr, nullptr};
     // profiling
     bool prof = false;
     std::vector<EventPair> ev;
@@ -996,11 +1001,6 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
 
     // decoder inputs of the un-masked tokens (kept sets are prefixes 0..kept-1 for the fd mask)
     const void* enc_op = dt == DT_BF16 ? h->Z : (const void*)h->EncOut;
-    for (int k = 0; k < 2; ++k) {
-        if (!pl->kept[k]) continue;
-        RowMap mm{pl->kept[k], Le, pl->enc_off[k]};
-        dec_embed(h, k, enc_op, mm, h->Y, mm, n * pl->kept[k], pl->kept[k], dt, st);
-    }
     const std::string pfx = "decoder.layers.0";
     LnP ln;
     memset(&ln, 0, sizeof(ln));
@@ -1014,6 +1014,40 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         ln.Yb = (bf16_t*)h->Hn;
     else
         ln.Yf = (float*)h->Hn;
+    bool kv_done = false;
+    static const bool no_kv_fused = getenv("M3PC_NO_KV_FUSED") != nullptr || getenv("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
+    if (dt == DT_BF16 && !no_kv_fused && q.all_masked && (long long)n * Le >= 512 && h->kvstream[0] && (pl->kept[0] || pl->kept[1])) {
+        // embedding, norm1 and the K|V projection in one launch (kv_fused_kernel): the fp32 rows Y are consumed by nothing
+        // else when every scored token is masked
+        KvFusedP kp;
+        memset(&kp, 0, sizeof(kp));
+        kp.Z = (const bf16_t*)h->Z;
+        kp.ldz = d;
+        int g = 0;
+        for (int k = 0; k < 2; ++k) {
+            if (!pl->kept[k]) continue;
+            kp.M[g] = n * pl->kept[k];
+            kp.map[g] = RowMap{pl->kept[k], Le, pl->enc_off[k]};
+            kp.rowtab[g] = h->Edec[k];
+            kp.rt_mod[g] = pl->kept[k];
+            kp.wstream[g] = h->kvstream[k];
+            ++g;
+        }
+        kp.ln_g = ln.g1;
+        kp.ln_b = ln.b1;
+        kp.bkv = W(h, pfx + ".self_attn.in_proj_bias").f + d;
+        kp.KV = (bf16_t*)h->QKV;
+        kp.ldkv = 2 * d;
+        kp.kv_bytes = (unsigned)((size_t)n * Le * 2 * d * 2);
+        GemmTimer t(h, st, 2.0 * n * Le * (3.0 * d * d), dt);
+        kv_done = launch_kv_fused(kp, st);
+    }
+    if (!kv_done) {
+    for (int k = 0; k < 2; ++k) {
+        if (!pl->kept[k]) continue;
+        RowMap mm{pl->kept[k], Le, pl->enc_off[k]};
+        dec_embed(h, k, enc_op, mm, h->Y, mm, n * pl->kept[k], pl->kept[k], dt, st);
+    }
     {  // K|V of the un-masked tokens: in_proj rows [d, 3d); norm1 rides on the operand load in the few-row fp32 pass
         const char* wkv = (const char*)Wop(h, pfx + ".self_attn.in_proj_weight", dt) + (size_t)d * d * es;
         GemmP p = gemm_basic(h->Hn, d, wkv, d, n * Le, 2 * d, d, W(h, pfx + ".self_attn.in_proj_bias").f + d);
@@ -1028,6 +1062,7 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
             launch_layernorm(ln, st);
         }
         gemm(h, p, dt, st);
+    }
     }
     // queries
     const void* Qp;
@@ -1332,6 +1367,23 @@ int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out) {
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     if (const char* e = getenv("M3PC_TWO_STREAM")) h->two_stream = atoi(e) != 0;
+    h->auxs.push_back(h->aux);
+    h->ev_joins.push_back(h->ev_join);
+    for (int i = 1; i < 3; ++i) {
+        hipStream_t s;
+        hipEvent_t e;
+        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->auxs.push_back(s);
+        h->ev_joins.push_back(e);
+    }
+    if (const char* e = getenv("M3PC_STREAM_SPLIT")) {
+        for (const char* q = e; *q;) {
+            h->stream_split.push_back(atoi(q));
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    }
     if (D.critic_hidden > 0) {
         const int Hd = D.critic_hidden, SA = h->S + h->A;
         for (int i = 0; i < 2; ++i) {
@@ -1368,6 +1420,10 @@ int m3pc_destroy(m3pc_handle* h) {
     const m3pc_handle::Base& bs = h->base;
     void* bufs[] = {bs.X, bs.Y, bs.EncOut, bs.G, bs.Hn, bs.QKV, bs.O, bs.F, bs.Z, bs.cand, h->loc, h->sd, h->rtok,
                     bs.pred[0], bs.pred[1], bs.qv, h->sel_scratch, h->d_topk, h->er_top, h->sa_buf, bs.splitk_ws, h->c_om, h->c_os};
+    for (size_t i = 1; i < h->auxs.size(); ++i) {
+        hipStreamDestroy(h->auxs[i]);
+        hipEventDestroy(h->ev_joins[i]);
+    }
     if (h->aux) hipStreamDestroy(h->aux);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -1393,6 +1449,8 @@ int m3pc_destroy(m3pc_handle* h) {
         hipEventDestroy(e.a);
         hipEventDestroy(e.b);
     }
+    for (int k = 0; k < 4; ++k)
+        if (h->kvstream[k]) hipFree(h->kvstream[k]);
     for (auto& kv : h->wstream)
         if (kv.second) hipFree(kv.second);
     delete h;
@@ -1423,6 +1481,12 @@ int m3pc_load_weights(m3pc_handle* h, const m3pc_named_tensor* tensors, int n, v
         };
         for (int i = 0; i < h->dm.n_enc_layer; ++i) CHK(pack("encoder.layers." + std::to_string(i)));
         for (int i = 0; i < h->dm.n_dec_layer; ++i) CHK(pack("decoder.layers." + std::to_string(i)));
+        if (h->dm.n_dec_layer >= 1)
+            for (int k = 0; k < 4; ++k) {
+                if (!h->kvstream[k]) CHK(dmalloc((char**)&h->kvstream[k], kv_stream_bytes()));
+                launch_pack_kv_stream(W(h, std::string("decoder_embed_dict.") + KEYN[k] + ".weight").b,
+                                      W(h, "decoder.layers.0.self_attn.in_proj_weight").b + (size_t)h->d * h->d, h->kvstream[k], st);
+            }
     }
     HIPCHK(hipStreamSynchronize(st));
     // small derived tables on the host
@@ -1628,21 +1692,36 @@ int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     const int dt = a->precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32;
     const int n = a->n_count;
     if (h->two_stream && dt == DT_BF16 && n >= 512) {
-        const int n0 = ((n / 2 + 127) / 128) * 128, n1 = n - n0;
+        // part sizes: M3PC_STREAM_SPLIT=a,b,c (lab) or two halves
+        std::vector<int> parts;
+        if (!h->stream_split.empty()) {
+            int left = n;
+            for (int v : h->stream_split)
+                if (v > 0 && v < left && parts.size() + 1 < h->auxs.size() + 1) {
+                    parts.push_back(v);
+                    left -= v;
+                }
+            parts.push_back(left);
+        } else {
+            int n0 = ((n / 2 + 127) / 128) * 128;
+            parts = {n0, n - n0};
+        }
         HIPCHK(hipEventRecord(h->ev_fork, st));
-        HIPCHK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-        int rc = 0;
-        set_view(h, 0, n0);
-        rc = candidate_pass(h, a, states, rewards, n0, sample_actions, expect_return, pred_rewards, pred_boot, dt, st);
-        if (rc == 0) {
-            set_view(h, n0, n1);
-            rc = candidate_pass(h, a, states, rewards, n1, sample_actions + (size_t)n0 * hh * h->A, expect_return + n0,
-                                pred_rewards ? pred_rewards + (size_t)n0 * hh : nullptr,
-                                pred_boot ? pred_boot + (size_t)n0 * hh : nullptr, dt, h->aux);
+        int rc = 0, c0 = 0;
+        for (size_t i = 0; i < parts.size() && rc == 0; ++i) {
+            hipStream_t s = i == 0 ? st : h->auxs[i - 1];
+            if (i) HIPCHK(hipStreamWaitEvent(s, h->ev_fork, 0));
+            set_view(h, c0, parts[i]);
+            rc = candidate_pass(h, a, states, rewards, parts[i], sample_actions + (size_t)c0 * hh * h->A, expect_return + c0,
+                                pred_rewards ? pred_rewards + (size_t)c0 * hh : nullptr,
+                                pred_boot ? pred_boot + (size_t)c0 * hh : nullptr, dt, s);
+            if (i) {
+                HIPCHK(hipEventRecord(h->ev_joins[i - 1], s));
+                HIPCHK(hipStreamWaitEvent(st, h->ev_joins[i - 1], 0));
+            }
+            c0 += parts[i];
         }
         set_view(h, 0, h->dm.max_candidates);
-        HIPCHK(hipEventRecord(h->ev_join, h->aux));
-        HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
         return rc;
     }
     return candidate_pass(h, a, states, rewards, n, sample_actions, expect_return, pred_rewards, pred_boot, dt, st);
@@ -1942,6 +2021,43 @@ int m3pc_debug_block_fused(const void* O, int M, const float* res, const float* 
     b.stamps = stamps;
     if (!launch_block_fused(b, st)) return fail(M3PC_EINVAL, "block_fused: arguments not covered");
     return check_launch("debug_block_fused");
+}
+
+// kv_fused_kernel alone (tests/test_block_fused_gpu.py): n candidates of Le rows each in Z (n*Le, 512) bf16; group g holds
+// the kept[g] rows at offset off[g] of every candidate, embedded with We[g] (512, 512) bf16 + rowtab[g] (kept[g], 512);
+// stream_buf: 2 * m3pc_debug_kv_stream_bytes() bytes; KV (n*Le, 1024) bf16
+long long m3pc_debug_kv_stream_bytes(void) { return (long long)kv_stream_bytes(); }
+int m3pc_debug_kv_fused(const void* Z, int n, int Le, int kept0, int off0, int kept1, int off1, const void* We0, const void* We1,
+                        const void* Wkv, void* stream_buf, const float* rowtab0, const float* rowtab1, const float* ln_g,
+                        const float* ln_b, const float* bkv, void* KV, void* stream, long long* stamps) {
+    hipStream_t st = (hipStream_t)stream;
+    bf16_t* s0 = (bf16_t*)stream_buf;
+    bf16_t* s1 = (bf16_t*)((char*)stream_buf + kv_stream_bytes());
+    launch_pack_kv_stream((const bf16_t*)We0, (const bf16_t*)Wkv, s0, st);
+    if (kept1) launch_pack_kv_stream((const bf16_t*)We1, (const bf16_t*)Wkv, s1, st);
+    KvFusedP p;
+    memset(&p, 0, sizeof(p));
+    p.Z = (const bf16_t*)Z;
+    p.ldz = 512;
+    p.M[0] = n * kept0;
+    p.map[0] = RowMap{kept0, Le, off0};
+    p.rowtab[0] = rowtab0;
+    p.rt_mod[0] = kept0;
+    p.wstream[0] = s0;
+    p.M[1] = n * kept1;
+    p.map[1] = RowMap{kept1 ? kept1 : 1, Le, off1};
+    p.rowtab[1] = rowtab1;
+    p.rt_mod[1] = kept1 ? kept1 : 1;
+    p.wstream[1] = s1;
+    p.ln_g = ln_g;
+    p.ln_b = ln_b;
+    p.bkv = bkv;
+    p.KV = (bf16_t*)KV;
+    p.ldkv = 1024;
+    p.kv_bytes = (unsigned)((size_t)n * Le * 1024 * 2);
+    p.stamps = stamps;
+    if (!launch_kv_fused(p, st)) return fail(M3PC_EINVAL, "kv_fused: arguments not covered");
+    return check_launch("debug_kv_fused");
 }
 
 int m3pc_debug_clock_big(long long* out4) {

@@ -19,6 +19,8 @@ import types
 from typing import Dict, Optional
 
 import numpy as np
+import os
+
 import torch
 
 from . import capi, dist as mdist
@@ -38,7 +40,7 @@ class HipPlanner:
                  obs_mean=None, obs_std=None, n_embd: int = 512, n_head: int = 4, n_enc_layer: int = 2,
                  n_dec_layer: int = 1, precision: str = "fp32", rescore_topk: int = 16, device: Optional[int] = None,
                  group=None, generator: Optional[torch.Generator] = None, max_batch: int = 1,
-                 rescore: str = "bound", rescore_min: int = 4, rescore_max: int = 64, rescore_delta: Optional[float] = None,
+                 rescore: str = "bound", rescore_min: int = 8, rescore_max: int = 64, rescore_delta: Optional[float] = None,
                  max_windows: int = 1):
         """cfg: any object with traj_length, action_samples, horizon, discount, temperature, lmbda,
         plan_guidance (finetune.py RunConfig fields read at learner.py:276,319,342).
@@ -146,7 +148,7 @@ class HipPlanner:
                                     N, begin, count, precision=self.precision)
         er, a0 = res["expect_return"], res["sample_actions"][:, 0]
         er, a0 = mdist.gather_candidates(er, a0, N, self.group)
-        top = None
+        top = sel = None
         extra = {}
         # the re-score is replicated on every rank (identical inputs => identical result): candidates chosen from the
         # gathered scores, fp32 candidate pass on them, scores written back in place
@@ -159,16 +161,31 @@ class HipPlanner:
             if self._delta is None:
                 self._delta = self._calibrate(er, rs, tail, N)
             kmax, kmin = min(self.rescore_max, N - 1 if N > 1 else 1), min(self.rescore_min, N)
-            # the one host read of the step: how many candidates are inside the window (pinned-memory spin, no stream sync)
-            cand, st = self.handle.topk_window_host(er, max(kmax, 1), max(min(kmin, kmax), 1), 2.0 * self._delta)
+            kmin = max(min(kmin, kmax), 1)
+            # The candidates come sorted by bf16 score, so the set inside the window is a prefix of the list and its first
+            # kmin entries are re-scored whatever the count turns out to be: that re-score and the select are enqueued
+            # BEFORE the one host read of the step (how many candidates are inside the window; pinned-memory spin, no
+            # stream sync), so the device never waits for the host.  Only when more than kmin candidates are inside the
+            # window the rest is re-scored and the select repeated on the same variates.
+            cand, ticket = self.handle.topk_window_issue(er, max(kmax, 1), kmin, 2.0 * self._delta)
+            if os.environ.get("M3PC_NO_SPEC"):  # A/B switch: the host read first (the device idles for the round trip)
+                self.handle.topk_window_wait(ticket)
+            self.handle.rescore_listed(mode, states, actions, rewards, eps, er, cand[:kmin], *tail)
+            expo = torch.empty((N,), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
+            sel = self.handle.select(er, a0, float(cfg.temperature), expo)
+            st = self.handle.topk_window_wait(ticket)
             n_re = int(st[0])
-            top = cand[:n_re].contiguous()
-            self.handle.rescore_listed(mode, states, actions, rewards, eps, er, top, *tail)
+            if n_re > kmin:
+                self.handle.rescore_listed(mode, states, actions, rewards, eps, er, cand[kmin:n_re].contiguous(), *tail)
+                sel = self.handle.select(er, a0, float(cfg.temperature), expo)
+            top = cand[:n_re]
             extra = dict(n_rescored=n_re, n_in_window=int(st[3]), min_margin_outside=float(st[1]), delta=self._delta)
         # torch.multinomial(p, 1) == argmax(p / q), q ~ Exp(1) from the same generator (ATen's
         # multinomial fast path); drawing q here and finishing inside the select kernel gives the same index
-        expo = torch.empty((N,), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
-        p, eval_action, argmax, sample_idx, sample_action = self.handle.select(er, a0, float(cfg.temperature), expo)
+        if sel is None:
+            expo = torch.empty((N,), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
+            sel = self.handle.select(er, a0, float(cfg.temperature), expo)
+        p, eval_action, argmax, sample_idx, sample_action = sel
         self.last = dict(expect_return=er, p=p, argmax=argmax, sample_idx=sample_idx, loc=res["loc"], std=res["std"],
                          sample_actions=res["sample_actions"], eps=eps, topk=top, **extra)
         return sample_action, eval_action

@@ -115,3 +115,75 @@ def test_block_fused_rowtab_and_head_norms():
     got = Hout[orow].float()
     assert torch.isfinite(Hout.float()).all()
     assert float((got - y).abs().max()) <= 4e-2
+
+
+# ------------------------------------------------------------------------------------------------ decoder input (kv_fused_kernel)
+def _kv_call(lib, Z, n, Le, kept, off, We, Wkv, rowtab, g, b, bkv, stamps=None):
+    fn = lib.m3pc_debug_kv_fused
+    fn.restype = C.c_int
+    vp, i = C.c_void_p, C.c_int
+    fn.argtypes = [vp, i, i, i, i, i, i] + [vp] * 12
+    lib.m3pc_debug_kv_stream_bytes.restype = C.c_longlong
+    sb = torch.empty(2 * lib.m3pc_debug_kv_stream_bytes(), dtype=torch.uint8, device="cuda")
+    KV = torch.zeros(n * Le, 2 * D, dtype=torch.bfloat16, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = fn(Z.data_ptr(), n, Le, kept[0], off[0], kept[1], off[1], We[0].data_ptr(), We[1].data_ptr(), Wkv.data_ptr(), sb.data_ptr(),
+            rowtab[0].data_ptr(), rowtab[1].data_ptr(), g.data_ptr(), b.data_ptr(), bkv.data_ptr(), KV.data_ptr(), st,
+            stamps.data_ptr() if stamps is not None else None)
+    assert rc == 0, lib.m3pc_last_error()
+    torch.cuda.synchronize()
+    return KV
+
+
+def _kv_reference(Z, n, Le, kept, off, We, Wkv, rowtab, g, b, bkv):
+    out = torch.zeros(n * Le, 2 * D, dtype=torch.float32, device="cuda")
+    Zr = Z.float().view(n, Le, D)
+    o = out.view(n, Le, 2 * D)
+    for k in range(2):
+        if kept[k] == 0:
+            continue
+        y = Zr[:, off[k]:off[k] + kept[k]] @ We[k].float().T + rowtab[k][None]
+        a = F.layer_norm(y, (D,), g, b, 1e-5).to(torch.bfloat16).float()
+        o[:, off[k]:off[k] + kept[k]] = a @ Wkv.float().T + bkv
+    return out
+
+
+@pytest.mark.parametrize("n,Le,kept,off", [(64, 49, (17, 32), (0, 17)), (100, 49, (17, 32), (0, 17)), (37, 40, (9, 31), (0, 9)),
+                                           (16, 32, (32, 0), (0, 0)), (1024, 49, (17, 32), (0, 17))])
+def test_kv_fused_matches_reference(n, Le, kept, off):
+    lib = capi.load_library()
+    dev = torch.device("cuda")
+    g_ = torch.Generator(device=dev).manual_seed(7 + n)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g_)
+    Z = rn(n * Le, D).to(torch.bfloat16)
+    We = [(rn(D, D) / D ** 0.5).to(torch.bfloat16) for _ in range(2)]
+    Wkv = (rn(2 * D, D) / D ** 0.5).to(torch.bfloat16)
+    rowtab = [0.5 * rn(max(kept[k], 1), D) for k in range(2)]
+    g, b, bkv = 1 + 0.1 * rn(D), 0.1 * rn(D), 0.1 * rn(2 * D)
+    KV = _kv_call(lib, Z, n, Le, kept, off, We, Wkv, rowtab, g, b, bkv).float()
+    ref = _kv_reference(Z, n, Le, kept, off, We, Wkv, rowtab, g, b, bkv)
+    used = torch.zeros(Le, dtype=torch.bool, device=dev)
+    for k in range(2):
+        used[off[k]:off[k] + kept[k]] = True
+    m = used.repeat(n)
+    assert (KV[~m] == 0).all()                       # rows of no group are not touched
+    err = (KV[m] - ref[m]).abs()
+    # one bf16 ulp of the output plus the flips of the LayerNorm rows' roundings
+    assert float(err.max()) <= 0.06 and float(err.mean()) <= 4e-3, (float(err.max()), float(err.mean()))
+
+
+def test_kv_fused_rows_independent_of_batch():
+    """A candidate's K|V rows do not depend on how many candidates the launch holds (candidate sharding stays bit-exact)."""
+    lib = capi.load_library()
+    dev = torch.device("cuda")
+    g_ = torch.Generator(device=dev).manual_seed(3)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g_)
+    n, Le, kept, off = 300, 49, (17, 32), (0, 17)
+    Z = rn(n * Le, D).to(torch.bfloat16)
+    We = [(rn(D, D) / D ** 0.5).to(torch.bfloat16) for _ in range(2)]
+    Wkv = (rn(2 * D, D) / D ** 0.5).to(torch.bfloat16)
+    rowtab = [0.5 * rn(kept[k], D) for k in range(2)]
+    g, b, bkv = 1 + 0.1 * rn(D), 0.1 * rn(D), 0.1 * rn(2 * D)
+    full = _kv_call(lib, Z, n, Le, kept, off, We, Wkv, rowtab, g, b, bkv)
+    part = _kv_call(lib, Z[37 * Le:(37 + 101) * Le].contiguous(), 101, Le, kept, off, We, Wkv, rowtab, g, b, bkv)
+    assert torch.equal(full[37 * Le:(37 + 101) * Le], part)

@@ -28,7 +28,8 @@ def main():
         gap = (s - prev) if prev else 0
         prev = e
         name = r["Kernel_Name"].replace("m3pc::", "").replace("void ", "")[:70]
-        lines.append("%8.1f %7.1f %6.1f  %s grid=%s" % ((s - t0) / 1e3, (e - s) / 1e3, gap / 1e3, name, r.get("Grid_Size_X", "")))
+        lines.append("%8.1f %7.1f %6.1f  q%s %s grid=%s" % ((s - t0) / 1e3, (e - s) / 1e3, gap / 1e3, r.get("Queue_Id", "?"), name,
+                                                         r.get("Grid_Size_X", "")))
     span = (int(step[-1]["End_Timestamp"]) - t0) / 1e3
     busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in step) / 1e3
     lines.append("# step span %.1f us, %d kernels, sum of durations %.1f us" % (span, len(step), busy))
