@@ -220,7 +220,12 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     {
         // residual + out-proj bias -> accumulators, four feature tiles (64 registers of loads) per batch, the next batch's
         // loads in flight while a batch is added
-        const float* rrow = p.rowtab ? p.rowtab + (size_t)(rld % p.rt_mod) * BD : p.res + (size_t)rld * p.ldr;
+        int rres = rld;
+        if (p.res_L > 0) {  // shared leading rows of a sequence: read from sequence 0
+            const int jj = rld % p.res_L;
+            if (jj < p.res_nshared) rres = jj;
+        }
+        const float* rrow = p.rowtab ? p.rowtab + (size_t)(rld % p.rt_mod) * BD : p.res + (size_t)rres * p.ldr;
         f32x4 xb[2][16];
         auto loads = [&](int bt) {
 #pragma unroll
@@ -359,32 +364,31 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
             for (int i = 0; i < 4; ++i) hh[4 * q + i] = b[i];
         }
     };
-    // gelu (exact-erf form of gemm_epilogue.h: ge_gelu, same arithmetic) of registers e, e + 1 (e even) of hidden tile t:
-    // both values advance by a quarter per MFMA slot of the group, so that neighbouring VALU instructions belong to
-    // different dependency chains (a chain of dependent fmas issues every ~6.6 clocks, independent ones every 4);
-    // the last quarter packs the pair into fragment 2 t + (e >> 3) of hb
-    float gx[2], gt[2], ge[2], gp[2];
+    // gelu of registers e, e + 1 (e even) of hidden tile t.  The wave's VALU issue bounds these phases (transcendentals
+    // cost 1.8 ordinary instructions, packed fp32 arithmetic does not overlap the MFMAs), so the cheapest form that
+    // stays below the bf16 rounding of the hidden activations is used:
+    //     gelu(x) = x / (1 + exp(-s(x))),  s(x) = x (c0 + c1 x^2 + c2 x^4),  x^2 clamped at 50
+    // fitted (minimax over [-8, 8]) to x Phi(x): |d gelu| <= 2.6e-5 everywhere, where the exact-erf form of the GEMM
+    // epilogues (gemm_epilogue.h, A&S 7.1.26) costs 13 instructions + 2 transcendentals per value against 7 + 2 here.
+    // Both values advance by a quarter per MFMA slot of the group (neighbouring instructions belong to different
+    // dependency chains); the last quarter packs the pair into fragment 2 t + (e >> 3) of hb.
+    float gx[2], gq[2], gs[2];
     auto gelu_slice = [&](const f32x16& hh, int t, int e, int k) {
+        constexpr float C0 = -2.3011212f, C1 = -0.10677572f, C2 = 0.001014263f;  // -log2(e) * (c0, c1, c2)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            if (k == 0) {         // t = 1 / (1 + p |x| / sqrt 2)
+            if (k == 0) {
                 const float x = hh[e + j];
                 gx[j] = x;
-                const float ax = fabsf(x) * 0.70710678118654752440f;
-                gt[j] = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-            } else if (k == 1) {  // e = exp(-x^2 / 2)
-                const float ax = fabsf(gx[j]) * 0.70710678118654752440f;
-                ge[j] = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
-                gx[j] = 0.5f * gx[j];
-            } else if (k == 2) {  // the polynomial in t
-                const float tt = gt[j];
-                float pp = fmaf(tt, 1.061405429f, -1.453152027f);
-                pp = fmaf(tt, pp, 1.421413741f);
-                pp = fmaf(tt, pp, -0.284496736f);
-                gp[j] = fmaf(tt, pp, 0.254829592f);
-            } else {              // 0.5 x (1 + erf)
-                const float erf_abs = fmaf(-(gp[j] * gt[j]), ge[j], 1.0f);
-                gx[j] = DBG == 2 ? gx[j] : fmaf(fabsf(gx[j]), erf_abs, gx[j]);
+                gs[j] = fminf(x * x, 50.0f);
+                gq[j] = fmaf(gs[j], C2, C1);
+            } else if (k == 1) {
+                gq[j] = fmaf(gs[j], gq[j], C0);
+                gq[j] = __builtin_amdgcn_exp2f(gx[j] * gq[j]);
+            } else if (k == 2) {
+                gq[j] = __builtin_amdgcn_rcpf(gq[j] + 1.0f);
+            } else {
+                gx[j] = DBG == 2 ? gx[j] : gx[j] * gq[j];
             }
         }
         if (k == 3) {
@@ -831,6 +835,7 @@ bool launch_block_fused(const BlockP& p, hipStream_t st) {
     if (((uintptr_t)p.O & 15) || (p.ldo % 8) || ((uintptr_t)p.wstream & 1023)) return false;
     if (!p.rowtab && (((uintptr_t)p.res & 15) || (p.ldr % 4))) return false;
     if (p.Xout && (((uintptr_t)p.Xout & 15) || (p.ldx % 4))) return false;
+    if (p.res_L > 0 && (p.rowtab || p.Xout == p.res || p.res_nshared > p.res_L)) return false;  // (in place, the shared rows would be overwritten while read)
     if (p.Hout && (((uintptr_t)p.Hout & 7) || (p.ldh % 4))) return false;
     if (p.out_mod > 0 && (p.M % p.out_mod != 0 || p.out_mod != 2 * p.out_grp)) return false;
     const dim3 grid((p.M + 127) / 128), block(256);

@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(EmbedP p, int CB, int n
     const float* E = p.E[key] + (long long)t * d;
     const bool indep = j < p.n_indep;
     const int b0 = ch * CB, b1 = b0 + CB < p.batch ? b0 + CB : p.batch;
+    if (indep && p.x_first_only && b0 > 0 && p.Hb && !p.Hf && j < p.n_sh) return;  // (nothing of this token is stored past element 0)
     const int n_own = p.L - p.n_sh;
     float4 ev[NV], gv[NV], bv[NV];
 #pragma unroll
@@ -164,8 +165,10 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(EmbedP p, int CB, int n
             }
         }
         const long long row = (long long)b * p.L + j;
+        if (!(indep && p.x_first_only && b > 0)) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) *(float4*)(p.X + row * d + (i * 64 + lane) * 4) = x[i];
+            for (int i = 0; i < NV; ++i) *(float4*)(p.X + row * d + (i * 64 + lane) * 4) = x[i];
+        }
         if (!p.ln_g) continue;
         if (p.Hf) {
 #pragma unroll

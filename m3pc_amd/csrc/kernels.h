@@ -78,6 +78,8 @@ struct BlockP {
     int M;
     const float* res;       // (M, d) residual rows (fp32), or
     int ldr;
+    int res_L, res_nshared; // res_L > 0: rows come in sequences of res_L; the first res_nshared rows of every sequence are the
+                            // same and are read from sequence 0 (the history tokens of a candidate pass: stored once)
     const float* rowtab;    // (rt_mod, d): row r takes rowtab[r % rt_mod] as its residual (res unused)
     int rt_mod;
     const bf16_t* wstream;  // packed weight fragments of the layer (launch_pack_block_stream)
@@ -206,6 +208,7 @@ struct EmbedP {
     float* Hf;               // ... as fp32 and/or
     bf16_t* Hb;              // ... bf16 rows (batch*L, d)
     int n_indep;             // the first n_indep tokens do not depend on the batch index (computed once per wave)
+    int x_first_only;        // != 0: the X rows of those tokens are stored for batch element 0 only (the consumer reads them there)
     int n_sh;                // > 0: LayerNorm rows of tokens j < n_sh go once to Hb_sh[j], those of tokens j >= n_sh
     bf16_t* Hb_sh;           //      compactly to Hb[b * (L - n_sh) + j - n_sh]  (first-layer pruning, see run_block)
 };

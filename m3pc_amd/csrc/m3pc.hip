@@ -138,7 +138,7 @@ struct m3pc_handle {
         char *Hn, *QKV, *O, *F, *Z;
         long long splitk_ws_bytes;
     } base;
-    bool two_stream = false;      // M3PC_TWO_STREAM=1: measured +2.5 % on C2, off by default to keep per-kernel timings clean
+    bool two_stream = true;       // candidate halves on two streams (M3PC_TWO_STREAM=0: one stream); measured -2.5 % step time on C2
     bool allow_splitk = true;     // see gemm(): off while sharded candidates are scored
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -402,8 +402,11 @@ void invalidate_tables(m3pc_handle* h) {
 // next_ln: the LayerNorm that follows this block on X (next block's norm1 or the stack's final norm); when the
 // FFN2 GEMM can apply it in its split-K reduce, *next_ln_done is set and the caller skips that launch.
 // x_dead: nothing reads X after this block except through next_ln (lets the fused tail skip the fp32 store).
+// Xnext / res_nshared (fused tail only): the block output goes to Xnext instead of X, and the first res_nshared rows of
+// every sequence of X are read from sequence 0 (the embedding kernel stored the history rows once, EmbedP::x_first_only).
 int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L, int dt, hipStream_t st, bool ln1_done = false,
-              int n_sh = 0, const LnP* next_ln = nullptr, bool* next_ln_done = nullptr, bool x_dead = false) {
+              int n_sh = 0, const LnP* next_ln = nullptr, bool* next_ln_done = nullptr, bool x_dead = false,
+              float* Xnext = nullptr, int res_nshared = 0) {
     const int d = h->d, ff = h->ff;
     const int rows = batch * L;
     const int es = (int)dtype_size(dt);
@@ -527,8 +530,12 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
         b.b2 = W(h, pfx + ".linear2.bias").f;
         b.ln2_g = W(h, pfx + ".norm2.weight").f;
         b.ln2_b = W(h, pfx + ".norm2.bias").f;
-        const bool fuse_ln = next_ln && next_ln->Yb && !next_ln->Yf && !next_ln->g2 && next_ln->X == X && next_ln->xmap.rpg == 0 &&
-                             next_ln->rows == rows;
+        const bool fuse_ln = next_ln && next_ln->Yb && !next_ln->Yf && !next_ln->g2 && next_ln->X == (Xnext ? Xnext : X) &&
+                             next_ln->xmap.rpg == 0 && next_ln->rows == rows;
+        if (res_nshared > 0) {
+            b.res_L = L;
+            b.res_nshared = res_nshared;
+        }
         if (fuse_ln) {
             b.lnA_g = next_ln->g1;
             b.lnA_b = next_ln->b1;
@@ -536,7 +543,7 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
             b.ldh = d;
         }
         if (!(fuse_ln && x_dead)) {
-            b.Xout = X;
+            b.Xout = Xnext ? Xnext : X;
             b.ldx = d;
         }
         GemmTimer t(h, st, 2.0 * rows * ((double)d * d + 2.0 * d * ff), dt);
@@ -545,6 +552,7 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
             return check_launch(pfx.c_str());
         }
     }
+    if (Xnext || res_nshared) return fail(M3PC_EINVAL, "%s: the fused layer tail did not take a pass set up for it", pfx.c_str());
     {
         GemmP p = gemm_basic(h->O, d, Wop(h, pfx + ".self_attn.out_proj.weight", dt), d, rows, d, d,
                              W(h, pfx + ".self_attn.out_proj.bias").f);
@@ -624,6 +632,14 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
         e.E[k] = h->Eenc[k];
         e.feat[k] = h->feat[k];
     }
+    // history rows of the residual stream stored once (sequence 0) when the first layer's tail is the fused kernel: it reads
+    // them there and writes the layer output to Y, which carries the stream through the remaining layers
+    // (M3PC_SHARED_RES=1; measured on C2: embedding 33 -> 15 us, but every tile of the fused kernel then reads the same 66 KiB
+    // and the step is 0.4 % SLOWER -- off)
+    static const bool shared_res_on = getenv("M3PC_SHARED_RES") != nullptr && getenv("M3PC_NO_BLOCK_FUSED") == nullptr;
+    const bool shared_res = n_sh > 0 && shared_res_on && (long long)batch * pl->Le >= 512 && h->wstream.count("encoder.layers.0") &&
+                            bf16_out_only;
+    e.x_first_only = shared_res ? 1 : 0;
     e.widx = in.widx;
     e.tokmap = pl->d_tokmap;
     e.batch = batch;
@@ -652,8 +668,11 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
         ln.Yf = h->EncOut;
     bool ln_done = true;  // norm1 of layer 0 comes from the embedding kernel
     const int nl = h->dm.n_enc_layer;
+    float* Xs = h->X;     // where the residual stream lives
     for (int i = 0; i < nl; ++i) {
+        float* Xn = shared_res && i == 0 ? h->Y : nullptr;
         LnP nxt = ln;  // what follows layer i on X: norm1 of layer i+1 (-> Hn) or encoder.norm (-> EncOut / Z)
+        nxt.X = ln.X = Xn ? Xn : Xs;
         if (i + 1 < nl) {
             nxt.g1 = W(h, "encoder.layers." + std::to_string(i + 1) + ".norm1.weight").f;
             nxt.b1 = W(h, "encoder.layers." + std::to_string(i + 1) + ".norm1.bias").f;
@@ -662,8 +681,9 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
         }
         const bool l1 = ln_done;
         ln_done = false;
-        CHK(run_block(h, "encoder.layers." + std::to_string(i), h->X, batch, pl->Le, dt, st, l1, i == 0 ? n_sh : 0, &nxt, &ln_done,
-                      i + 1 == nl && bf16_out_only));
+        CHK(run_block(h, "encoder.layers." + std::to_string(i), Xs, batch, pl->Le, dt, st, l1, i == 0 ? n_sh : 0, &nxt, &ln_done,
+                      i + 1 == nl && bf16_out_only, Xn, Xn ? n_indep : 0));
+        if (Xn) Xs = Xn;
     }
     if (!ln_done) launch_layernorm(ln, st);
     return check_launch("encoder");
@@ -1686,9 +1706,10 @@ int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     launch_sample(sp, st);
 
     // PASS 2 + scoring.  Large bf16 batches are cut into two candidate halves that run the same kernel chain
-    // on two HIP streams over disjoint workspace halves: while one half is in an MFMA-bound GEMM the other
-    // is typically in an HBM-bound LayerNorm / attention / epilogue-heavy kernel, so matrix cores and HBM
-    // are both kept busy.  Candidates are independent, results are identical to the one-stream order.
+    // on two HIP streams over disjoint workspace halves.  The fused layer tails work in 128-row tiles, one per CU:
+    // 1024 candidates are 392 tiles = two rounds on 256 CUs with the second round half empty, a half is 196 tiles =
+    // one round, and the other half's attention / projection kernels run on the CUs it leaves free.  Candidates are
+    // independent, results are identical to the one-stream order.
     const int dt = a->precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32;
     const int n = a->n_count;
     if (h->two_stream && dt == DT_BF16 && n >= 512) {
