@@ -189,6 +189,11 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     char* const abase = smem + ACT_OFF + wu * ACT_LDS * 1024 + lane16;
     auto afrag = [&](int m) -> u32x4 { return *(const u32x4*)(abase + m * 1024); };
     float* const tab = (float*)(smem + TAB_OFF);
+    // this lane's view of the tables (+ 4 lh), opaque to the compiler: every table read is then ONE base register + an
+    // immediate offset (left to itself it builds a separate address register per read and spills them between the passes)
+    typedef const float __attribute__((address_space(3))) * lds_cf32_t;  // (an LDS pointer: laundered as a generic one the reads become flat loads)
+    lds_cf32_t tabl = (lds_cf32_t)(tab + 4 * lh);
+    asm volatile("" : "+v"(tabl));
 
     // ---- prologue: first stages in flight, parameter tables, accumulators = residual + out-proj bias
 #pragma unroll
@@ -328,27 +333,35 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
         s1 = half_swap_sum(s1);
         s2 = half_swap_sum(s2);
         const float mean = s1 * (1.0f / BD);
-        const float rstd = rsqrtf(fmaxf(s2 * (1.0f / BD) - mean * mean, 0.f) + 1e-5f);
-        const float nmr = -mean * rstd;
+        float rstd = rsqrtf(fmaxf(s2 * (1.0f / BD) - mean * mean, 0.f) + 1e-5f);
+        float nmr = -mean * rstd;
         acc_touch(acc);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
+            // (volatile asm statements keep their order: the table reads of fragment s stay behind this one and its
+            // arithmetic in front of the one that closes the iteration; left alone, the compiler issues the table reads of
+            // all fragments first and spills them)
+            asm volatile("" : "+v"(rstd), "+v"(nmr) : : "memory");
             __builtin_amdgcn_sched_barrier(0);
             const int jn = s >> 1;
             float y[8];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const int q = 2 * (s & 1) + k, n = 32 * jn + 8 * q + 4 * lh;
-                const f32x4 g = *(const f32x4*)(tab + T_G2 + n);
-                const f32x4 b = *(const f32x4*)(tab + T_BE2 + n);
+                const int q = 2 * (s & 1) + k, n = 32 * jn + 8 * q;
+                const f32x4 g = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_G2 + n);
+                const f32x4 b = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_BE2 + n);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) y[4 * k + i] = fmaf(fmaf(acc[jn][4 * q + i], rstd, nmr), g[i], b[i]);
             }
             bf16x8 w;
 #pragma unroll
             for (int j = 0; j < 8; ++j) w[j] = (bf16_t)y[j];
-            if (s < KS - ACT_LDS) act[s] = __builtin_bit_cast(u32x4, w);
-            else *(u32x4*)(abase + (s - (KS - ACT_LDS)) * 1024) = __builtin_bit_cast(u32x4, w);
+            if (s < KS - ACT_LDS) {
+                act[s] = __builtin_bit_cast(u32x4, w);
+                asm volatile("" : "+v"(act[s]));
+            } else {
+                *(u32x4*)(abase + (s - (KS - ACT_LDS)) * 1024) = __builtin_bit_cast(u32x4, w);
+            }
         }
     }
     stamps[3] = __builtin_readcyclecounter();
@@ -359,7 +372,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     auto bias_init = [&](f32x16& hh, int c, int t) {  // hidden accumulator := linear1 bias of its 32 units
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 b = *(const f32x4*)(tab + T_B1 + 64 * c + 32 * t + 8 * q + 4 * lh);
+            const f32x4 b = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_B1 + 64 * c + 32 * t + 8 * q);
 #pragma unroll
             for (int i = 0; i < 4; ++i) hh[4 * q + i] = b[i];
         }
@@ -455,7 +468,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     for (int jn = 0; jn < NT; ++jn) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 b = *(const f32x4*)(tab + T_B2 + 32 * jn + 8 * q + 4 * lh);
+            const f32x4 b = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_B2 + 32 * jn + 8 * q);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[jn][4 * q + i] += b[i];
         }
@@ -510,9 +523,10 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
             for (int jn = 0; jn < NT; ++jn)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int n = 32 * jn + 8 * q + 4 * lh;
-                    const f32x4 g = *(const f32x4*)(tab + T_GA + n);
-                    const f32x4 b = *(const f32x4*)(tab + T_BA + n);
+                    if (q == 0) asm volatile("" : "+v"(rstd), "+v"(nmr) : : "memory");  // (see LayerNorm-2)
+                    const int n = 32 * jn + 8 * q;
+                    const f32x4 g = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_GA + n);
+                    const f32x4 b = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_BA + n);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[jn][4 * q + i] = fmaf(fmaf(acc[jn][4 * q + i], rstd, nmr), g[i], b[i]);
                     if (q == 3) __builtin_amdgcn_sched_barrier(0);
@@ -521,20 +535,21 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
             row_stats(rstd, nmr);
             acc_touch(acc);
         }
-        const float* const gtab = two ? tab + T_GB + sel * BD : tab + T_GA;
-        const float* const btab = two ? tab + T_BB + sel * BD : tab + T_BA;
+        lds_cf32_t const gtab = two ? tabl + T_GB + sel * BD : tabl + T_GA;
+        lds_cf32_t const btab = two ? tabl + T_BB + sel * BD : tabl + T_BA;
         bf16_t* hrow = p.Hout + (size_t)(valid ? orow_h : 0) * p.ldh;
 #pragma unroll
         for (int jn = 0; jn < NT; ++jn)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int n = 32 * jn + 8 * q + 4 * lh;
-                const f32x4 g = *(const f32x4*)(gtab + n);
-                const f32x4 b = *(const f32x4*)(btab + n);
+                if (q == 0) asm volatile("" : "+v"(rstd), "+v"(nmr) : : "memory");
+                const int n = 32 * jn + 8 * q;
+                const f32x4 g = *(const f32x4 __attribute__((address_space(3)))*)(gtab + n);
+                const f32x4 b = *(const f32x4 __attribute__((address_space(3)))*)(btab + n);
                 bf16x4 w;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) w[i] = (bf16_t)fmaf(fmaf(acc[jn][4 * q + i], rstd, nmr), g[i], b[i]);
-                if (valid) *(bf16x4*)(hrow + n) = w;
+                if (valid) *(bf16x4*)(hrow + n + 4 * lh) = w;
                 if (q == 3) __builtin_amdgcn_sched_barrier(0);
             }
     }
