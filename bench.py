@@ -205,26 +205,50 @@ def main():
                "min": round(lat[0], 4), "steps": len(lat)}
 
     n_local = mdist_count(n_global, rank, world)
-    planner.handle.profile_enable(True)
-    planner.handle.profile_read(reset=True)
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
     prec = capi.PREC_BF16 if args.precision == "bf16" else capi.PREC_FP32
-    launches, gemm_ms, gemm_flops = planner.handle.profile_read(prec, reset=False)
-    all_launches, all_ms, all_flops = planner.handle.profile_read(-1, reset=True)
-    planner.handle.profile_enable(False)
-    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+
+    def instrumented(mode):
+        planner.handle.profile_enable(mode)
+        planner.handle.profile_read(reset=True)
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        cls_ = planner.handle.profile_read(prec, reset=False)
+        tail_ = planner.handle.profile_read(capi.PROF_LAYER_TAIL, reset=False)
+        all_ = planner.handle.profile_read(-1, reset=True)
+        planner.handle.profile_enable(False)
+        return cls_, tail_, all_
+
+    # as run (the two candidate halves overlapped on two streams: a bracket also holds what the other half does meanwhile) ...
+    (o_launches, o_ms, o_flops), (ot_launches, ot_ms, ot_flops), _ = instrumented(True)
+    # ... and with the halves one after the other on one stream: the same launches, each alone on the chip
+    (launches, gemm_ms, gemm_flops), (t_launches, t_ms, t_flops), (all_launches, all_ms, all_flops) = instrumented(2)
     peak = MFMA_PEAK_TFLOPS[args.precision]
     f_step = alg_flops(n_local, T, H, S, A, mode="critic" if critic_mode else "rtg")
+    cls = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    if t_launches:   # the dominant kernel: the fused layer tail (block_fused.hip), 59 % of the step's kernel time
+        achieved, dom_l, dom_ms, dom_fl = t_flops / (t_ms * 1e-3) / 1e12, t_launches, t_ms, t_flops
+        kname = ("m3pc::block_fused_kernel (layer tail: out-proj + residual + LayerNorm + Linear/GELU/Linear + residual + LayerNorm, "
+                 "one launch per layer and candidate half)")
+    else:            # fp32 mode / shapes the fused kernel does not cover: the GEMM class
+        achieved, dom_l, dom_ms, dom_fl = cls, launches, gemm_ms, gemm_flops
+        kname = f"the {args.precision} MFMA GEMM launches (gemm_line_kernel / gemm_glds_ring3_kernel / gemm_kernel)"
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.precision),
                 "peak_measured": 1800.0 if args.precision == "bf16" else None,  # register-resident v_mfma loop at the 1.75 GHz the chip holds
-                "kernel": f"m3pc::block_fused_kernel (layer tails: out-proj + LN + FFN) / gemm_line_kernel / gemm_glds_ring3_kernel "
-                          f"(few-row launches: gemm_kernel), the {args.precision} MFMA launches of the candidate pass",
+                "kernel": kname,
+                "flops_per_launch": dom_fl / max(dom_l, 1), "avg_launch_us": 1e3 * dom_ms / max(dom_l, 1),
+                "launches_per_step": dom_l / args.steps, "kernel_ms_per_step": dom_ms / args.steps,
+                "note": "HIP-event brackets on the launch stream, candidate halves one after the other (m3pc_profile_enable(h, 2)): the "
+                        "launches of the timed region, each alone on the chip; `overlapped` = the same brackets with the halves on "
+                        "two streams as in the timed region, where a launch shares the chip with the other half's kernels",
+                "overlapped": {"avg_launch_us": 1e3 * (ot_ms if t_launches else o_ms) / max(ot_launches if t_launches else o_launches, 1),
+                               "achieved": round((ot_flops / (ot_ms * 1e-3) if t_launches and ot_ms > 0 else
+                                                  (o_flops / (o_ms * 1e-3) if o_ms > 0 else 0.0)) / 1e12, 2)},
+                # every MFMA launch of the compute dtype (fused tails, fused decoder input, Q|K|V / head GEMMs)
+                "mfma_class": {"achieved": round(cls, 2), "frac": round(cls / peak, 4), "launches_per_step": launches / args.steps,
+                               "ms_per_step": gemm_ms / args.steps},
                 "all_gemm_ms_per_step": all_ms / args.steps, "all_gemm_launches_per_step": all_launches / args.steps,
-                "flops_per_launch": gemm_flops / max(launches, 1), "avg_launch_us": 1e3 * gemm_ms / max(launches, 1),
-                "launches_per_step": launches / args.steps, "gemm_ms_per_step": gemm_ms / args.steps,
                 "step_alg_tflop": round(f_step / 1e12, 4),
                 "step_mfma_frac": round(f_step / (elapsed / args.steps) / 1e12 / peak, 4),
                 "step_alg_bytes": alg_bytes(n_local, T, S, A),
@@ -313,11 +337,35 @@ def extras(args, dims, cfg, hist, planner, S, A):
             ship["zeroshot_piid_B1"] = _time_calls(lambda: p8.action_piid_sample(h8, eval=True, rtg=2.5).cpu(), 40)
         p8.handle.close()
     out["latency_ms_shipped"] = {"config": "hopper rtg_guiding N=625 H=4 T=8 (closed loop, per call)", **ship}
+    # batched multi-env planning: E windows x N candidates per call, pipelined like the headline
+    if args.precision == "bf16" and cfg.plan_guidance == "rtg_guiding":
+        bat = {}
+        for E in (1, 4, 8):
+            pb = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None, precision="bf16",
+                            generator=torch.Generator(device="cuda").manual_seed(1), max_batch=E, max_windows=E)
+            hs = []
+            for i in range(E):
+                hi = synth.make_history(dims, i)
+                hi["path_length"] = 500
+                hs.append(hi)
+            for _ in range(3):
+                pb.action_sample_batch(hs, eval=True, rtg=3.0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 12
+            for _ in range(reps):
+                pb.action_sample_batch(hs, eval=True, rtg=3.0)
+            torch.cuda.synchronize()
+            dt_ = (time.perf_counter() - t0) / reps
+            bat[f"E{E}"] = {"ms_per_call": round(1e3 * dt_, 4), "plan_steps_per_s": round(E / dt_, 2)}
+            pb.handle.close()
+        out["batched"] = {"what": "action_sample_batch: E env windows x N=%d candidates per call (incl. window H2D copies)" % cfg.action_samples,
+                          **bat}
     return out
 
 
 def pmc_traffic(precision):
-    """HBM bytes per launch of the dominant kernel class, from the committed rocprofv3 PMC passes of this same
+    """HBM bytes per launch of the dominant kernel (block_fused_kernel), from the committed rocprofv3 PMC passes of this same
     command (profiles/pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950-corrected); PMC counters
     cannot be read from inside the process, so this is the launch-weighted mean of that profile, or null."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -329,7 +377,7 @@ def pmc_traffic(precision):
         return None
     n = b = 0
     for name, v in ks.items():
-        if "gemm_glds" in name or "gemm_line" in name or "gemm_big" in name or "gemm_kernelIDF16b" in name:
+        if "block_fused_kernel" in name:
             n += v["launches_profiled"]
             b += v["launches_profiled"] * v["hbm_bytes_per_launch"]
     return int(b / n) if n else None

@@ -215,10 +215,14 @@ int m3pc_select(m3pc_handle* h, const float* expect_return, const float* a0, lon
                 int* sample_idx, float* sample_action, void* stream);
 
 /* kernel-level timing of the last plan_step for bench.py / profiling: when enabled the library
- * brackets the dominant kernel class (the MFMA GEMMs) with hipEvents on `stream`. */
+ * brackets the MFMA launches with hipEvents on the stream they run on.  enable = 2: in addition the two candidate
+ * halves of a plan step (normally overlapped on two streams) run one after the other on `stream`, so that a
+ * bracket holds that launch alone. */
 int m3pc_profile_enable(m3pc_handle* h, int enable);
-/* sums since the last reset over the GEMM launches of one arithmetic (precision = M3PC_PREC_*, or -1 for
- * all): launches, milliseconds between the bracketing events, flops (2*M*N*K) */
+/* sums since the last reset over the MFMA launches of one arithmetic (precision = M3PC_PREC_*, or -1 for
+ * all) or over the fused layer-tail launches alone (M3PC_PROF_LAYER_TAIL: the dominant kernel, block_fused.hip):
+ * launches, milliseconds between the bracketing events, flops (2*M*N*K per product) */
+#define M3PC_PROF_LAYER_TAIL 16
 int m3pc_profile_read(m3pc_handle* h, int precision, long long* launches, double* gemm_ms, double* gemm_flops,
                       int reset);
 

@@ -20,6 +20,7 @@ STATES, ACTIONS, REWARDS, RETURNS = 0, 1, 2, 3
 KEYS = ("states", "actions", "rewards", "returns")
 MODE_RTG, MODE_CRITIC, MODE_NOISE = 0, 1, 2
 PREC_FP32, PREC_BF16 = 0, 1
+PROF_LAYER_TAIL = 16  # m3pc_profile_read: the fused layer-tail launches only
 ABI_VERSION = 1
 
 EXPORTS = (
@@ -383,7 +384,8 @@ class Handle:
         return p, ev, am, si, sa
 
     # -- profiling ---------------------------------------------------------------------------------
-    def profile_enable(self, on: bool):
+    def profile_enable(self, on):
+        """False / True, or 2: also run the candidate halves one after the other (each bracket holds one launch alone)."""
         check(self.lib.m3pc_profile_enable(self._h, int(on)))
 
     def profile_read(self, precision: int = -1, reset: bool = True):

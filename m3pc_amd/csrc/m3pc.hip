@@ -94,6 +94,7 @@ struct EventPair {
     hipEvent_t a, b;
     double flops;
     int dt;
+    int kind;  // 0: GEMM launch, 1: fused layer tail (block_fused_kernel), 2: fused decoder input (kv_fused_kernel)
 };
 
 }  // namespace
@@ -152,6 +153,7 @@ struct m3pc_handle {
     bf16_t* kvstream[4] = {nullptr, nullptr, nullptr, nullptr};
     // profiling
     bool prof = false;
+    bool prof_serial = false;     // m3pc_profile_enable(h, 2): the candidate halves run one after the other on the caller's stream
     std::vector<EventPair> ev;
     size_t ev_used = 0;
 };
@@ -259,7 +261,7 @@ struct GemmTimer {
     m3pc_handle* h;
     hipStream_t st;
     EventPair* e = nullptr;
-    GemmTimer(m3pc_handle* h_, hipStream_t st_, double flops, int dt) : h(h_), st(st_) {
+    GemmTimer(m3pc_handle* h_, hipStream_t st_, double flops, int dt, int kind = 0) : h(h_), st(st_) {
         if (!h->prof) return;
         if (h->ev_used == h->ev.size()) {
             EventPair n;
@@ -270,6 +272,7 @@ struct GemmTimer {
         e = &h->ev[h->ev_used++];
         e->flops = flops;
         e->dt = dt;
+        e->kind = kind;
         hipEventRecord(e->a, st);
     }
     ~GemmTimer() {
@@ -546,7 +549,7 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
             b.Xout = Xnext ? Xnext : X;
             b.ldx = d;
         }
-        GemmTimer t(h, st, 2.0 * rows * ((double)d * d + 2.0 * d * ff), dt);
+        GemmTimer t(h, st, 2.0 * rows * ((double)d * d + 2.0 * d * ff), dt, 1);
         if (launch_block_fused(b, st)) {
             if (next_ln_done) *next_ln_done = fuse_ln;
             return check_launch(pfx.c_str());
@@ -1059,7 +1062,7 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         kp.KV = (bf16_t*)h->QKV;
         kp.ldkv = 2 * d;
         kp.kv_bytes = (unsigned)((size_t)n * Le * 2 * d * 2);
-        GemmTimer t(h, st, 2.0 * n * Le * (3.0 * d * d), dt);
+        GemmTimer t(h, st, 2.0 * n * Le * (3.0 * d * d), dt, 2);
         kv_done = launch_kv_fused(kp, st);
     }
     if (!kv_done) {
@@ -1189,7 +1192,7 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         b.ldh = d;
         bool ok;
         {
-            GemmTimer t(h, st, 2.0 * n * nq * ((double)d * d + 2.0 * d * h->ff), dt);
+            GemmTimer t(h, st, 2.0 * n * nq * ((double)d * d + 2.0 * d * h->ff), dt, 1);
             ok = launch_block_fused(b, st);
         }
         if (ok) {
@@ -1712,7 +1715,8 @@ int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     // independent, results are identical to the one-stream order.
     const int dt = a->precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32;
     const int n = a->n_count;
-    if (h->two_stream && dt == DT_BF16 && n >= 512) {
+    // (only when one half alone fills the chip with fused-tail tiles: more than 256 tiles of 128 rows in the whole pass)
+    if (h->two_stream && dt == DT_BF16 && n >= 512 && (long long)n * (2 * T - hh + 1) > 256 * 128) {
         // part sizes: M3PC_STREAM_SPLIT=a,b,c (lab) or two halves
         std::vector<int> parts;
         if (!h->stream_split.empty()) {
@@ -1730,13 +1734,13 @@ int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         HIPCHK(hipEventRecord(h->ev_fork, st));
         int rc = 0, c0 = 0;
         for (size_t i = 0; i < parts.size() && rc == 0; ++i) {
-            hipStream_t s = i == 0 ? st : h->auxs[i - 1];
-            if (i) HIPCHK(hipStreamWaitEvent(s, h->ev_fork, 0));
+            hipStream_t s = i == 0 || h->prof_serial ? st : h->auxs[i - 1];
+            if (s != st) HIPCHK(hipStreamWaitEvent(s, h->ev_fork, 0));
             set_view(h, c0, parts[i]);
             rc = candidate_pass(h, a, states, rewards, parts[i], sample_actions + (size_t)c0 * hh * h->A, expect_return + c0,
                                 pred_rewards ? pred_rewards + (size_t)c0 * hh : nullptr,
                                 pred_boot ? pred_boot + (size_t)c0 * hh : nullptr, dt, s);
-            if (i) {
+            if (s != st) {
                 HIPCHK(hipEventRecord(h->ev_joins[i - 1], s));
                 HIPCHK(hipStreamWaitEvent(st, h->ev_joins[i - 1], 0));
             }
@@ -2090,6 +2094,7 @@ int m3pc_debug_clock_big(long long* out4) {
 int m3pc_profile_enable(m3pc_handle* h, int enable) {
     if (!h) return fail(M3PC_EINVAL, "null handle");
     h->prof = enable != 0;
+    h->prof_serial = enable == 2;
     return 0;
 }
 
@@ -2100,7 +2105,11 @@ int m3pc_profile_read(m3pc_handle* h, int precision, long long* launches, double
     double ms = 0, fl = 0;
     long long cnt = 0;
     for (size_t i = 0; i < h->ev_used; ++i) {
-        if (precision >= 0 && h->ev[i].dt != (precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32)) continue;
+        if (precision == M3PC_PROF_LAYER_TAIL) {
+            if (h->ev[i].kind != 1) continue;
+        } else if (precision >= 0 && h->ev[i].dt != (precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32)) {
+            continue;
+        }
         float t = 0.f;
         HIPCHK(hipEventElapsedTime(&t, h->ev[i].a, h->ev[i].b));
         ms += t;
