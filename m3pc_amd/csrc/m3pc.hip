@@ -1392,19 +1392,21 @@ int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out) {
     if (const char* e = getenv("M3PC_TWO_STREAM")) h->two_stream = atoi(e) != 0;
     h->auxs.push_back(h->aux);
     h->ev_joins.push_back(h->ev_join);
-    for (int i = 1; i < 3; ++i) {
-        hipStream_t s;
-        hipEvent_t e;
-        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        h->auxs.push_back(s);
-        h->ev_joins.push_back(e);
-    }
+    // (lab: more than two candidate parts.  Streams are created only when asked for: a process has four hardware queues,
+    // with more streams than that two of them share a queue and the halves no longer overlap)
     if (const char* e = getenv("M3PC_STREAM_SPLIT")) {
         for (const char* q = e; *q;) {
             h->stream_split.push_back(atoi(q));
             while (*q && *q != ',') ++q;
             if (*q == ',') ++q;
+        }
+        for (size_t i = 1; i < h->stream_split.size() && i < 3; ++i) {
+            hipStream_t s2;
+            hipEvent_t e2;
+            HIPCHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+            h->auxs.push_back(s2);
+            h->ev_joins.push_back(e2);
         }
     }
     if (D.critic_hidden > 0) {
