@@ -2087,6 +2087,25 @@ int m3pc_debug_kv_fused(const void* Z, int n, int Le, int kept0, int off0, int k
     return check_launch("debug_kv_fused");
 }
 
+// which XCD (and CU) every workgroup of a launch on `stream` lands on: out[2 i] = XCC_ID, out[2 i + 1] = HW_ID register
+// (tools/xcd_probe.py: maps the bits of a hipExtStreamCreateWithCUMask mask to XCDs)
+__global__ void xcc_probe_kernel(int* out) {
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = (int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID[3:0]
+        out[2 * blockIdx.x + 1] = (int)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); // HW_REG_HW_ID
+    }
+    // (long enough that the workgroups of the launch spread over everything the stream may use)
+    const long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < 1024; ++i) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 >= 300) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+int m3pc_debug_xcc_probe(int* out, int n_blocks, void* stream) {
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, out);
+    return check_launch("xcc_probe");
+}
+
 int m3pc_debug_clock_big(long long* out4) {
     HIPCHK(hipDeviceSynchronize());
     read_big_probe(out4);
