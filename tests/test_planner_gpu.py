@@ -110,6 +110,36 @@ def test_c2_bf16_with_fp32_rescore_keeps_reference_argmax():
     p.handle.close()
 
 
+def test_c2_candidate_halves_on_two_streams_are_bit_identical_to_one_stream(monkeypatch):
+    """The default splits the 1024 candidates of BASELINE config 2 into two halves on two HIP streams (fused-tail tiles: one
+    round per half instead of two, DESIGN.md 4 "overlap"); M3PC_TWO_STREAM=0 (read when the handle is created) runs one chain.
+    Candidates are independent and every kernel's result for a row does not depend on the row count, so all scores are equal
+    bit for bit -- also with the fused kernels switched off (the GEMM + LayerNorm chains)."""
+    dims = synth.Dims(11, 3, 32)
+    eps = synth.make_eps(1024, dims, 1).cuda()
+    hist = synth.make_history(dims, 0)
+    hist["path_length"] = 500
+
+    def scores(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        p = _planner(dims, _cfg(32, 1024, 16, 0.01, "rtg_guiding"), precision="bf16")
+        for k in env:
+            monkeypatch.delenv(k)
+        p._eps = lambda shape: eps
+        s, a, r, h, rtg = p.assemble_window(hist, rtg=3.0)
+        res = p.handle.plan_step(capi.MODE_RTG, s, a, r, eps.reshape(1024, -1, 3), h, rtg, 0.6, 0.99, 1024, 0, 1024,
+                                 precision=capi.PREC_BF16)
+        out = res["expect_return"].clone(), res["sample_actions"].clone()
+        torch.cuda.synchronize()
+        p.handle.close()
+        return out
+
+    er2, sa2 = scores({})
+    er1, sa1 = scores({"M3PC_TWO_STREAM": "0"})
+    assert torch.equal(er1, er2) and torch.equal(sa1, sa2)
+
+
 @pytest.mark.parametrize("pl", [0, 2, 37, 997])
 def test_zeroshot_goal_reaching_matches_reference_golden(pl):
     """action_piid_sample (two chained forwards) and action_id_sample on windows whose future states are the
