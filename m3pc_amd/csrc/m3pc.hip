@@ -612,8 +612,10 @@ struct TokIn {
 
 // embed + encoder stack + encoder.norm -> EncOut (fp32) [and bf16 copy in Z when dt == bf16 and want_b]
 // n_indep: number of leading encoder tokens that are identical for every batch element (candidate pass: history)
+// layer_from / layer_to / ln_state: the pass can be enqueued in pieces (the embedding goes with layer 0, encoder.norm with the
+// last layer); *ln_state carries "norm1 of the next layer is already in Hn" from one piece to the next
 int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hipStream_t st, bool bf16_out_only = false,
-                int n_indep = 0) {
+                int n_indep = 0, int layer_from = 0, int layer_to = 1 << 30, bool* ln_state = nullptr) {
     // first-layer pruning (run_block): whole 32-query tiles of shared tokens, bf16 candidate passes only
     int n_sh = 0;
     static const bool no_prune1 = getenv("M3PC_NO_PRUNE1") != nullptr;  // A/B switch
@@ -656,7 +658,7 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
         e.Hb = (bf16_t*)h->Hn;
     else
         e.Hf = (float*)h->Hn;
-    launch_embed(e, st);
+    if (layer_from <= 0) launch_embed(e, st);
     LnP ln;
     memset(&ln, 0, sizeof(ln));
     ln.X = h->X;
@@ -669,10 +671,10 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
         ln.Yb = (bf16_t*)h->Z;  // the candidate pass consumes the encoder output only as a bf16 GEMM operand
     else
         ln.Yf = h->EncOut;
-    bool ln_done = true;  // norm1 of layer 0 comes from the embedding kernel
+    bool ln_done = layer_from <= 0 || !ln_state ? true : *ln_state;  // norm1 of layer 0 comes from the embedding kernel
     const int nl = h->dm.n_enc_layer;
-    float* Xs = h->X;     // where the residual stream lives
-    for (int i = 0; i < nl; ++i) {
+    float* Xs = shared_res && layer_from > 0 ? h->Y : h->X;  // where the residual stream lives
+    for (int i = layer_from > 0 ? layer_from : 0; i < nl && i < layer_to; ++i) {
         float* Xn = shared_res && i == 0 ? h->Y : nullptr;
         LnP nxt = ln;  // what follows layer i on X: norm1 of layer i+1 (-> Hn) or encoder.norm (-> EncOut / Z)
         nxt.X = ln.X = Xn ? Xn : Xs;
@@ -688,6 +690,9 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
                       i + 1 == nl && bf16_out_only, Xn, Xn ? n_indep : 0));
         if (Xn) Xs = Xn;
     }
+    if (ln_state) *ln_state = ln_done;
+    if (layer_to < nl) return check_launch("encoder");
+    ln.X = Xs;
     if (!ln_done) launch_layernorm(ln, st);
     return check_launch("encoder");
 }
@@ -986,9 +991,12 @@ int build_tables(m3pc_handle* h, Plan* pl, int qi, int dt, hipStream_t st) {
 // ---------------------------------------------------------------------------------- candidate pass
 // widx (optional, device (n,)): candidate c belongs to history window widx[c] of states (., T, S) / rewards (., T, 1);
 // without it all candidates share window 0 and the history tokens are computed once (first-layer sharing).
+// stage_from / stage_to / ln_state: the pass can be enqueued in pieces -- stage k < n_enc_layer is encoder layer k (the
+// embedding goes with stage 0), stage n_enc_layer everything behind the encoder -- so that the pieces of two candidate halves
+// can be enqueued alternately (m3pc_plan_step)
 int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* rewards, int n,
                    const float* sample_actions, float* expect_return, float* pred_rewards, float* pred_boot, int dt,
-                   hipStream_t st, const int* widx = nullptr) {
+                   hipStream_t st, const int* widx = nullptr, int stage_from = 0, int stage_to = 1 << 30, bool* ln_state = nullptr) {
     const int T = h->T, d = h->d, hh = a->horizon, idx = T - hh;
     const size_t es = dtype_size(dt);
     std::vector<unsigned char> m[4];
@@ -1020,7 +1028,9 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     in.wstride[M3PC_REWARDS] = T;
     // encoder order is states 0..idx, actions 0..T-1: everything before actions[idx] is history, shared by all candidates
     // of one window
-    CHK(run_encoder(h, pl, in, n, dt, st, dt == DT_BF16, widx ? 0 : (idx + 1) + idx));
+    const int nl_enc = h->dm.n_enc_layer;
+    if (stage_from < nl_enc) CHK(run_encoder(h, pl, in, n, dt, st, dt == DT_BF16, widx ? 0 : (idx + 1) + idx, stage_from, stage_to, ln_state));
+    if (stage_to <= nl_enc) return check_launch("candidate_pass");
 
     // decoder inputs of the un-masked tokens (kept sets are prefixes 0..kept-1 for the fd mask)
     const void* enc_op = dt == DT_BF16 ? h->Z : (const void*)h->EncOut;
@@ -1734,19 +1744,28 @@ int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
             parts = {n0, n - n0};
         }
         HIPCHK(hipEventRecord(h->ev_fork, st));
-        int rc = 0, c0 = 0;
-        for (size_t i = 0; i < parts.size() && rc == 0; ++i) {
-            hipStream_t s = i == 0 || h->prof_serial ? st : h->auxs[i - 1];
-            if (s != st) HIPCHK(hipStreamWaitEvent(s, h->ev_fork, 0));
-            set_view(h, c0, parts[i]);
-            rc = candidate_pass(h, a, states, rewards, parts[i], sample_actions + (size_t)c0 * hh * h->A, expect_return + c0,
-                                pred_rewards ? pred_rewards + (size_t)c0 * hh : nullptr,
-                                pred_boot ? pred_boot + (size_t)c0 * hh : nullptr, dt, s);
-            if (s != st) {
-                HIPCHK(hipEventRecord(h->ev_joins[i - 1], s));
-                HIPCHK(hipStreamWaitEvent(st, h->ev_joins[i - 1], 0));
+        int rc = 0;
+        // enqueued stage by stage, alternating between the parts: the host needs ~1.5 us per launch, and a part whose 45
+        // launches are all enqueued behind the other part's starts that much later on the device -- and ends that much later,
+        // with the other stream idle.  (With the profiling brackets in serial mode: one part after the other.)
+        const int n_stage = h->dm.n_enc_layer + 1;
+        bool lnst[4] = {true, true, true, true};
+        for (int stg = 0; stg < (h->prof_serial ? 1 : n_stage) && rc == 0; ++stg) {
+            int c0 = 0;
+            for (size_t i = 0; i < parts.size() && rc == 0; ++i) {
+                hipStream_t s = i == 0 || h->prof_serial ? st : h->auxs[i - 1];
+                if (s != st && stg == 0) HIPCHK(hipStreamWaitEvent(s, h->ev_fork, 0));
+                set_view(h, c0, parts[i]);
+                rc = candidate_pass(h, a, states, rewards, parts[i], sample_actions + (size_t)c0 * hh * h->A, expect_return + c0,
+                                    pred_rewards ? pred_rewards + (size_t)c0 * hh : nullptr,
+                                    pred_boot ? pred_boot + (size_t)c0 * hh : nullptr, dt, s, nullptr,
+                                    h->prof_serial ? 0 : stg, h->prof_serial ? 1 << 30 : stg + 1, &lnst[i]);
+                if (s != st && stg == n_stage - 1) {
+                    HIPCHK(hipEventRecord(h->ev_joins[i - 1], s));
+                    HIPCHK(hipStreamWaitEvent(st, h->ev_joins[i - 1], 0));
+                }
+                c0 += parts[i];
             }
-            c0 += parts[i];
         }
         set_view(h, 0, h->dm.max_candidates);
         return rc;
