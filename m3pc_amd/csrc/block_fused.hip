@@ -38,10 +38,10 @@
 // Registers: 256 accumulators + the 32 LayerNorm-2 fragments (128) + hidden tiles, their bf16 fragments and the
 // fragment window do not fit 512 with room for the compiler, so the fragments of k-steps 24..31 live in LDS (8 KiB per
 // wave, private to it) and are read like the weights, one per group of four MFMAs.
-// Sync: ONE s_waitcnt vmcnt(8) lgkmcnt(0) + s_barrier per stage, placed four MFMAs before the stage ends: every wave
+// Sync: ONE s_waitcnt vmcnt(7) lgkmcnt(0) + s_barrier per stage, placed eight MFMAs before the stage ends: every wave
 // has read all of stage t (slot t % 3 is free: stage t+3's pieces go there) and stage t+1 has landed everywhere (its
 // first fragments are read under the last MFMAs of stage t).  Stage t+2 stays in flight across the barrier.
-// Fragments are read four at a time, one group (four MFMAs) ahead: one lgkmcnt wait per four MFMAs.
+// Fragments are read four at a time, two groups (eight MFMAs) ahead: one lgkmcnt wait per four MFMAs.
 // With one wave per SIMD the kernel is bound by what that wave has to ISSUE besides its MFMAs (an MFMA leaves room for
 // about five other instructions); the layout above is what keeps that count down.
 #include <type_traits>
@@ -269,9 +269,14 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     stamps[1] = __builtin_readcyclecounter();
 
-    u32x4 R[2][4];   // weight fragment groups: group g of a ring stage lives in R[g & 1]
+    // weight fragment groups, read TWO groups (eight MFMAs) ahead: group g of phase ph lives in R[(2 ph + g) % 3] -- 8 groups
+    // per phase, so the index of a phase's first group is 2 ph mod 3 = (2 SL) % 3, static like the ring slot
+    u32x4 R[3][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) R[0][k] = frag(0, k);
+    for (int k = 0; k < 4; ++k) {
+        R[0][k] = frag(0, k);
+        R[1][k] = frag(0, 4 + k);
+    }
 
     // one phase = one ring stage = 8 groups of {reads of the next group, one DMA piece, 4 x (MFMA, VALU slice)}
     //   ph: phase index (runtime); SL: its ring slot ph % 3 (static)
@@ -280,23 +285,25 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     // Every MFMA slot is its own scheduling region, so the VALU slices stay between the MFMAs they are written beside.
     auto phase = [&](int ph, auto sl_c, auto&& extra, auto&& mma, auto&& valu) {
         constexpr int SL = decltype(sl_c)::value;
+        constexpr int RB = (2 * SL) % 3;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            if (g == 7) {  // every read of this stage is issued: sync, then on into the next stage's slot
-                if (DBG == 6) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (g == 6) {  // every read of this stage is issued (two groups ahead): sync, then on into the next stage's slot
+                if (DBG == 6) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             if (DBG != 7) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) R[(g + 1) & 1][k] = g < 7 ? frag(SL, 4 * (g + 1) + k) : frag((SL + 1) % 3, k);
+                for (int k = 0; k < 4; ++k)
+                    R[(RB + g + 2) % 3][k] = g < 6 ? frag(SL, 4 * (g + 2) + k) : frag((SL + 1) % 3, 4 * (g - 6) + k);
             }
             extra(g + 1);
-            // 8 DMA pieces per stage: pieces 1..7 of stage ph+2 before the sync, piece 0 of stage ph+3 after it
+            // 8 DMA pieces per stage: pieces 1..7 of stage ph+2, piece 0 of stage ph+3 behind the sync
             if (g < 7) piece(ph + 2, (SL + 2) % 3, 1 + g);
             else piece(ph + 3, SL, 0);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                mma(4 * g + k, R[DBG == 7 ? 0 : g & 1][k], g);
+                mma(4 * g + k, R[DBG == 7 ? 0 : (RB + g) % 3][k], g);
                 if (DBG == 4) __builtin_amdgcn_sched_barrier(0);
                 valu(g, k);
                 __builtin_amdgcn_sched_barrier(0);
