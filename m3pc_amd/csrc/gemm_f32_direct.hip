@@ -12,6 +12,8 @@
 //     exact-erf GELU / residual run once per output element.
 // One launch per GEMM instead of two, K chains 4-16x shorter.  Costs twice the L2->CU operand traffic of an
 // LDS-shared tile, which does not matter at these sizes (<= 200 MB per launch).
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace m3pc {
@@ -173,11 +175,14 @@ bool gemm_f32_direct_covers(const GemmP& p) {
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || (p.lda % 4) || (p.ldw % 4)) return false;
     const long long tiles64 = (long long)((p.M + 63) / 64) * (p.N / 64);
     // Measured (tools/gemm_bench_f32.py, variants 0 / 2): wins where the problem is tiny -- K = 512 with fewer than
-    // 128 64x64 tiles (policy pass 6.4 vs 9.6 us, re-score out-proj 11.9 vs 15.7 us); loses to the LDS-shared tile
+    // 200 64x64 tiles (policy pass 6.4 vs 9.6 us, re-score out-proj 11.9 vs 15.7 us); loses to the LDS-shared tile
     // once operands are re-read by many workgroups (M = 784, N >= 1024: 39 vs 25 us) and on K = 2048 (one launch with
     // 128-deep slices: 20.6 us against 7.2 + 7.4 us for split-K slabs + the row-wise reduce, which also applies the
     // LayerNorm that follows).
-    if (p.K > 512 || tiles64 >= 128) return false;
+    // 200: with the bound-driven re-score at its usual 8 candidates (392 rows) the Q|K|V projection (168 tiles) is 3 us faster
+    // here, FFN1 (224 tiles) is not: step -15 us against a limit of 128 (M3PC_DIRECT_TILES re-measures).
+    static const long long max_tiles = getenv("M3PC_DIRECT_TILES") ? atoll(getenv("M3PC_DIRECT_TILES")) : 200;
+    if (p.K > 512 || tiles64 >= max_tiles) return false;
     if (p.N % 32 != 0 || p.K % (16 * 32) != 0) return false;
     if (p.a_ln_g && (!p.a_ln_b || p.K % 256 != 0 || p.K > 2048 || ((uintptr_t)p.a_ln_g & 15) || ((uintptr_t)p.a_ln_b & 15))) return false;
     return true;
