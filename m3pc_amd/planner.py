@@ -81,6 +81,7 @@ class HipPlanner:
         self.rescore_min, self.rescore_max = int(rescore_min), int(rescore_max)
         self._delta_fixed = None if rescore_delta is None else float(rescore_delta)
         self._delta: Optional[float] = self._delta_fixed
+        self._kspec, self._exceed = int(rescore_min), 0.05  # size of the unconditional first re-score, share of steps that needed more
         self.generator = generator
         if self.world > 1:
             # every rank draws eps / the multinomial variates itself: the streams must be the same ones
@@ -101,6 +102,7 @@ class HipPlanner:
     def load_state_dict(self, state_dict):
         self.handle.load_weights(state_dict)
         self._delta = getattr(self, "_delta_fixed", None)  # the bf16 error bound belongs to the weights: re-calibrate
+        self._kspec, self._exceed = int(getattr(self, "rescore_min", 8)), 0.05
 
     def load_critic(self, q_state_dict, obs_mean, obs_std):
         self.handle.set_critic(q_state_dict, obs_mean, obs_std)
@@ -160,7 +162,7 @@ class HipPlanner:
             tail = (h, rtg, float(lmbda), float(cfg.discount))
             if self._delta is None:
                 self._delta = self._calibrate(er, rs, tail, N)
-            kmax, kmin = min(self.rescore_max, N - 1 if N > 1 else 1), min(self.rescore_min, N)
+            kmax, kmin = min(self.rescore_max, N - 1 if N > 1 else 1), min(max(self.rescore_min, self._kspec), N)
             kmin = max(min(kmin, kmax), 1)
             # The candidates come sorted by bf16 score, so the set inside the window is a prefix of the list and its first
             # kmin entries are re-scored whatever the count turns out to be: that re-score and the select are enqueued
@@ -179,7 +181,15 @@ class HipPlanner:
                 self.handle.rescore_listed(mode, states, actions, rewards, eps, er, cand[kmin:n_re].contiguous(), *tail)
                 sel = self.handle.select(er, a0, float(cfg.temperature), expo)
             top = cand[:n_re]
-            extra = dict(n_rescored=n_re, n_in_window=int(st[3]), min_margin_outside=float(st[1]), delta=self._delta)
+            # the size of the first (unconditional) re-score follows the workload: a second pass costs a whole fp32 chain
+            # (~0.3 ms), four more candidates in the first ~0.02-0.05 ms -- grown when more than a fifth of the recent steps
+            # needed the second pass, shrunk again when (almost) none did.  Same decisions on every rank (same counts).
+            self._exceed += (float(n_re > kmin) - self._exceed) / 16.0
+            if self._exceed > 0.2 and kmin < kmax:
+                self._kspec, self._exceed = min(kmax, kmin + 4), 0.05
+            elif self._exceed < 0.005 and self._kspec > self.rescore_min:
+                self._kspec, self._exceed = max(self.rescore_min, self._kspec - 4), 0.05
+            extra = dict(n_rescored=n_re, n_in_window=int(st[3]), min_margin_outside=float(st[1]), delta=self._delta, n_first=kmin)
         # torch.multinomial(p, 1) == argmax(p / q), q ~ Exp(1) from the same generator (ATen's
         # multinomial fast path); drawing q here and finishing inside the select kernel gives the same index
         if sel is None:
