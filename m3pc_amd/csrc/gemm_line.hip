@@ -72,10 +72,12 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 1) void gemm_line_kernel(GemmP
     };
     // DMA pieces: piece I = wid + 4 i (i < PU) of a unit = its rows 8 I .. 8 I + 7, 8 lanes per 128-byte row.  The
     // per-lane source offsets are relative to the tile, the tile itself is a scalar byte offset (buffer soffset) -- so
-    // moving on to the next tile costs no registers.  That needs every tile to look alike: no A row map (a ragged
-    // last tile is fine: its rows past M lie outside the buffer resource, read as zeros and are never stored); otherwise
-    // (`uniform` false) the launcher starts one workgroup per tile and the offsets are absolute.
-    const bool uniform = p.amap.rpg == 0;
+    // moving on to the next tile costs no registers.  That needs every tile to look alike: no A row map, and a ragged
+    // last tile only when the caller vouches for readable memory behind A (GemmP::a_padded): the tile's origin rides in
+    // the buffer instruction's scalar offset, which the hardware range check does NOT include, so the DMA of a ragged
+    // tile reads up to 127 rows past M (never stored).  Otherwise (`uniform` false) the launcher starts one workgroup
+    // per tile and the per-lane offsets are absolute and clamped to row M - 1.
+    const bool uniform = p.amap.rpg == 0 && (p.M % BT == 0 || p.a_padded);
     int a_vo[PU], w_vo[PU];
     auto piece_offsets = [&](int r0, int c0) {
 #pragma unroll
@@ -312,7 +314,7 @@ static bool launch_line(const GemmP& p, hipStream_t st) {
     const bool f32out = p.Cf != nullptr;
     const int epi = (p.gelu ? GE_GELU : 0) | (p.res ? GE_RES : 0) | (f32out ? GE_F32OUT : 0);
     const int tiles = ((p.M + BT - 1) / BT) * (p.N / BT), slots = (BT == 128 ? 2 : 1) * 256;  // resident workgroups on 256 CUs
-    const bool uniform = p.amap.rpg == 0;  // (see the kernel: persistent workgroups need look-alike tiles)
+    const bool uniform = p.amap.rpg == 0 && (p.M % BT == 0 || p.a_padded);  // (see the kernel: persistent workgroups need look-alike tiles)
     const dim3 grid(uniform && tiles > slots ? slots : tiles), block(256);
     switch (epi) {
         case 0:

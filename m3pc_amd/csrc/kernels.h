@@ -43,6 +43,9 @@ struct GemmP {
     RowMap cmap;   // applies to res, Cf, Cb
     float* ws;     // split-K slab workspace (optional): few-row fp32 GEMMs split K over blocks
     long long ws_bytes;
+    int a_padded;  // != 0: at least 127 rows (lda each) of readable memory follow the last row of A (the handle's
+                   // workspaces: bf16 rows in fp32-sized buffers).  gemm_line.hip then runs a ragged last tile on its
+                   // persistent path, whose DMA reads rows past M (never stored); 0: ragged M takes the clamped path
     int variant;   // 0 = default kernel selection; other values pick experimental configurations
     int peel;      // set by launch_gemm_glds: rows >= peel are covered by small tiles (0 = off); callers leave it 0
     // optional: the LayerNorm that consumes C (fp32, N % 256 == 0, identity cmap).  When the launcher takes the

@@ -318,6 +318,9 @@ GemmP gemm_basic(const void* A, int lda, const void* Wp, int ldw, int M, int N, 
     p.K = K;
     p.bias = bias;
     p.rt_mod = 1;
+    // every A operand built here is one of the handle's workspaces (fp32-sized, R rows): a many-row bf16 operand leaves at
+    // least as many bytes behind its last row as it occupies (see GemmP::a_padded)
+    p.a_padded = 1;
     return p;
 }
 void gemm_out(GemmP& p, int dt_out, void* C, int ldc) {
@@ -1992,6 +1995,7 @@ int m3pc_debug_gemm(int dtype, const void* A, const void* Wt, const float* bias,
                     int K, int gelu, int f32out, int variant, void* stream) {
     static const int ldpad = getenv("M3PC_DEBUG_LDPAD") ? atoi(getenv("M3PC_DEBUG_LDPAD")) : 0;  // operand row padding (elements)
     GemmP p = gemm_basic(A, K + ldpad, Wt, K + ldpad, M, N, K, bias);
+    p.a_padded = 0;  // (a caller's tensor: nothing is known about the memory behind it)
     p.gelu = gelu;
     p.res = res;
     p.ldr = N;
