@@ -387,8 +387,9 @@ int launch_gemm(const GemmP& p, int dtype, hipStream_t st) {
     // a five-unit ring, persistent workgroups (gemm_line.hip).  The residual GEMMs of this class are HBM-bound and stay
     // on the three-slot ring kernel, as do output row maps / row tables.
     static const bool no_line = getenv("M3PC_NO_GEMM_LINE") != nullptr;  // A/B switch
+    static const long long line_min = getenv("M3PC_LINE_MIN_TILES") ? atoll(getenv("M3PC_LINE_MIN_TILES")) : 256;  // (one tile per CU at least: the head GEMMs of a candidate half, 256 tiles, take 12-15 us here against 22-26)
     if (dtype == DT_BF16 && p.variant == 0 && !no_line && !p.res && p.K < 1024 &&
-        (long long)((p.M + 127) / 128) * (p.N / 128) >= 384 && launch_gemm_line(p, 128, st))
+        (long long)((p.M + 127) / 128) * (p.N / 128) >= line_min && launch_gemm_line(p, 128, st))
         return 0;
     if (dtype == DT_BF16 && p.variant == 0 && !no_big && p.K >= 1024 && (long long)((p.M + 255) / 256) * (p.N / 256) >= 224 &&
         launch_gemm_big(p, st))
