@@ -694,6 +694,7 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreP p) {
         disc = __fmul_rn(disc, p.gamma);
     }
     p.expect_return[n] = er;
+    if (p.scatter_out) p.scatter_out[p.scatter_index[n]] = er;
 }
 void launch_score(const ScoreP& p, hipStream_t st) {
     if (p.n <= 0) return;

@@ -305,6 +305,8 @@ struct ScoreP {
     double lmbda;
     float* expect_return;  // (n,)
     float* boot_out;       // optional: scaled bootstrap written back (n,h)
+    const int* scatter_index;  // optional (n,): the score of row i also goes to scatter_out[scatter_index[i]]
+    float* scatter_out;
 };
 void launch_score(const ScoreP& p, hipStream_t st);
 

@@ -143,6 +143,8 @@ struct m3pc_handle {
     bool allow_splitk = true;     // see gemm(): off while sharded candidates are scored
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    const int* score_scatter_index = nullptr;  // set around a pass whose scores also go to scatter_out[index[i]] (score_kernel)
+    float* score_scatter_out = nullptr;
     std::vector<hipStream_t> auxs;   // auxs[0] == aux
     std::vector<hipEvent_t> ev_joins;
     std::vector<int> stream_split;
@@ -1309,6 +1311,8 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     sc.lmbda = a->lmbda;
     sc.expect_return = expect_return;
     sc.boot_out = pred_boot;
+    sc.scatter_index = h->score_scatter_index;  // (m3pc_rescore_listed: the scores also go straight to their candidates' slots)
+    sc.scatter_out = h->score_scatter_out;
     launch_score(sc, st);
     if (pred_rewards) HIPCHK(hipMemcpyAsync(pred_rewards, rw, (size_t)n * hh * sizeof(float), hipMemcpyDeviceToDevice, st));
     return check_launch("candidate_pass");
@@ -1960,8 +1964,12 @@ int m3pc_rescore_listed(m3pc_handle* h, const m3pc_plan_args* a, const float* st
                         const float* eps, const int* index, int n, float* expect_return, void* stream) {
     if (!h || !a || !expect_return || !index) return fail(M3PC_EINVAL, "null argument");
     if (n < 1 || n > 1024) return fail(M3PC_EINVAL, "n %d outside [1, 1024]", n);
-    CHK(m3pc_rescore(h, a, states, actions, rewards, eps, index, n, nullptr, h->er_top, stream));
-    launch_scatter(h->er_top, index, n, expect_return, nullptr, (hipStream_t)stream);
+    h->score_scatter_index = index;
+    h->score_scatter_out = expect_return;
+    const int rc = m3pc_rescore(h, a, states, actions, rewards, eps, index, n, nullptr, h->er_top, stream);
+    h->score_scatter_index = nullptr;
+    h->score_scatter_out = nullptr;
+    if (rc) return rc;
     return check_launch("rescore_listed");
 }
 
