@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / closed-loop / shipped-config side measurements")
     ap.add_argument("--strong", action="store_true", help="keep the global candidate count fixed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alone-pass", action="store_true",
+                    help="skip the extra instrumented pass with the candidate halves serialised (roofline.alone); "
+                         "tools/profile_round.sh: every launch of the profiled command then runs as in the timed region")
     ap.add_argument("--env", default="hopper", choices=["hopper", "walker2d", "halfcheetah"],
                     help="state/action dims of the D4RL family (BASELINE configs 3-4 use walker2d / halfcheetah)")
     ap.add_argument("--guidance", default="rtg_guiding", choices=["rtg_guiding", "critic_lambda_guiding"])
@@ -219,32 +222,36 @@ def main():
         planner.handle.profile_enable(False)
         return cls_, tail_, all_
 
-    # as run (the two candidate halves overlapped on two streams: a bracket also holds what the other half does meanwhile) ...
-    (o_launches, o_ms, o_flops), (ot_launches, ot_ms, ot_flops), _ = instrumented(True)
+    # as run: the two candidate halves overlapped on two streams exactly as in the timed region (a bracket also holds what
+    # the other half does on the chip meanwhile) ...
+    (launches, gemm_ms, gemm_flops), (t_launches, t_ms, t_flops), (all_launches, all_ms, all_flops) = instrumented(True)
     # ... and with the halves one after the other on one stream: the same launches, each alone on the chip
-    (launches, gemm_ms, gemm_flops), (t_launches, t_ms, t_flops), (all_launches, all_ms, all_flops) = instrumented(2)
+    (a_launches, a_ms, a_flops), (at_launches, at_ms, at_flops), _ = ((0, 0.0, 0.0), (0, 0.0, 0.0), None) if args.no_alone_pass else instrumented(2)
     peak = MFMA_PEAK_TFLOPS[args.precision]
     f_step = alg_flops(n_local, T, H, S, A, mode="critic" if critic_mode else "rtg")
     cls = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    if t_launches:   # the dominant kernel: the fused layer tail (block_fused.hip), 59 % of the step's kernel time
+    if t_launches:   # the dominant kernel: the fused layer tail (block_fused.hip), ~40 % of the step's kernel time
         achieved, dom_l, dom_ms, dom_fl = t_flops / (t_ms * 1e-3) / 1e12, t_launches, t_ms, t_flops
+        al_l, al_ms, al_fl = at_launches, at_ms, at_flops
         kname = ("m3pc::block_fused_kernel (layer tail: out-proj + residual + LayerNorm + Linear/GELU/Linear + residual + LayerNorm, "
                  "one launch per layer and candidate half)")
     else:            # fp32 mode / shapes the fused kernel does not cover: the GEMM class
         achieved, dom_l, dom_ms, dom_fl = cls, launches, gemm_ms, gemm_flops
+        al_l, al_ms, al_fl = a_launches, a_ms, a_flops
         kname = f"the {args.precision} MFMA GEMM launches (gemm_line_kernel / gemm_glds_ring3_kernel / gemm_kernel)"
+    alone = al_fl / (al_ms * 1e-3) / 1e12 if al_ms > 0 else None
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.precision),
                 "peak_measured": 1800.0 if args.precision == "bf16" else None,  # register-resident v_mfma loop at the 1.75 GHz the chip holds
                 "kernel": kname,
                 "flops_per_launch": dom_fl / max(dom_l, 1), "avg_launch_us": 1e3 * dom_ms / max(dom_l, 1),
                 "launches_per_step": dom_l / args.steps, "kernel_ms_per_step": dom_ms / args.steps,
-                "note": "HIP-event brackets on the launch stream, candidate halves one after the other (m3pc_profile_enable(h, 2)): the "
-                        "launches of the timed region, each alone on the chip; `overlapped` = the same brackets with the halves on "
-                        "two streams as in the timed region, where a launch shares the chip with the other half's kernels",
-                "overlapped": {"avg_launch_us": 1e3 * (ot_ms if t_launches else o_ms) / max(ot_launches if t_launches else o_launches, 1),
-                               "achieved": round((ot_flops / (ot_ms * 1e-3) if t_launches and ot_ms > 0 else
-                                                  (o_flops / (o_ms * 1e-3) if o_ms > 0 else 0.0)) / 1e12, 2)},
+                "note": "HIP-event brackets on the stream of each launch in an instrumented pass of the same K steps, run as the timed "
+                        "region runs: the two candidate halves on two streams, so a launch shares the chip with the other half's "
+                        "kernels for part of its bracket; `alone` = the same launches with the halves one after the other on one "
+                        "stream (m3pc_profile_enable(h, 2)), each alone on the chip",
+                "alone": None if alone is None else {"avg_launch_us": 1e3 * al_ms / max(al_l, 1), "achieved": round(alone, 2),
+                                                      "frac": round(alone / peak, 4)},
                 # every MFMA launch of the compute dtype (fused tails, fused decoder input, Q|K|V / head GEMMs)
                 "mfma_class": {"achieved": round(cls, 2), "frac": round(cls / peak, 4), "launches_per_step": launches / args.steps,
                                "ms_per_step": gemm_ms / args.steps},

@@ -3,7 +3,7 @@
 #   kernel trace + stats, FETCH_SIZE, WRITE_SIZE (separate passes: TCC slots), SQ counters.  usage: tools/profile_round.sh r02
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-B="python3 bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline"
+B="python3 bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline --no-alone-pass"
 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_trace -o kt --output-format csv -- $B > gpurun_out/${TAG}_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/${TAG}_fetch -o pmc --output-format csv -- $B > gpurun_out/${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/${TAG}_write -o pmc --output-format csv -- $B > gpurun_out/${TAG}_write.log 2>&1
