@@ -15,8 +15,24 @@
  *     ordinary process memory and are consumed before the call returns.
  *   - `stream` is a hipStream_t passed as void* (0 = default stream).  Calls enqueue work on
  *     it and return without synchronising unless documented otherwise.
- *   - one handle per (process, device); a handle is not re-entrant.
+ *   - one handle per (process, device); a handle is not re-entrant: calls are made from one host thread
+ *     at a time.  Work enqueued by DIFFERENT calls may overlap on the device only as documented at
+ *     "Pipelined plan steps" below.
  *   - all tensors are dense row-major fp32 unless stated otherwise.
+ *   - the library reads no environment variable (A/B switches and kernel-level hooks live in the
+ *     lab build libm3pc_hip_lab.so only, declared in m3pc_hip_debug.h).
+ *
+ * Pipelined plan steps.  A rollout over independent windows (the reference's loops plan one window per
+ * call: replay_buffer.py:204-232, learner.py:645-741) may keep several plan steps in flight: each step
+ * owns one of M3PC_SLOTS step slots (m3pc_plan_args::slot: the policy head and returns tokens of its
+ * policy pass), and the handle holds three workspaces -- the candidate workspace (m3pc_candidate_pass,
+ * m3pc_plan_step_batch's candidate pass, m3pc_forward, m3pc_score_actions of more than max_rescore
+ * candidates or in bf16), the policy workspace (m3pc_policy_pass, m3pc_plan_step_batch's policy pass) and
+ * the re-score workspace (m3pc_rescore* / fp32 m3pc_score_actions of <= max_rescore candidates).  Calls
+ * that use the SAME workspace must be ordered on the device (same stream, or events); calls on different
+ * workspaces may run on different streams at
+ * the same time.  m3pc_amd/planner.py (plan_async) is the reference user: candidate passes back to back
+ * on the caller's stream, the policy passes and the re-scores of the neighbouring steps on two more.
  */
 #ifndef M3PC_HIP_H
 #define M3PC_HIP_H
@@ -25,7 +41,7 @@
 extern "C" {
 #endif
 
-#define M3PC_ABI_VERSION 1
+#define M3PC_ABI_VERSION 2
 
 #define M3PC_OK 0
 #define M3PC_EINVAL (-1)   /* bad argument / shape mismatch            */
@@ -65,7 +81,12 @@ typedef struct m3pc_dims {
     int max_candidates; /* largest n_count a plan_step call will use on this device */
     int max_batch;      /* largest B for m3pc_forward */
     int critic_hidden;  /* TwinQ hidden width (256), 0 = no critic */
+    int max_rescore;    /* largest n of m3pc_rescore* / fp32 m3pc_score_actions that runs in the re-score
+                           workspace (beside a candidate pass); 0 = 64 */
 } m3pc_dims;
+
+/* step slots of a handle (see "Pipelined plan steps") */
+#define M3PC_SLOTS 4
 
 /* one entry of a state_dict: fp32, contiguous, torch layout */
 typedef struct m3pc_named_tensor {
@@ -85,6 +106,10 @@ typedef struct m3pc_plan_args {
     double lmbda;      /* TD(lambda) mixing, python float in the reference (learner.py:313-316) */
     double discount;   /* gamma (learner.py:307-309)                                         */
     double rtg;        /* return-to-go written into every returns slot (learner.py:368-385)  */
+    int slot;          /* step slot in [0, M3PC_SLOTS) holding this step's policy pass           */
+    int returns_f64;   /* dtype of `returns`: 0 float32, 1 float64                               */
+    const void* returns; /* optional device (T,) raw returns row of the window (what
+                          trajectory["returns"] holds, learner.py:272-293); NULL: `rtg` everywhere */
 } m3pc_plan_args;
 
 const char* m3pc_last_error(void);
@@ -96,9 +121,15 @@ int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out);
 int m3pc_destroy(m3pc_handle* h);
 
 /* omtm.load_state_dict (learner.py:33-35): tensors by state_dict name.
- * Unknown names are ignored; every required name must be present.  Re-callable after each
- * fine-tuning update (finetune.py:306); invalidates cached mask-pattern tables.  Synchronous. */
+ * Unknown names are ignored.  The FIRST call must bring every required name; later calls may bring any
+ * subset -- fine-tuning updates the weights between rollouts (finetune.py:306) -- and re-derive only what
+ * depends on the tensors that came: their bf16 copies, the packed fragment streams of the layers they
+ * belong to, the embedding tables, and (decoder-side tensors only) the cached mask-pattern tables.
+ * Synchronous (the tensors may be released when the call returns). */
 int m3pc_load_weights(m3pc_handle* h, const m3pc_named_tensor* tensors, int n, void* stream);
+/* what the last m3pc_load_weights did: out4 = {tensors copied, fused-layer-tail streams re-packed,
+ * fused-decoder-input streams re-packed, 1 if the cached decoder tables were invalidated} */
+int m3pc_load_stats(m3pc_handle* h, long long* out4);
 
 /* ContinuousTokenizer(mean, std, stats, normalize) (tokenizers/continuous.py:31-62):
  * host arrays of `dim` floats. */
@@ -126,6 +157,19 @@ int m3pc_detokenize(m3pc_handle* h, int key, const float* in, float* out, long l
 int m3pc_forward(m3pc_handle* h, int batch, const float* const tokens[4], const unsigned char* const masks[4],
                  float* out_states, float* out_rewards, float* out_returns, float* out_mu, float* out_std,
                  int precision, void* stream);
+
+/* The two halves of m3pc_plan_step as calls of their own, for pipelined callers:
+ *   m3pc_policy_pass     learner.py:278-284: returns tokens + return-conditioned policy (batch 1, rcbc
+ *                        mask, fp32) -> loc / std of the slot (and the caller's copies, optional).  Policy
+ *                        workspace.
+ *   m3pc_candidate_pass  learner.py:285-316: candidates from the slot's policy head and eps, batched
+ *                        forward under the fd mask, TD(lambda) scores.  Candidate workspace.  Arguments as
+ *                        m3pc_plan_step. */
+int m3pc_policy_pass(m3pc_handle* h, const m3pc_plan_args* args, const float* states, const float* actions,
+                     const float* rewards, float* loc, float* std, void* stream);
+int m3pc_candidate_pass(m3pc_handle* h, const m3pc_plan_args* args, const float* states, const float* actions,
+                        const float* rewards, const float* eps, float* loc, float* std, float* sample_actions,
+                        float* expect_return, float* pred_rewards, float* pred_boot, void* stream);
 
 /* One MPC plan step up to (not including) the cross-candidate select:
  * rtg_guiding / critic_lambda_guiding / noise_adding_lambda (learner.py:142-316).
@@ -167,8 +211,9 @@ int m3pc_plan_step_batch(m3pc_handle* h, const m3pc_plan_args* args, int n_windo
                          const int* window_index, float* loc, float* std, float* sample_actions, float* expect_return,
                          void* stream);
 
-/* fp32 re-scoring of an arbitrary subset of the candidates of the LAST m3pc_plan_step on this handle
+/* fp32 re-scoring of an arbitrary subset of the candidates of the plan step that owns args->slot
  * (its policy-pass loc/std are reused; same window, eps and args as that call, args->precision ignored).
+ * Runs in the re-score workspace when n <= max_rescore, else in the candidate workspace.
  * Used after a bf16 candidate pass to make the reported arg-max independent of bf16 rounding: the same
  * learner.py:288-316 arithmetic, restricted to rows `index`.
  *   index           device (n,) int32 candidate ids in [0, n_total)
@@ -191,11 +236,29 @@ int m3pc_rescore_topk(m3pc_handle* h, const m3pc_plan_args* args, const float* s
  * within window = 2 delta of the bf16 maximum.  Finds the kmax + 1 best entries of expect_return (descending; ties to the
  * lower index) and n = clamp(#{E_i >= max E - window}, kmin, kmax).
  *   topk_index  device out (kmax + 1,) int32
- *   stats       device out float[4]: {n, max E - (best E not among the n) [inf if none], max E, unclamped count}
+ *   stats       device out float[4]: {n, max E - (best E not among the n) [inf if none], max E, the count over ALL n_total
+ *               entries, unclamped: > kmax means the listed prefix does not cover the window}
+ *   top_scores  device out (kmax + 1,), optional: expect_return[topk_index[i]] (kept for m3pc_rescore_merge)
  *   host_stats  optional: host-mapped (pinned) float[5] the kernel also writes -- the four stats, then `seq` into [4] with
  *               system scope; a caller that spins on host_stats[4] == seq reads n without a stream synchronisation */
 int m3pc_topk_window(m3pc_handle* h, const float* expect_return, int n_total, int kmax, int kmin, float window,
-                     int* topk_index, float* stats, float* host_stats, float seq, void* stream);
+                     int* topk_index, float* stats, float* top_scores, float* host_stats, float seq, void* stream);
+/* The score vector the select runs on after a partial fp32 re-score, and the certificate that the partial re-score was
+ * enough.  bf16 scores and their fp32 values differ by a common shift c plus a bounded deviation, so un-re-scored entries
+ * are brought onto the fp32 scale before they meet the re-scored ones in one softmax / arg-max (learner.py:318-325):
+ *   index / top_scores / top_rescored: the n best candidates by bf16 score (best first: m3pc_topk_window), their bf16
+ *   scores and their fp32 re-scores (m3pc_rescore)
+ *   c = lower median over the n listed entries of (top_scores[i] - top_rescored[i])
+ *   merged[j] = scores[j] - c for all j < n_total;  merged[index[i]] = top_rescored[i]
+ *   With |(bf16_j - fp32_j) - c| <= delta for every candidate, an un-listed j can hold the fp32 arg-max only if
+ *   scores[j] > f* + c - delta (f* = the best re-scored fp32 score).  need = #{j : scores[j] > f* + c - delta}: need <= n
+ *   certifies arg-max(merged) = the fp32 arg-max; otherwise re-score entries n .. need-1 of the order and merge again
+ *   (need can only shrink).
+ *   stats device out float[4] = {c, max_i |top_scores[i] - top_rescored[i] - c|, need, threshold - best un-listed score};
+ *   host_stats / seq as for m3pc_topk_window.  `merged` may alias `scores`. */
+int m3pc_rescore_merge(m3pc_handle* h, const float* scores, int n_total, const int* index, int n, const float* top_scores,
+                       const float* top_rescored, float delta, float* merged, float* stats, float* host_stats, float seq,
+                       void* stream);
 /* m3pc_rescore of the n listed candidates (device int32 ids), written back into the full score vector in place. */
 int m3pc_rescore_listed(m3pc_handle* h, const m3pc_plan_args* args, const float* states, const float* actions,
                         const float* rewards, const float* eps, const int* index, int n, float* expect_return,

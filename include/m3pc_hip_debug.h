@@ -1,0 +1,42 @@
+/*
+ * m3pc_hip_debug.h -- kernel-level test and bench hooks of the LAB build (libm3pc_hip_lab.so,
+ * `python -m m3pc_amd.build --lab`, compiled with -DM3PC_LAB).  The product library libm3pc_hip.so
+ * exports none of these and reads no environment variable; the lab build additionally honours the
+ * A/B switches M3PC_NO_* / M3PC_GEMM_VARIANT / M3PC_TWO_STREAM / ... listed in DESIGN.md section 7.
+ * Users: tests/test_gemm_kernels_gpu.py, tests/test_block_fused_gpu.py, tools/*.py.
+ */
+#ifndef M3PC_HIP_DEBUG_H
+#define M3PC_HIP_DEBUG_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* one GEMM launch of the library's dispatch on caller tensors (dtype 0 fp32 / 1 bf16 operands):
+ * C = epilogue(A (M,K) W (N,K)^T + bias [gelu] [+ res]); variant selects a kernel configuration (0: dispatch) */
+int m3pc_debug_gemm(int dtype, const void* A, const void* Wt, const float* bias, const float* res, void* C, int M, int N,
+                    int K, int gelu, int f32out, int variant, void* stream);
+/* clock probes of the last probed GEMM workgroup: {shader clocks, 100-MHz ticks} / gemm_big phase timers */
+int m3pc_debug_clock(long long* out2);
+int m3pc_debug_clock_big(long long* out4);
+/* the top-k kernels on their own: indices of the k largest of v (n), descending, ties to the lower index */
+int m3pc_debug_topk(const float* v, int n, int k, int* idx_out, void* stream);
+/* the fused layer tail (block_fused.hip) on caller tensors; see csrc/m3pc.hip for the argument layout */
+long long m3pc_debug_block_stream_bytes(void);
+int m3pc_debug_block_fused(const void* O, int M, const float* res, const float* rowtab, int rt_mod, const void* Wo, const void* W1,
+                           const void* W2, void* stream_buf, int pack, const float* bo, const float* b1, const float* b2,
+                           const float* ln2_g, const float* ln2_b, const float* lnA_g, const float* lnA_b, const float* lnB_g0,
+                           const float* lnB_b0, const float* lnB_g1, const float* lnB_b1, int out_mod, int out_grp, float* Xout,
+                           void* Hout, int variant, void* stream, long long* stamps);
+/* the fused decoder input (kv_fused_kernel) on caller tensors */
+long long m3pc_debug_kv_stream_bytes(void);
+int m3pc_debug_kv_fused(const void* Z, int n, int Le, int kept0, int off0, int kept1, int off1, const void* We0, const void* We1,
+                        const void* Wkv, void* stream_buf, const float* rowtab0, const float* rowtab1, const float* ln_g,
+                        const float* ln_b, const float* bkv, void* KV, void* stream, long long* stamps);
+/* XCD / CU of every workgroup of a launch on `stream`: out[2 i] = XCC_ID, out[2 i + 1] = HW_ID */
+int m3pc_debug_xcc_probe(int* out, int n_blocks, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M3PC_HIP_DEBUG_H */

@@ -39,7 +39,7 @@ def _stale(target: str, deps) -> bool:
 def build_library(force: bool = False, verbose: bool = False, lab: bool = False) -> str:
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, n) for n in ("kernels.h", "gemm_epilogue.h", "gemm_stage_asm.h")] + \
-              [os.path.join(os.path.dirname(HERE), "include", "m3pc_hip.h")]
+              [os.path.join(os.path.dirname(HERE), "include", n) for n in ("m3pc_hip.h", "m3pc_hip_debug.h")]
     objdir = os.path.join(CSRC, "build_lab" if lab else "build")
     os.makedirs(objdir, exist_ok=True)
     flags = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",

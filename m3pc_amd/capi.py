@@ -21,13 +21,15 @@ KEYS = ("states", "actions", "rewards", "returns")
 MODE_RTG, MODE_CRITIC, MODE_NOISE = 0, 1, 2
 PREC_FP32, PREC_BF16 = 0, 1
 PROF_LAYER_TAIL = 16  # m3pc_profile_read: the fused layer-tail launches only
-ABI_VERSION = 1
+ABI_VERSION = 2
+SLOTS = 4  # M3PC_SLOTS: plan steps in flight per handle
 
 EXPORTS = (
-    "m3pc_last_error", "m3pc_abi_version", "m3pc_create", "m3pc_destroy", "m3pc_load_weights",
+    "m3pc_last_error", "m3pc_abi_version", "m3pc_create", "m3pc_destroy", "m3pc_load_weights", "m3pc_load_stats",
     "m3pc_set_tokenizer", "m3pc_set_critic", "m3pc_tokenize", "m3pc_detokenize", "m3pc_forward",
+    "m3pc_policy_pass", "m3pc_candidate_pass",
     "m3pc_plan_step", "m3pc_plan_step_batch", "m3pc_score_actions", "m3pc_rescore", "m3pc_rescore_topk", "m3pc_topk_window",
-    "m3pc_rescore_listed", "m3pc_select",
+    "m3pc_rescore_listed", "m3pc_rescore_merge", "m3pc_select",
     "m3pc_profile_enable",
     "m3pc_profile_read",
 )
@@ -36,7 +38,7 @@ EXPORTS = (
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "state_dim", "action_dim", "traj_length", "n_embd", "n_head", "n_enc_layer", "n_dec_layer",
-        "max_candidates", "max_batch", "critic_hidden")]
+        "max_candidates", "max_batch", "critic_hidden", "max_rescore")]
 
 
 class NamedTensor(C.Structure):
@@ -46,7 +48,7 @@ class NamedTensor(C.Structure):
 class PlanArgs(C.Structure):
     _fields_ = [("mode", C.c_int), ("precision", C.c_int), ("horizon", C.c_int), ("n_total", C.c_int),
                 ("n_begin", C.c_int), ("n_count", C.c_int), ("lmbda", C.c_double), ("discount", C.c_double),
-                ("rtg", C.c_double)]
+                ("rtg", C.c_double), ("slot", C.c_int), ("returns_f64", C.c_int), ("returns", C.c_void_p)]
 
 
 class M3pcError(RuntimeError):
@@ -74,17 +76,21 @@ def load_library(path: Optional[str] = None):
         "m3pc_create": [C.POINTER(Dims), i, C.POINTER(vp)],
         "m3pc_destroy": [vp],
         "m3pc_load_weights": [vp, C.POINTER(NamedTensor), i, vp],
+        "m3pc_load_stats": [vp, C.POINTER(ll)],
         "m3pc_set_tokenizer": [vp, i, C.POINTER(f), C.POINTER(f), i, i],
         "m3pc_set_critic": [vp, C.POINTER(NamedTensor), i, C.POINTER(f), C.POINTER(f), vp],
         "m3pc_tokenize": [vp, i, vp, i, vp, ll, vp],
         "m3pc_detokenize": [vp, i, vp, vp, ll, vp],
         "m3pc_forward": [vp, i, C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp, vp, i, vp],
+        "m3pc_policy_pass": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, vp],
+        "m3pc_candidate_pass": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_plan_step": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_plan_step_batch": [vp, C.POINTER(PlanArgs), i, vp, vp, vp, C.POINTER(d), vp, vp, vp, vp, vp, vp, vp],
         "m3pc_score_actions": [vp, C.POINTER(PlanArgs), i, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_rescore": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, i, vp, vp, vp],
         "m3pc_rescore_topk": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, i, vp, vp],
-        "m3pc_topk_window": [vp, vp, i, i, i, f, vp, vp, vp, f, vp],
+        "m3pc_topk_window": [vp, vp, i, i, i, f, vp, vp, vp, vp, f, vp],
+        "m3pc_rescore_merge": [vp, vp, i, vp, i, vp, vp, f, vp, vp, vp, f, vp],
         "m3pc_rescore_listed": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, i, vp, vp],
         "m3pc_select": [vp, vp, vp, ll, i, f, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_profile_enable": [vp, i],
@@ -126,17 +132,53 @@ def _named(sd: Dict[str, torch.Tensor]):
     return arr, keep
 
 
+class HostStats:
+    """A pinned, host-mapped float buffer a kernel writes its statistics to, followed (system scope, release) by a sequence
+    number at [4]: the host reads them by spinning on the sequence number -- visible a few microseconds after the kernel
+    ends, where a blocking device-to-host copy costs tens -- without synchronising a stream."""
+
+    def __init__(self):
+        self.buf = torch.zeros(8, dtype=torch.float32).pin_memory()
+        self.np = self.buf.numpy()
+        self.seq = 0
+
+    def next_seq(self) -> float:
+        self.seq = self.seq % 1000000 + 1
+        return float(self.seq)
+
+    def ready(self, seq: float) -> bool:
+        return self.np[4] == seq
+
+    def read(self):
+        hs = self.np
+        return [float(hs[0]), float(hs[1]), float(hs[2]), float(hs[3])]
+
+    def wait(self, seq: float, fallback: Optional[torch.Tensor] = None, timeout: float = 10.0):
+        import time as _t
+        hs = self.np
+        t0 = _t.perf_counter()
+        spins = 0
+        while hs[4] != seq:
+            spins += 1
+            if (spins & 1023) == 0 and _t.perf_counter() - t0 > timeout:  # never hang on the mapped buffer
+                if fallback is not None:
+                    return [float(x) for x in fallback.cpu()]
+                raise M3pcError("timed out waiting for kernel statistics in host-mapped memory")
+        return self.read()
+
+
 class Handle:
     """RAII wrapper of one m3pc_handle (one per process and GPU)."""
 
     def __init__(self, state_dim, action_dim, traj_length, n_embd=512, n_head=4, n_enc_layer=2, n_dec_layer=1,
-                 max_candidates=1024, max_batch=1, critic_hidden=256, device: int = 0):
+                 max_candidates=1024, max_batch=1, critic_hidden=256, device: int = 0, max_rescore: int = 64):
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise M3pcError("no HIP device visible: m3pc_amd runs only on a GPU (there is no CPU path)")
         self.device = torch.device("cuda", device)
         self.dims = Dims(state_dim, action_dim, traj_length, n_embd, n_head, n_enc_layer, n_dec_layer,
-                         max_candidates, max_batch, critic_hidden)
+                         max_candidates, max_batch, critic_hidden, max(int(max_rescore), 1))
+        self.max_rescore = max(int(max_rescore), 1)
         self._h = C.c_void_p()
         torch.cuda.init()
         with torch.cuda.device(self.device):
@@ -156,9 +198,16 @@ class Handle:
 
     # -- setup -------------------------------------------------------------------------------------
     def load_weights(self, state_dict: Dict[str, torch.Tensor]):
+        """All tensors (first call) or any subset of them (later calls: only what depends on them is re-derived)."""
         arr, keep = _named(state_dict)
         check(self.lib.m3pc_load_weights(self._h, arr, len(state_dict), _stream(self.device)))
         del keep
+
+    def load_stats(self):
+        """{tensors, tail_streams, kv_streams, tables_invalidated} of the last ``load_weights``."""
+        out = (C.c_longlong * 4)()
+        check(self.lib.m3pc_load_stats(self._h, out))
+        return dict(tensors=out[0], tail_streams=out[1], kv_streams=out[2], tables_invalidated=bool(out[3]))
 
     def set_tokenizer(self, key: int, mean, std, normalize: bool):
         m = torch.as_tensor(mean, dtype=torch.float32).contiguous().cpu().reshape(-1)
@@ -219,9 +268,61 @@ class Handle:
         return out
 
     # -- plan step ---------------------------------------------------------------------------------
+    @staticmethod
+    def _f32(t):
+        return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+
+    def _args(self, mode, precision, horizon, n_total, n_begin, n_count, lmbda, discount, rtg, slot=0, returns=None):
+        a = PlanArgs(mode, precision, horizon, n_total, n_begin, n_count, lmbda, discount, rtg, slot, 0, None)
+        if returns is not None:
+            assert returns.is_cuda and returns.is_contiguous() and returns.numel() == self.T
+            assert returns.dtype in (torch.float32, torch.float64)
+            a.returns_f64 = int(returns.dtype == torch.float64)
+            a.returns = returns.data_ptr()
+        return a
+
+    def policy_pass(self, mode: int, states, actions, rewards, horizon: int, rtg: float, slot: int = 0, returns=None,
+                    loc=None, std=None):
+        """PASS 1 of a plan step on the current stream (chain workspace): leaves the policy head in ``slot``.
+        returns: optional (T,) device row of raw returns (float32 / float64) instead of the constant ``rtg``."""
+        args = self._args(mode, PREC_FP32, horizon, 1, 0, 1, 0.0, 0.0, rtg, slot, returns)
+        check(self.lib.m3pc_policy_pass(self._h, C.byref(args), _ptr(self._f32(states)), _ptr(self._f32(actions)),
+                                        _ptr(self._f32(rewards)), _ptr(loc), _ptr(std), _stream(self.device)))
+
+    def candidate_pass(self, mode: int, states, actions, rewards, eps, horizon: int, lmbda: float, discount: float,
+                       n_total: int, n_begin: int = 0, n_count: Optional[int] = None, precision: int = PREC_FP32, slot: int = 0,
+                       want_debug: bool = False, out=None):
+        """Candidates + PASS 2 + scores of a plan step on the current stream (candidate workspace) from ``slot``'s policy
+        head.  ``out``: optional dict of preallocated loc / std / sample_actions / expect_return."""
+        n_count = n_total - n_begin if n_count is None else n_count
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        out = out or {}
+        loc = out.get("loc")
+        std = out.get("std")
+        if loc is None:
+            loc = torch.empty((self.T, self.A), **f32)
+            std = torch.empty((self.T, self.A), **f32)
+        acts = out.get("sample_actions")
+        if acts is None:
+            acts = torch.empty((n_count, horizon, self.A), **f32)
+        er = out.get("expect_return")
+        if er is None:
+            er = torch.empty((n_count,), **f32)
+        pr = torch.empty((n_count, horizon), **f32) if want_debug else None
+        pb = torch.empty((n_count, horizon), **f32) if want_debug else None
+        args = self._args(mode, precision, horizon, n_total, n_begin, n_count, lmbda, discount, 0.0, slot)
+        ins = [self._f32(t) for t in (states, actions, rewards, eps)]
+        check(self.lib.m3pc_candidate_pass(self._h, C.byref(args), _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), _ptr(ins[3]),
+                                           _ptr(loc), _ptr(std), _ptr(acts), _ptr(er), _ptr(pr), _ptr(pb), _stream(dev)))
+        res = dict(loc=loc, std=std, sample_actions=acts, expect_return=er)
+        if want_debug:
+            res["pred_rewards"], res["pred_boot"] = pr, pb
+        return res
+
     def plan_step(self, mode: int, states, actions, rewards, eps, horizon: int, rtg: float, lmbda: float,
                   discount: float, n_total: int, n_begin: int = 0, n_count: Optional[int] = None,
-                  precision: int = PREC_FP32, want_debug: bool = False):
+                  precision: int = PREC_FP32, want_debug: bool = False, slot: int = 0, returns=None):
         n_count = n_total - n_begin if n_count is None else n_count
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -231,8 +332,8 @@ class Handle:
         er = torch.empty((n_count,), **f32)
         pr = torch.empty((n_count, horizon), **f32) if want_debug else None
         pb = torch.empty((n_count, horizon), **f32) if want_debug else None
-        args = PlanArgs(mode, precision, horizon, n_total, n_begin, n_count, lmbda, discount, rtg)
-        ins = [t.to(torch.float32).contiguous() for t in (states, actions, rewards, eps)]
+        args = self._args(mode, precision, horizon, n_total, n_begin, n_count, lmbda, discount, rtg, slot, returns)
+        ins = [self._f32(t) for t in (states, actions, rewards, eps)]
         check(self.lib.m3pc_plan_step(self._h, C.byref(args), _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), _ptr(ins[3]),
                                       _ptr(loc), _ptr(std), _ptr(acts), _ptr(er), _ptr(pr), _ptr(pb), _stream(dev)))
         res = dict(loc=loc, std=std, sample_actions=acts, expect_return=er)
@@ -241,7 +342,7 @@ class Handle:
         return res
 
     def plan_step_batch(self, mode: int, states, actions, rewards, rtg, eps, horizon: int, lmbda: float, discount: float,
-                        n_total: int, precision: int = PREC_FP32):
+                        n_total: int, precision: int = PREC_FP32, slot: int = 0):
         """E windows x n_total candidates in one pass: states (E,T,S), actions (E,T,A), rewards (E,T,1), rtg (E,) floats,
         eps (E, n_total, T|h, A).  Returns expect_return (E, n_total), sample_actions (E, n_total, h, A), loc/std (E,T,A)."""
         E = states.shape[0]
@@ -252,8 +353,8 @@ class Handle:
         acts = torch.empty((E, n_total, horizon, self.A), **f32)
         er = torch.empty((E, n_total), **f32)
         widx = torch.arange(E, dtype=torch.int32, device=dev).repeat_interleave(n_total).contiguous()
-        args = PlanArgs(mode, precision, horizon, n_total, 0, n_total, lmbda, discount, 0.0)
-        ins = [t.to(torch.float32).contiguous() for t in (states, actions, rewards, eps)]
+        args = self._args(mode, precision, horizon, n_total, 0, n_total, lmbda, discount, 0.0, slot)
+        ins = [self._f32(t) for t in (states, actions, rewards, eps)]
         assert ins[3].numel() == E * n_total * (horizon if mode == MODE_NOISE else self.T) * self.A
         rt = (C.c_double * E)(*[float(v) for v in rtg])
         check(self.lib.m3pc_plan_step_batch(self._h, C.byref(args), E, _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), rt, _ptr(ins[3]),
@@ -266,85 +367,77 @@ class Handle:
         window_index (n,) int32 (None: one window)."""
         dev = self.device
         n = cand.shape[0]
-        ins = [t.to(torch.float32).contiguous() for t in (states, actions, rewards, cand)]
+        ins = [self._f32(t) for t in (states, actions, rewards, cand)]
         E = 1 if ins[0].dim() == 2 else ins[0].shape[0]
         er = torch.empty((n,), dtype=torch.float32, device=dev)
         pr = torch.empty((n, horizon), dtype=torch.float32, device=dev) if want_debug else None
         pb = torch.empty((n, horizon), dtype=torch.float32, device=dev) if want_debug else None
         wi = None if window_index is None else window_index.to(torch.int32).contiguous()
-        args = PlanArgs(mode, precision, horizon, n, 0, n, lmbda, discount, 0.0)
+        args = self._args(mode, precision, horizon, n, 0, n, lmbda, discount, 0.0)
         check(self.lib.m3pc_score_actions(self._h, C.byref(args), E, _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), _ptr(ins[3]),
                                           _ptr(wi), _ptr(er), _ptr(pr), _ptr(pb), _stream(dev)))
         return (er, pr, pb) if want_debug else er
 
     def rescore(self, mode: int, states, actions, rewards, eps, index: torch.Tensor, horizon: int, rtg: float,
-                lmbda: float, discount: float, n_total: int):
-        """fp32 scores (and candidates) of rows ``index`` (int32 cuda) of the last plan_step."""
+                lmbda: float, discount: float, n_total: int, slot: int = 0, out: Optional[torch.Tensor] = None, want_actions: bool = True):
+        """fp32 scores (and candidates) of rows ``index`` (int32 cuda) of the plan step that owns ``slot``.
+        ``out``: optional (n,) fp32 destination of the scores (a slice of a larger buffer is fine)."""
         n = index.numel()
         dev = self.device
-        acts = torch.empty((n, horizon, self.A), dtype=torch.float32, device=dev)
-        er = torch.empty((n,), dtype=torch.float32, device=dev)
-        args = PlanArgs(mode, PREC_FP32, horizon, n_total, 0, n, lmbda, discount, rtg)
-        ins = [t.to(torch.float32).contiguous() for t in (states, actions, rewards, eps)]
-        idx = index.to(torch.int32).contiguous()
+        acts = torch.empty((n, horizon, self.A), dtype=torch.float32, device=dev) if want_actions else None
+        er = out if out is not None else torch.empty((n,), dtype=torch.float32, device=dev)
+        assert er.numel() == n and er.is_contiguous() and er.dtype == torch.float32
+        args = self._args(mode, PREC_FP32, horizon, n_total, 0, n, lmbda, discount, rtg, slot)
+        ins = [self._f32(t) for t in (states, actions, rewards, eps)]
+        assert index.dtype == torch.int32 and index.is_contiguous()
         check(self.lib.m3pc_rescore(self._h, C.byref(args), _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), _ptr(ins[3]),
-                                    _ptr(idx), n, _ptr(acts), _ptr(er), _stream(dev)))
+                                    _ptr(index), n, _ptr(acts), _ptr(er), _stream(dev)))
         return er, acts
 
     def rescore_topk(self, mode: int, states, actions, rewards, eps, expect_return: torch.Tensor, k: int,
-                     horizon: int, rtg: float, lmbda: float, discount: float):
+                     horizon: int, rtg: float, lmbda: float, discount: float, slot: int = 0):
         """Replace the k largest entries of ``expect_return`` (all N candidates, contiguous fp32 cuda) by
         their fp32 re-scores, in place.  Returns the re-scored candidate ids (k,) int32."""
         n = expect_return.numel()
         assert expect_return.is_contiguous() and expect_return.dtype == torch.float32
         top = torch.empty((k,), dtype=torch.int32, device=self.device)
-        args = PlanArgs(mode, PREC_FP32, horizon, n, 0, n, lmbda, discount, rtg)
-        ins = [t.to(torch.float32).contiguous() for t in (states, actions, rewards, eps)]
+        args = self._args(mode, PREC_FP32, horizon, n, 0, n, lmbda, discount, rtg, slot)
+        ins = [self._f32(t) for t in (states, actions, rewards, eps)]
         check(self.lib.m3pc_rescore_topk(self._h, C.byref(args), _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]),
                                          _ptr(ins[3]), _ptr(expect_return), k, _ptr(top), _stream(self.device)))
         return top
 
-    def topk_window(self, expect_return: torch.Tensor, kmax: int, kmin: int, window: float):
+    def topk_window(self, expect_return: torch.Tensor, kmax: int, kmin: int, window: float, top: Optional[torch.Tensor] = None,
+                    stats: Optional[torch.Tensor] = None, top_scores: Optional[torch.Tensor] = None, host_stats=None, seq: float = 0.0):
         """The kmax + 1 best candidates (ids, best first) and stats = [n, margin to the best one outside the n, max, raw
-        count] where n = clamp(#{E >= max E - window}, kmin, kmax).  Both stay on the device."""
+        count over the whole vector] where n = clamp(#{E >= max E - window}, kmin, kmax).  Both stay on the device.
+        top_scores: optional (kmax + 1,) buffer receiving the listed scores; host_stats: optional pinned float tensor (>= 5)
+        the kernel also writes, followed by ``seq`` (see ``HostStats``)."""
         n = expect_return.numel()
         assert expect_return.is_contiguous() and expect_return.dtype == torch.float32
-        top = torch.empty((kmax + 1,), dtype=torch.int32, device=self.device)
-        stats = torch.empty((4,), dtype=torch.float32, device=self.device)
+        if top is None:
+            top = torch.empty((kmax + 1,), dtype=torch.int32, device=self.device)
+        if stats is None:
+            stats = torch.empty((4,), dtype=torch.float32, device=self.device)
         check(self.lib.m3pc_topk_window(self._h, _ptr(expect_return), n, kmax, kmin, float(window), _ptr(top), _ptr(stats),
-                                        None, 0.0, _stream(self.device)))
+                                        _ptr(top_scores), None if host_stats is None else C.c_void_p(host_stats.data_ptr()),
+                                        float(seq), _stream(self.device)))
         return top, stats
 
     def topk_window_issue(self, expect_return: torch.Tensor, kmax: int, kmin: int, window: float):
-        """Launch ``topk_window`` with its statistics also written to a pinned, host-mapped buffer followed by a sequence
-        number.  Returns (top ids on the device, ticket for ``topk_window_wait``); one ticket outstanding at a time."""
-        n = expect_return.numel()
+        """``topk_window`` with its statistics also written to a pinned, host-mapped buffer followed by a sequence number.
+        Returns (top ids on the device, ticket for ``topk_window_wait``); one ticket outstanding at a time."""
         if not hasattr(self, "_hs"):
-            self._hs = torch.zeros(8, dtype=torch.float32).pin_memory()
-            self._hs_np = self._hs.numpy()
-            self._hs_seq = 0
-        self._hs_seq = self._hs_seq % 1000000 + 1
-        seq = float(self._hs_seq)
-        top = torch.empty((kmax + 1,), dtype=torch.int32, device=self.device)
-        stats = torch.empty((4,), dtype=torch.float32, device=self.device)
-        check(self.lib.m3pc_topk_window(self._h, _ptr(expect_return), n, kmax, kmin, float(window), _ptr(top), _ptr(stats),
-                                        self._hs.data_ptr(), seq, _stream(self.device)))
+            self._hs = HostStats()
+        seq = self._hs.next_seq()
+        top, stats = self.topk_window(expect_return, kmax, kmin, window, host_stats=self._hs.buf, seq=seq)
         return top, (seq, stats)
 
     def topk_window_wait(self, ticket):
-        """The statistics of ``topk_window_issue`` on the host without a stream synchronisation: spins on the sequence
-        number in the mapped buffer (visible a few microseconds after the kernel ends, where a blocking device-to-host
-        copy costs tens).  [n, margin_outside, max, raw count] as python floats."""
-        import time as _t
+        """The statistics of ``topk_window_issue`` on the host without a stream synchronisation.
+        [n, margin_outside, max, raw count] as python floats."""
         seq, stats = ticket
-        hs = self._hs_np
-        t0 = _t.perf_counter()
-        spins = 0
-        while hs[4] != seq:
-            spins += 1
-            if (spins & 1023) == 0 and _t.perf_counter() - t0 > 0.25:  # never hang on the mapped buffer: the ordinary copy
-                return [float(x) for x in stats.cpu()]
-        return [float(hs[0]), float(hs[1]), float(hs[2]), float(hs[3])]
+        return self._hs.wait(seq, stats)
 
     def topk_window_host(self, expect_return: torch.Tensor, kmax: int, kmin: int, window: float):
         """``topk_window_issue`` + ``topk_window_wait``: (top ids on the device, statistics on the host)."""
@@ -352,33 +445,53 @@ class Handle:
         return top, self.topk_window_wait(ticket)
 
     def rescore_listed(self, mode: int, states, actions, rewards, eps, expect_return: torch.Tensor, index: torch.Tensor,
-                       horizon: int, rtg: float, lmbda: float, discount: float):
+                       horizon: int, rtg: float, lmbda: float, discount: float, slot: int = 0):
         """Replace the entries ``index`` (int32 cuda) of ``expect_return`` by their fp32 re-scores, in place."""
         n = expect_return.numel()
         assert index.dtype == torch.int32 and index.is_contiguous() and expect_return.is_contiguous()
-        args = PlanArgs(mode, PREC_FP32, horizon, n, 0, n, lmbda, discount, rtg)
-        ins = [t.to(torch.float32).contiguous() for t in (states, actions, rewards, eps)]
+        args = self._args(mode, PREC_FP32, horizon, n, 0, n, lmbda, discount, rtg, slot)
+        ins = [self._f32(t) for t in (states, actions, rewards, eps)]
         check(self.lib.m3pc_rescore_listed(self._h, C.byref(args), _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), _ptr(ins[3]),
                                            _ptr(index), index.numel(), _ptr(expect_return), _stream(self.device)))
 
+    def rescore_merge(self, scores: torch.Tensor, index: torch.Tensor, n: int, top_scores: torch.Tensor, top_rescored: torch.Tensor,
+                      delta: float = 0.0, merged: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, host_stats=None,
+                      seq: float = 0.0):
+        """merged = scores - median(top_scores[:n] - top_rescored[:n]), entries index[:n] replaced by top_rescored[:n];
+        stats = [shift, largest deviation from it, need = #{scores > best fp32 + shift - delta}, margin].  See m3pc_rescore_merge."""
+        assert scores.is_contiguous() and scores.dtype == torch.float32 and index.dtype == torch.int32
+        if merged is None:
+            merged = torch.empty_like(scores)
+        if stats is None:
+            stats = torch.empty((4,), dtype=torch.float32, device=self.device)
+        check(self.lib.m3pc_rescore_merge(self._h, _ptr(scores), scores.numel(), _ptr(index), int(n), _ptr(top_scores),
+                                          _ptr(top_rescored), float(delta), _ptr(merged), _ptr(stats),
+                                          None if host_stats is None else C.c_void_p(host_stats.data_ptr()), float(seq),
+                                          _stream(self.device)))
+        return merged, stats
+
+    def select_buffers(self, n: int):
+        """Output tensors of ``select`` (p, eval_action, argmax, sample_idx, sample_action), allocated on the current stream."""
+        dev = self.device
+        return (torch.empty((n,), dtype=torch.float32, device=dev), torch.empty((self.A,), dtype=torch.float32, device=dev),
+                torch.empty((1,), dtype=torch.int32, device=dev), torch.empty((1,), dtype=torch.int32, device=dev),
+                torch.empty((1, self.A), dtype=torch.float32, device=dev))
+
     def select(self, expect_return: torch.Tensor, a0: torch.Tensor, temperature: float,
-               expo: Optional[torch.Tensor] = None):
+               expo: Optional[torch.Tensor] = None, out=None):
         """a0: (N, A) view (may be a strided slice sample_actions[:, 0]).  Returns (p, eval_action, argmax)
-        and, when ``expo`` (N Exp(1) variates) is given, also (sample_idx, sample_action (1, A))."""
+        and, when ``expo`` (N Exp(1) variates) is given, also (sample_idx, sample_action (1, A)).
+        out: optional ``select_buffers(n)`` tuple to write into."""
         n = expect_return.numel()
         assert a0.shape[0] == n and a0.stride(-1) == 1
-        dev = self.device
-        p = torch.empty((n,), dtype=torch.float32, device=dev)
-        ev = torch.empty((self.A,), dtype=torch.float32, device=dev)
-        am = torch.empty((1,), dtype=torch.int32, device=dev)
-        si = sa = None
-        if expo is not None:
+        p, ev, am, si, sa = out if out is not None else self.select_buffers(n)
+        if expo is None:
+            si = sa = None
+        else:
             assert expo.numel() == n and expo.dtype == torch.float32 and expo.is_contiguous()
-            si = torch.empty((1,), dtype=torch.int32, device=dev)
-            sa = torch.empty((1, self.A), dtype=torch.float32, device=dev)
         check(self.lib.m3pc_select(self._h, _ptr(expect_return.contiguous()), _ptr(a0), a0.stride(0), n,
                                    float(temperature), _ptr(expo), _ptr(p), _ptr(ev), _ptr(am), _ptr(si), _ptr(sa),
-                                   _stream(dev)))
+                                   _stream(self.device)))
         if expo is None:
             return p, ev, am
         return p, ev, am, si, sa

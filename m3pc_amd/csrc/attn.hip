@@ -484,9 +484,9 @@ template <typename T, int HDT>
 static void launch_hd(const AttnP& p, hipStream_t st) {
     const int Lk = p.L1 + p.L2;
     const int qgroups = (p.Lq + 127) / 128;
-    static const bool no_split = getenv("M3PC_NO_ATTN_SPLIT") != nullptr;  // A/B switch
+    static const bool no_split = M3PC_ENV("M3PC_NO_ATTN_SPLIT") != nullptr;  // A/B switch
     if (Lk <= 256 && (long long)p.batch * p.n_head * qgroups <= 64 && !no_split) {
-        static const bool no_pair = getenv("M3PC_NO_ATTN_PAIR") != nullptr;  // A/B switch
+        static const bool no_pair = M3PC_ENV("M3PC_NO_ATTN_PAIR") != nullptr;  // A/B switch
         if constexpr (HDT == 4) {  // (each wave owns one 32-wide slice of the output: four waves = head dim 128)
             if (Lk <= 64 && !no_pair) {
                 dim3 grid(p.batch, p.n_head, (p.Lq + 31) / 32), block(256);

@@ -413,7 +413,7 @@ static void launch_hd(const AttnP& p, hipStream_t st) {
     const int rows = nw * 32 > 64 ? nw * 32 : 64;
     const size_t smem = (size_t)rows * (HDT * 64 + 16) + 512;  // + per-query weights of the pre-reduced block
     dim3 grid(p.batch, p.n_head, qgroups), block(nw * 64);
-    static const bool no_direct = getenv("M3PC_NO_ATTN_DIRECT") != nullptr;  // A/B switch
+    static const bool no_direct = M3PC_ENV("M3PC_NO_ATTN_DIRECT") != nullptr;  // A/B switch
     if (Lk <= 64 && !no_direct) {
         if (slots <= 32)
             launch_direct<HDT, 1, 2>(p, slots, st);

@@ -467,7 +467,7 @@ static void launch_ln_rows(const LnP& p, hipStream_t st) {
 void launch_layernorm(const LnP& p, hipStream_t st) {
     if (p.rows <= 0) return;
     if (p.d % 256 == 0 && p.d <= 1024 && p.ldx % 4 == 0 && p.rows >= 8192) {
-        static const int rpw = getenv("M3PC_LN_RPW") ? atoi(getenv("M3PC_LN_RPW")) : 2;  // 1 = the one-row kernel below
+        static const int rpw = M3PC_ENV("M3PC_LN_RPW") ? atoi(M3PC_ENV("M3PC_LN_RPW")) : 2;  // 1 = the one-row kernel below
         if (rpw == 4) return launch_ln_rows<4>(p, st);
         if (rpw == 2) return launch_ln_rows<2>(p, st);
     }
@@ -758,6 +758,32 @@ __global__ __launch_bounds__(256) void fill_kernel(float* out, float value, long
 void launch_fill(float* out, float value, long long n, hipStream_t st) {
     if (n <= 0) return;
     hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, st, out, value, n);
+}
+
+// Derived weight tables (m3pc_load_weights), computed on the device so that a weight update costs no host round trip:
+//   transpose: out[j * rows + c] = in[c * cols + j]   (encoder_embed weight (d, D_k) -> (D_k, d))
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* in, float* out, int rows, int cols) {
+    const long long n = (long long)rows * cols;
+    for (long long x = blockIdx.x * (long long)blockDim.x + threadIdx.x; x < n; x += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(x / cols), j = (int)(x % cols);
+        out[(long long)j * rows + c] = in[x];
+    }
+}
+void launch_transpose_f32(const float* in, float* out, int rows, int cols, hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return;
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3(grid_for((long long)rows * cols)), dim3(256), 0, st, in, out, rows, cols);
+}
+//   embedding table: out[t, c] = (bias[c] + per_dim[c]) + pos[t, c]   (mtm_model.py:549-553 / 653-657; this association)
+__global__ __launch_bounds__(256) void embed_table_kernel(const float* bias, const float* per_dim, const float* pos, float* out, int T,
+                                                          int d) {
+    const long long n = (long long)T * d;
+    for (long long x = blockIdx.x * (long long)blockDim.x + threadIdx.x; x < n; x += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(x % d);
+        out[x] = (bias[c] + per_dim[c]) + pos[x];
+    }
+}
+void launch_embed_table(const float* bias, const float* per_dim, const float* pos, float* out, int T, int d, hipStream_t st) {
+    hipLaunchKernelGGL(embed_table_kernel, dim3(grid_for((long long)T * d)), dim3(256), 0, st, bias, per_dim, pos, out, T, d);
 }
 
 }  // namespace m3pc

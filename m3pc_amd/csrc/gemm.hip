@@ -380,14 +380,14 @@ int launch_gemm(const GemmP& p, int dtype, hipStream_t st) {
     // long-K many-row problems (this step's FFN2, K = 2048): 256x256 tiles at one wave per SIMD (gemm_big.hip).  Same
     // MFMA instruction, k order and epilogue arithmetic as the 128x128 ring kernel, so results are bit-identical and the
     // choice may depend on the row count.  It needs about one tile per CU to pay (one workgroup per CU, no overlap).
-    static const bool no_big = getenv("M3PC_NO_GEMM_BIG") != nullptr;  // A/B switch
+    static const bool no_big = M3PC_ENV("M3PC_NO_GEMM_BIG") != nullptr;  // A/B switch
     if (dtype == DT_BF16 && p.variant >= 37 && p.variant <= 42 && launch_gemm_big(p, st)) return 0;
     if (dtype == DT_BF16 && p.variant >= 43 && p.variant <= 46 && launch_gemm_line(p, p.variant == 44 ? 256 : 128, st)) return 0;
     // K = 512-class many-row problems without a residual stream: 128x128 tiles fed by whole-cache-line DMA pieces through
     // a five-unit ring, persistent workgroups (gemm_line.hip).  The residual GEMMs of this class are HBM-bound and stay
     // on the three-slot ring kernel, as do output row maps / row tables.
-    static const bool no_line = getenv("M3PC_NO_GEMM_LINE") != nullptr;  // A/B switch
-    static const long long line_min = getenv("M3PC_LINE_MIN_TILES") ? atoll(getenv("M3PC_LINE_MIN_TILES")) : 256;  // (one tile per CU at least: the head GEMMs of a candidate half, 256 tiles, take 12-15 us here against 22-26)
+    static const bool no_line = M3PC_ENV("M3PC_NO_GEMM_LINE") != nullptr;  // A/B switch
+    static const long long line_min = M3PC_ENV("M3PC_LINE_MIN_TILES") ? atoll(M3PC_ENV("M3PC_LINE_MIN_TILES")) : 256;  // (one tile per CU at least: the head GEMMs of a candidate half, 256 tiles, take 12-15 us here against 22-26)
     if (dtype == DT_BF16 && p.variant == 0 && !no_line && !p.res && p.K < 1024 &&
         (long long)((p.M + 127) / 128) * (p.N / 128) >= line_min && launch_gemm_line(p, 128, st))
         return 0;
@@ -403,7 +403,7 @@ int launch_gemm(const GemmP& p, int dtype, hipStream_t st) {
     if (dtype == DT_BF16) return launch_t<bf16_t>(p, st);
     // few-row fp32 GEMMs: K split inside a 16-wave workgroup, one launch (only where split-K is allowed at all, i.e.
     // where every rank runs the same row count: p.ws is set exactly then).  variant 2 keeps the slab path for A/B runs.
-    static const bool no_direct = getenv("M3PC_NO_F32_DIRECT") != nullptr;  // A/B switch
+    static const bool no_direct = M3PC_ENV("M3PC_NO_F32_DIRECT") != nullptr;  // A/B switch
     if (p.ws && p.variant != 2 && !no_direct && launch_gemm_f32_direct(p, st)) return 0;
     return launch_t<float>(p, st);
 }

@@ -181,7 +181,7 @@ bool gemm_f32_direct_covers(const GemmP& p) {
     // LayerNorm that follows).
     // 200: with the bound-driven re-score at its usual 8 candidates (392 rows) the Q|K|V projection (168 tiles) is 3 us faster
     // here, FFN1 (224 tiles) is not: step -15 us against a limit of 128 (M3PC_DIRECT_TILES re-measures).
-    static const long long max_tiles = getenv("M3PC_DIRECT_TILES") ? atoll(getenv("M3PC_DIRECT_TILES")) : 200;
+    static const long long max_tiles = M3PC_ENV("M3PC_DIRECT_TILES") ? atoll(M3PC_ENV("M3PC_DIRECT_TILES")) : 200;
     if (p.K > 512 || tiles64 >= max_tiles) return false;
     if (p.N % 32 != 0 || p.K % (16 * 32) != 0) return false;
     if (p.a_ln_g && (!p.a_ln_b || p.K % 256 != 0 || p.K > 2048 || ((uintptr_t)p.a_ln_g & 15) || ((uintptr_t)p.a_ln_b & 15))) return false;

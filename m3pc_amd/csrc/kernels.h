@@ -3,6 +3,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Environment A/B switches (M3PC_NO_*, M3PC_GEMM_VARIANT, ...) exist in the LAB build only (libm3pc_hip_lab.so,
+// `python -m m3pc_amd.build --lab`): the product library never reads the environment.
+#ifdef M3PC_LAB
+#define M3PC_ENV(name) getenv(name)
+#else
+#define M3PC_ENV(name) ((const char*)nullptr)
+#endif
+
 namespace m3pc {
 
 typedef __bf16 bf16_t;
@@ -328,9 +336,14 @@ void launch_select(const SelectP& p, hipStream_t st);
 
 // indices of the k largest values (descending; ties -> lower index first), n <= 16384, k <= n
 void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st);
-// re-score window statistics over the kk best entries idx (best first); stats = {n, margin to the best entry outside, max, raw count}
-void launch_window_stats(const float* v, const int* idx, int kk, int kmin, int kmax, float window, float* stats, float* host_stats,
-                         float seq, hipStream_t st);
+// re-score window statistics: idx = the kk best entries of v (best first); stats = {n, margin to the best entry outside the n,
+// max, raw count over all n_total entries}; top_scores (optional, kk) = v[idx[i]]
+void launch_window_stats(const float* v, int n_total, const int* idx, int kk, int kmin, int kmax, float window, float* stats,
+                         float* host_stats, float seq, float* top_scores, hipStream_t st);
+// out = b - median(b_top - f_top), listed entries replaced by their fp32 re-scores;
+// stats = {shift, max deviation, #{b > best listed fp32 + shift - delta}, margin of that threshold over the best un-listed b}
+void launch_rescore_merge(const float* b, int n_total, const int* idx, int n, const float* b_top, const float* f_top, float delta,
+                          float* out, float* stats, float* host_stats, float seq, hipStream_t st);
 // dst[index[i]] = src[i]
 void launch_scatter(const float* src, const int* index, int n, float* dst, int* index_copy, hipStream_t st);  // + index_copy[i] = index[i]
 
@@ -340,5 +353,7 @@ void launch_detokenize(const float* in, float* out, long long rows, int D, const
                        int normalize, hipStream_t st);
 void launch_f32_to_bf16(const float* in, bf16_t* out, long long n, hipStream_t st);
 void launch_fill(float* out, float value, long long n, hipStream_t st);
+void launch_transpose_f32(const float* in, float* out, int rows, int cols, hipStream_t st);  // out (cols, rows) = in (rows, cols)^T
+void launch_embed_table(const float* bias, const float* per_dim, const float* pos, float* out, int T, int d, hipStream_t st);
 
 }  // namespace m3pc

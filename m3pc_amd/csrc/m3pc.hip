@@ -23,6 +23,9 @@
 #include <vector>
 
 #include "../../include/m3pc_hip.h"
+#ifdef M3PC_LAB
+#include "../../include/m3pc_hip_debug.h"
+#endif
 #include "kernels.h"
 
 using namespace m3pc;
@@ -105,6 +108,7 @@ struct m3pc_handle {
     int d = 0, nh = 0, hd = 0, T = 0, S = 0, A = 0, ff = 0, feat[4] = {0, 0, 0, 0};
     std::map<std::string, Tensor> w;
     bool weights_loaded = false;
+    long long load_stats[4] = {0, 0, 0, 0};  // last m3pc_load_weights: tensors copied, layer-tail streams packed, kv streams packed, tables invalidated
     // derived tables
     float* WT[4] = {nullptr, nullptr, nullptr, nullptr};
     float* Eenc[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -129,16 +133,32 @@ struct m3pc_handle {
     float* sel_scratch = nullptr;
     int* d_topk = nullptr;        // (1024,) candidate ids of the last top-k
     float* er_top = nullptr;      // (1024,) their fp32 re-scores
-    float* sa_buf = nullptr;      // (max_candidates, T, A) scratch for m3pc_rescore
+    float* sa_buf = nullptr;      // (max(max_candidates, max_rescore), h, A) scratch for m3pc_rescore
     float* splitk_ws = nullptr;   // raw split-K slabs of the few-row fp32 GEMMs
     long long splitk_ws_bytes = 0;
-    bool policy_valid = false;    // loc/sd/rtok hold the last plan_step's policy pass
-    // two-stream candidate halves: the workspace pointers above are VIEWS that set_view() re-bases per half
+    // Step slots: the per-step state a plan step leaves behind its policy pass (loc / sd of the policy head, the normalised
+    // returns tokens).  A pipelined caller (m3pc_policy_pass of step t+1 on one stream beside m3pc_candidate_pass of step t on
+    // another, the fp32 re-score of step t after it) gives every step in flight its own slot (m3pc_plan_args::slot);
+    // loc / sd / rtok above are VIEWS of the slot bound last (bind_slot).
+    struct Slot {
+        float *loc = nullptr, *sd = nullptr, *rtok = nullptr;
+        bool policy_valid = false;  // loc / sd / rtok hold a single-window policy pass (what m3pc_rescore needs)
+    } slot[M3PC_SLOTS];
+    int cur_slot = 0;
+    // Workspaces.  The pointers above (X ... splitk_ws) are VIEWS of the workspace bound last (bind_ws), re-based per candidate
+    // half by set_view().  `base` is the candidate workspace (max_candidates); the few-row fp32 chains run in two small ones of
+    // their own -- `pchain` the policy pass (batch <= max_batch), `chain` the re-score (<= max_rescore candidates) -- so that a
+    // policy pass, a re-score and a candidate pass of three different steps can be enqueued on three streams at the same time
+    // without sharing a buffer.
     struct Base {
-        float *X, *Y, *EncOut, *G, *cand, *pred[2], *qv, *splitk_ws;
-        char *Hn, *QKV, *O, *F, *Z;
-        long long splitk_ws_bytes;
-    } base;
+        float *X = nullptr, *Y = nullptr, *EncOut = nullptr, *G = nullptr, *cand = nullptr, *pred[2] = {nullptr, nullptr},
+              *qv = nullptr, *splitk_ws = nullptr;
+        char *Hn = nullptr, *QKV = nullptr, *O = nullptr, *F = nullptr, *Z = nullptr;
+        long long splitk_ws_bytes = 0;
+        long long R = 0;       // token rows
+        int max_cand = 0;      // candidates (rows of cand / pred / qv)
+    } base, chain, pchain;
+    Base* cur = nullptr;
     bool two_stream = true;       // candidate halves on two streams (M3PC_TWO_STREAM=0: one stream); measured -2.5 % step time on C2
     bool allow_splitk = true;     // see gemm(): off while sharded candidates are scored
     hipStream_t aux = nullptr;
@@ -149,6 +169,7 @@ struct m3pc_handle {
     std::vector<hipEvent_t> ev_joins;
     std::vector<int> stream_split;
     std::map<std::string, std::unique_ptr<Plan>> plans;
+    Plan* mask_plan[2][65] = {};  // get_mask_plan cache: [rcbc | fd][idx]
     // packed MFMA-fragment weight streams of the fused layer tails (block_fused.hip), by block prefix
     std::map<std::string, bf16_t*> wstream;
     // packed streams of the fused decoder input (kv_fused_kernel), by key: embedding of key k + K|V rows of decoder layer 0
@@ -178,7 +199,7 @@ int check_launch(const char* what) {
 // Re-base the workspace views at candidate c0 (each candidate owns 2T workspace rows).
 void set_view(m3pc_handle* h, int c0, int /*n*/) {
     const size_t rows = (size_t)c0 * 2 * h->T, d = (size_t)h->d;
-    const m3pc_handle::Base& b = h->base;
+    const m3pc_handle::Base& b = *h->cur;
     h->X = b.X + rows * d;
     h->Y = b.Y + rows * d;
     h->EncOut = b.EncOut + rows * d;
@@ -195,6 +216,55 @@ void set_view(m3pc_handle* h, int c0, int /*n*/) {
     const long long half = b.splitk_ws_bytes / 2;
     h->splitk_ws = c0 == 0 ? b.splitk_ws : b.splitk_ws + half / 4;
     h->splitk_ws_bytes = half;
+}
+
+// Bind a workspace (the candidate one or the chain one): every launcher below reads the views.  Host-side state only: what
+// was enqueued before keeps the pointers it was enqueued with.
+void bind_ws(m3pc_handle* h, m3pc_handle::Base* b) {
+    h->cur = b;
+    h->R = b->R;
+    set_view(h, 0, b->max_cand);
+}
+struct WsScope {  // binds a chain workspace for the duration of a few-row fp32 pass
+    m3pc_handle* h;
+    WsScope(m3pc_handle* h_, bool chain, bool policy = false) : h(h_) {
+        if (chain) bind_ws(h, policy ? &h->pchain : &h->chain);
+    }
+    ~WsScope() { bind_ws(h, &h->base); }
+};
+void bind_slot(m3pc_handle* h, int s) {
+    h->cur_slot = s;
+    h->loc = h->slot[s].loc;
+    h->sd = h->slot[s].sd;
+    h->rtok = h->slot[s].rtok;
+}
+
+int alloc_ws(m3pc_handle* h, m3pc_handle::Base& b, long long R_, int max_cand, long long splitk_bytes) {
+    const size_t R = (size_t)R_, d = (size_t)h->d, T = (size_t)h->T;
+    b.R = R_;
+    b.max_cand = max_cand;
+    CHK(dmalloc(&b.X, R * d));
+    CHK(dmalloc(&b.Y, R * d));
+    CHK(dmalloc(&b.EncOut, R * d));
+    CHK(dmalloc(&b.G, R * d));
+    CHK(dmalloc((float**)&b.Hn, R * d));
+    CHK(dmalloc((float**)&b.QKV, R * 3 * d));
+    CHK(dmalloc((float**)&b.O, R * d));
+    CHK(dmalloc((float**)&b.F, R * 4 * d));
+    CHK(dmalloc((float**)&b.Z, R * d));
+    CHK(dmalloc(&b.cand, (size_t)max_cand * T * h->A));
+    CHK(dmalloc(&b.pred[0], (size_t)max_cand * T * 32));
+    CHK(dmalloc(&b.pred[1], (size_t)max_cand * T * 32));
+    CHK(dmalloc(&b.qv, (size_t)max_cand * T));
+    b.splitk_ws_bytes = splitk_bytes;
+    CHK(dmalloc(&b.splitk_ws, (size_t)(splitk_bytes / 4)));
+    return 0;
+}
+void free_ws(m3pc_handle::Base& b) {
+    void* bufs[] = {b.X, b.Y, b.EncOut, b.G, b.Hn, b.QKV, b.O, b.F, b.Z, b.cand, b.pred[0], b.pred[1], b.qv, b.splitk_ws};
+    for (void* p : bufs)
+        if (p) hipFree(p);
+    b = m3pc_handle::Base();
 }
 
 Tensor& W(m3pc_handle* h, const std::string& n) { return h->w.at(n); }
@@ -290,7 +360,7 @@ int gemm(m3pc_handle* h, const GemmP& p_in, int dt, hipStream_t st) {
     p.ws = h->allow_splitk ? h->splitk_ws : nullptr;
     p.ws_bytes = h->splitk_ws_bytes;
 #ifdef M3PC_LAB  // (the lab build only: an environment variable must not change which kernels the product runs)
-    static const int env_variant = getenv("M3PC_GEMM_VARIANT") ? atoi(getenv("M3PC_GEMM_VARIANT")) : 0;  // A/B runs
+    static const int env_variant = M3PC_ENV("M3PC_GEMM_VARIANT") ? atoi(M3PC_ENV("M3PC_GEMM_VARIANT")) : 0;  // A/B runs
     if (env_variant) p.variant = env_variant;
 #endif
     GemmTimer t(h, st, 2.0 * p.M * (double)p.N * p.K, dt);
@@ -303,8 +373,8 @@ int gemm(m3pc_handle* h, const GemmP& p_in, int dt, hipStream_t st) {
 // took 11-12 -- every workgroup recomputes its rows' statistics behind a barrier before its K loop starts, which costs what
 // the launch cost.  Neutral, so OFF by default (M3PC_LN_FOLD=1 turns it on for A/B runs); the GPU tests pass either way.
 bool can_fold_ln(m3pc_handle* h, const GemmP& p, int dt) {
-    static const bool on = getenv("M3PC_LN_FOLD") != nullptr && getenv("M3PC_NO_F32_DIRECT") == nullptr &&
-                           getenv("M3PC_GEMM_VARIANT") == nullptr;  // A/B switch
+    static const bool on = M3PC_ENV("M3PC_LN_FOLD") != nullptr && M3PC_ENV("M3PC_NO_F32_DIRECT") == nullptr &&
+                           M3PC_ENV("M3PC_GEMM_VARIANT") == nullptr;  // A/B switch
     return dt == DT_F32 && on && h->allow_splitk && h->splitk_ws && gemm_f32_direct_covers(p);
 }
 
@@ -385,6 +455,26 @@ int get_plan(m3pc_handle* h, const unsigned char* const masks[4], Plan** out) {
         HIPCHK(hipMemcpy(pl->d_masked_rowsrc, masked_rowsrc.data(), masked_rowsrc.size() * sizeof(int), hipMemcpyHostToDevice));
     *out = pl.get();
     h->plans[key] = std::move(pl);
+    return 0;
+}
+
+// The two deterministic test-time masks of a plan step, cached per (kind, idx): kind 0 = rcbc (finetune_omtm/masks.py:7-27:
+// states[:idx+1], actions[:idx], all returns), kind 1 = fd (masks.py:30-44: states[:idx+1], all actions).  No host-side mask
+// work after the first call with a given idx.
+int get_mask_plan(m3pc_handle* h, int kind, int idx, Plan** out) {
+    Plan*& slot = h->mask_plan[kind][idx];
+    if (!slot) {
+        const int T = h->T;
+        std::vector<unsigned char> m[4];
+        for (int k = 0; k < 4; ++k) m[k].assign(T, 0);
+        for (int t = 0; t <= idx && t < T; ++t) m[M3PC_STATES][t] = 1;
+        for (int t = 0; t < (kind == 0 ? idx : T); ++t) m[M3PC_ACTIONS][t] = 1;
+        if (kind == 0)
+            for (int t = 0; t < T; ++t) m[M3PC_RETURNS][t] = 1;
+        const unsigned char* mp[4] = {m[0].data(), m[1].data(), m[2].data(), m[3].data()};
+        CHK(get_plan(h, mp, &slot));
+    }
+    *out = slot;
     return 0;
 }
 
@@ -523,7 +613,7 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
     }
     }
     // many-row bf16 passes: everything after the attention is one launch (block_fused.hip)
-    static const bool no_fused = getenv("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
+    static const bool no_fused = M3PC_ENV("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
     if (dt == DT_BF16 && !no_fused && rows >= 512 && h->wstream.count(pfx)) {
         BlockP b;
         memset(&b, 0, sizeof(b));
@@ -623,7 +713,7 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
                 int n_indep = 0, int layer_from = 0, int layer_to = 1 << 30, bool* ln_state = nullptr) {
     // first-layer pruning (run_block): whole 32-query tiles of shared tokens, bf16 candidate passes only
     int n_sh = 0;
-    static const bool no_prune1 = getenv("M3PC_NO_PRUNE1") != nullptr;  // A/B switch
+    static const bool no_prune1 = M3PC_ENV("M3PC_NO_PRUNE1") != nullptr;  // A/B switch
     if (dt == DT_BF16 && batch >= 64 && h->d % 256 == 0 && h->d <= 1024 && n_indep >= 32 && !no_prune1)
         n_sh = (n_indep / 32) * 32;
     EmbedP e;
@@ -646,7 +736,7 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
     // them there and writes the layer output to Y, which carries the stream through the remaining layers
     // (M3PC_SHARED_RES=1; measured on C2: embedding 33 -> 15 us, but every tile of the fused kernel then reads the same 66 KiB
     // and the step is 0.4 % SLOWER -- off)
-    static const bool shared_res_on = getenv("M3PC_SHARED_RES") != nullptr && getenv("M3PC_NO_BLOCK_FUSED") == nullptr;
+    static const bool shared_res_on = M3PC_ENV("M3PC_SHARED_RES") != nullptr && M3PC_ENV("M3PC_NO_BLOCK_FUSED") == nullptr;
     const bool shared_res = n_sh > 0 && shared_res_on && (long long)batch * pl->Le >= 512 && h->wstream.count("encoder.layers.0") &&
                             bf16_out_only;
     e.x_first_only = shared_res ? 1 : 0;
@@ -721,8 +811,8 @@ void dec_embed(m3pc_handle* h, int k, const void* Zop, RowMap amap, float* Yout,
 int run_decoder_full(m3pc_handle* h, const void* Zop, int batch, int dt, hipStream_t st) {
     const int T = h->T, d = h->d;
     bool grouped = false;
-    static const bool no_group = getenv("M3PC_NO_GEMM_GROUP") != nullptr || getenv("M3PC_NO_F32_DIRECT") != nullptr ||
-                                 getenv("M3PC_GEMM_VARIANT") != nullptr;  // A/B switches
+    static const bool no_group = M3PC_ENV("M3PC_NO_GEMM_GROUP") != nullptr || M3PC_ENV("M3PC_NO_F32_DIRECT") != nullptr ||
+                                 M3PC_ENV("M3PC_GEMM_VARIANT") != nullptr;  // A/B switches
     if (dt == DT_F32 && !no_group && h->allow_splitk) {  // few-row fp32 pass: the four modality GEMMs as one launch
         GemmP ps[4];
         for (int k = 0; k < 4; ++k) {
@@ -965,7 +1055,7 @@ int build_tables(m3pc_handle* h, Plan* pl, int qi, int dt, hipStream_t st) {
     g.out = tb.Yq;
     g.outb = nullptr;
     launch_gather_rows(g, st);
-    static const bool no_prestats = getenv("M3PC_NO_PRESTATS") != nullptr;  // A/B switch
+    static const bool no_prestats = M3PC_ENV("M3PC_NO_PRESTATS") != nullptr;  // A/B switch
     if (dt == DT_BF16 && q.all_masked && pl->Lm > 0 && pl->Lm <= 256 && !no_prestats) {
         // queries and masked-token keys are both candidate-independent: reduce that block of the softmax once
         if (!tb.pre_m) {
@@ -1004,13 +1094,8 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
                    hipStream_t st, const int* widx = nullptr, int stage_from = 0, int stage_to = 1 << 30, bool* ln_state = nullptr) {
     const int T = h->T, d = h->d, hh = a->horizon, idx = T - hh;
     const size_t es = dtype_size(dt);
-    std::vector<unsigned char> m[4];
-    for (int k = 0; k < 4; ++k) m[k].assign(T, 0);
-    for (int t = 0; t <= idx; ++t) m[M3PC_STATES][t] = 1;
-    for (int t = 0; t < T; ++t) m[M3PC_ACTIONS][t] = 1;
-    const unsigned char* mp[4] = {m[0].data(), m[1].data(), m[2].data(), m[3].data()};
     Plan* pl = nullptr;
-    CHK(get_plan(h, mp, &pl));  // fd mask (finetune_omtm/masks.py:30-44)
+    CHK(get_mask_plan(h, 1, idx, &pl));  // fd mask (finetune_omtm/masks.py:30-44)
     const int qi = a->mode == M3PC_MODE_RTG ? 0 : 1;
     CHK(build_query(h, pl, qi, hh));
     CHK(build_tables(h, pl, qi, dt, st));
@@ -1053,7 +1138,7 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     else
         ln.Yf = (float*)h->Hn;
     bool kv_done = false;
-    static const bool no_kv_fused = getenv("M3PC_NO_KV_FUSED") != nullptr || getenv("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
+    static const bool no_kv_fused = M3PC_ENV("M3PC_NO_KV_FUSED") != nullptr || M3PC_ENV("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
     if (dt == DT_BF16 && !no_kv_fused && q.all_masked && (long long)n * Le >= 512 && h->kvstream[0] && (pl->kept[0] || pl->kept[1])) {
         // embedding, norm1 and the K|V projection in one launch (kv_fused_kernel): the fp32 rows Y are consumed by nothing
         // else when every scored token is masked
@@ -1172,7 +1257,7 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         launch_attention(at, dt, st);
     }
     float* Y1 = h->EncOut;  // (n*nq, d) decoder residual of the scored tokens (EncOut is dead: Z/Y hold its uses)
-    static const bool no_fused = getenv("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
+    static const bool no_fused = M3PC_ENV("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
     bool tail_done = false;
     if (dt == DT_BF16 && !no_fused && (long long)n * nq >= 512 && h->wstream.count(pfx)) {
         // out-proj, norm2, FFN, decoder.norm and the two heads' LayerNorms in one launch (block_fused.hip): the rows of
@@ -1374,44 +1459,41 @@ int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out) {
         CHK(dmalloc(&h->tok_std[k], 32));
     }
     CHK(dmalloc(&h->mask_tokens, (size_t)4 * d));
-    const long long r1 = (long long)D.max_candidates * 2 * T, r2 = (long long)D.max_batch * 4 * T;
-    h->R = r1 > r2 ? r1 : r2;
-    if (h->R < 4 * T) h->R = 4 * T;
-    const size_t R = (size_t)h->R;
-    CHK(dmalloc(&h->X, R * d));
-    CHK(dmalloc(&h->Y, R * d));
-    CHK(dmalloc(&h->EncOut, R * d));
-    CHK(dmalloc(&h->G, R * d));
-    CHK(dmalloc((float**)&h->Hn, R * d));
-    CHK(dmalloc((float**)&h->QKV, R * 3 * d));
-    CHK(dmalloc((float**)&h->O, R * d));
-    CHK(dmalloc((float**)&h->F, R * 4 * d));
-    CHK(dmalloc((float**)&h->Z, R * d));
-    CHK(dmalloc(&h->cand, (size_t)D.max_candidates * T * h->A));
-    CHK(dmalloc(&h->loc, (size_t)D.max_batch * T * h->A + 64));
-    CHK(dmalloc(&h->sd, (size_t)D.max_batch * T * h->A + 64));
-    CHK(dmalloc(&h->rtok, (size_t)D.max_batch * T));
-    CHK(dmalloc(&h->pred[0], (size_t)D.max_candidates * T * 32));
-    CHK(dmalloc(&h->pred[1], (size_t)D.max_candidates * T * 32));
-    CHK(dmalloc(&h->qv, (size_t)D.max_candidates * T));
+    // candidate workspace: max_candidates candidates of 2T token rows (or max_batch generic forwards of 4T)
+    {
+        const long long r1 = (long long)D.max_candidates * 2 * T, r2 = (long long)D.max_batch * 4 * T;
+        long long R = r1 > r2 ? r1 : r2;
+        if (R < 4 * T) R = 4 * T;
+        CHK(alloc_ws(h.get(), h->base, R, D.max_candidates, 64LL << 20));
+    }
+    // chain workspaces: fp32 re-scores (<= max_rescore candidates) / policy passes (batch <= max_batch)
+    {
+        const int mr = D.max_rescore > 0 ? D.max_rescore : 64;
+        long long R = (long long)mr * 2 * T;
+        if (R < 4 * T) R = 4 * T;
+        CHK(alloc_ws(h.get(), h->chain, R, mr, 32LL << 20));
+        CHK(alloc_ws(h.get(), h->pchain, (long long)D.max_batch * 4 * T, 1, 32LL << 20));
+    }
+    for (int s = 0; s < M3PC_SLOTS; ++s) {
+        CHK(dmalloc(&h->slot[s].loc, (size_t)D.max_batch * T * h->A + 64));
+        CHK(dmalloc(&h->slot[s].sd, (size_t)D.max_batch * T * h->A + 64));
+        CHK(dmalloc(&h->slot[s].rtok, (size_t)D.max_batch * T));
+    }
     CHK(dmalloc(&h->sel_scratch, 64));
     CHK(dmalloc(&h->d_topk, 1024));
     CHK(dmalloc(&h->er_top, 1024));
-    CHK(dmalloc(&h->sa_buf, (size_t)D.max_candidates * T * h->A));
-    h->splitk_ws_bytes = 64LL << 20;
-    CHK(dmalloc(&h->splitk_ws, (size_t)(h->splitk_ws_bytes / 4)));
-    h->base = m3pc_handle::Base{h->X, h->Y, h->EncOut, h->G, h->cand, {h->pred[0], h->pred[1]}, h->qv, h->splitk_ws,
-                                (char*)h->Hn, (char*)h->QKV, (char*)h->O, (char*)h->F, (char*)h->Z, h->splitk_ws_bytes};
-    set_view(h.get(), 0, D.max_candidates);
+    CHK(dmalloc(&h->sa_buf, (size_t)(D.max_candidates > h->chain.max_cand ? D.max_candidates : h->chain.max_cand) * T * h->A));
+    bind_ws(h.get(), &h->base);
+    bind_slot(h.get(), 0);
     HIPCHK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    if (const char* e = getenv("M3PC_TWO_STREAM")) h->two_stream = atoi(e) != 0;
+    if (const char* e = M3PC_ENV("M3PC_TWO_STREAM")) h->two_stream = atoi(e) != 0;
     h->auxs.push_back(h->aux);
     h->ev_joins.push_back(h->ev_join);
     // (lab: more than two candidate parts.  Streams are created only when asked for: a process has four hardware queues,
     // with more streams than that two of them share a queue and the halves no longer overlap)
-    if (const char* e = getenv("M3PC_STREAM_SPLIT")) {
+    if (const char* e = M3PC_ENV("M3PC_STREAM_SPLIT")) {
         for (const char* q = e; *q;) {
             h->stream_split.push_back(atoi(q));
             while (*q && *q != ',') ++q;
@@ -1459,9 +1541,15 @@ int m3pc_destroy(m3pc_handle* h) {
         hipFree(h->tok_std[k]);
     }
     hipFree(h->mask_tokens);
-    const m3pc_handle::Base& bs = h->base;
-    void* bufs[] = {bs.X, bs.Y, bs.EncOut, bs.G, bs.Hn, bs.QKV, bs.O, bs.F, bs.Z, bs.cand, h->loc, h->sd, h->rtok,
-                    bs.pred[0], bs.pred[1], bs.qv, h->sel_scratch, h->d_topk, h->er_top, h->sa_buf, bs.splitk_ws, h->c_om, h->c_os};
+    free_ws(h->base);
+    free_ws(h->chain);
+    free_ws(h->pchain);
+    for (int s = 0; s < M3PC_SLOTS; ++s) {
+        hipFree(h->slot[s].loc);
+        hipFree(h->slot[s].sd);
+        hipFree(h->slot[s].rtok);
+    }
+    void* bufs[] = {h->sel_scratch, h->d_topk, h->er_top, h->sa_buf, h->c_om, h->c_os};
     for (size_t i = 1; i < h->auxs.size(); ++i) {
         hipStreamDestroy(h->auxs[i]);
         hipEventDestroy(h->ev_joins[i]);
@@ -1503,61 +1591,89 @@ int m3pc_load_weights(m3pc_handle* h, const m3pc_named_tensor* tensors, int n, v
     if (!h || !tensors) return fail(M3PC_EINVAL, "null argument");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->device));
+    // The first call must bring every tensor; later calls may bring any subset (fine-tuning changes the weights between
+    // rollouts, finetune.py:306): only what depends on a tensor that came is re-derived.
+    const bool first = !h->weights_loaded;
+    std::vector<std::string> dirty;
     for (auto& kv : h->w) {
         const int i = find_tensor(tensors, n, kv.first);
-        if (i < 0) return fail(M3PC_EINVAL, "state_dict is missing '%s'", kv.first.c_str());
+        if (i < 0) {
+            if (first) return fail(M3PC_EINVAL, "state_dict is missing '%s'", kv.first.c_str());
+            continue;
+        }
         if (tensors[i].numel != kv.second.numel)
             return fail(M3PC_EINVAL, "'%s' has %lld elements, expected %lld", kv.first.c_str(), tensors[i].numel, kv.second.numel);
         HIPCHK(hipMemcpyAsync(kv.second.f, tensors[i].data, (size_t)kv.second.numel * sizeof(float),
                               tensors[i].on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         if (kv.second.gemm) launch_f32_to_bf16(kv.second.f, kv.second.b, kv.second.numel, st);
         kv.second.loaded = true;
+        dirty.push_back(kv.first);
     }
+    auto is_dirty = [&](const std::string& name) {
+        for (const std::string& d : dirty)
+            if (d == name) return true;
+        return false;
+    };
+    long long* ls = h->load_stats;
+    ls[0] = (long long)dirty.size();
+    ls[1] = ls[2] = ls[3] = 0;
     if (block_fused_supported(h->d, h->ff)) {  // fragment streams of the fused layer tails (block_fused.hip)
         auto pack = [&](const std::string& pfx) -> int {
+            if (!(is_dirty(pfx + ".self_attn.out_proj.weight") || is_dirty(pfx + ".linear1.weight") || is_dirty(pfx + ".linear2.weight")))
+                return 0;
             bf16_t*& ws = h->wstream[pfx];
             if (!ws) CHK(dmalloc((char**)&ws, block_stream_bytes()));
             launch_pack_block_stream(W(h, pfx + ".self_attn.out_proj.weight").b, W(h, pfx + ".linear1.weight").b,
                                      W(h, pfx + ".linear2.weight").b, ws, st);
+            ++ls[1];
             return 0;
         };
         for (int i = 0; i < h->dm.n_enc_layer; ++i) CHK(pack("encoder.layers." + std::to_string(i)));
         for (int i = 0; i < h->dm.n_dec_layer; ++i) CHK(pack("decoder.layers." + std::to_string(i)));
         if (h->dm.n_dec_layer >= 1)
             for (int k = 0; k < 4; ++k) {
+                const std::string we = std::string("decoder_embed_dict.") + KEYN[k] + ".weight";
+                if (!(is_dirty(we) || is_dirty("decoder.layers.0.self_attn.in_proj_weight"))) continue;
                 if (!h->kvstream[k]) CHK(dmalloc((char**)&h->kvstream[k], kv_stream_bytes()));
-                launch_pack_kv_stream(W(h, std::string("decoder_embed_dict.") + KEYN[k] + ".weight").b,
-                                      W(h, "decoder.layers.0.self_attn.in_proj_weight").b + (size_t)h->d * h->d, h->kvstream[k], st);
+                launch_pack_kv_stream(W(h, we).b, W(h, "decoder.layers.0.self_attn.in_proj_weight").b + (size_t)h->d * h->d,
+                                      h->kvstream[k], st);
+                ++ls[2];
             }
     }
-    HIPCHK(hipStreamSynchronize(st));
-    // small derived tables on the host
+    // small derived tables, on the device: transposed encoder-embed weights, E_enc / E_dec = (bias + per-dim) + pos, mask tokens
     const int d = h->d, T = h->T;
-    std::vector<float> pos((size_t)T * d);
-    HIPCHK(hipMemcpy(pos.data(), W(h, "pos_embed").f, pos.size() * sizeof(float), hipMemcpyDeviceToHost));
-    std::vector<float> mt((size_t)4 * d);
+    const bool pos_dirty = is_dirty("pos_embed");
     for (int k = 0; k < 4; ++k) {
         const std::string kn = KEYN[k];
-        const int f = h->feat[k];
-        std::vector<float> w((size_t)d * f), wt((size_t)d * f), b(d), pd(d), e((size_t)T * d);
-        HIPCHK(hipMemcpy(w.data(), W(h, "encoder_embed_dict." + kn + ".weight").f, w.size() * sizeof(float), hipMemcpyDeviceToHost));
-        for (int c = 0; c < d; ++c)
-            for (int j = 0; j < f; ++j) wt[(size_t)j * d + c] = w[(size_t)c * f + j];
-        HIPCHK(hipMemcpy(h->WT[k], wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (is_dirty("encoder_embed_dict." + kn + ".weight"))
+            launch_transpose_f32(W(h, "encoder_embed_dict." + kn + ".weight").f, h->WT[k], d, h->feat[k], st);
         for (int pass = 0; pass < 2; ++pass) {
             const std::string side = pass == 0 ? "encoder" : "decoder";
-            HIPCHK(hipMemcpy(b.data(), W(h, side + "_embed_dict." + kn + ".bias").f, d * sizeof(float), hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(pd.data(), W(h, side + "_per_dim_encoding." + kn).f, d * sizeof(float), hipMemcpyDeviceToHost));
-            for (int t = 0; t < T; ++t)
-                for (int c = 0; c < d; ++c) e[(size_t)t * d + c] = (b[c] + pd[c]) + pos[(size_t)t * d + c];
-            HIPCHK(hipMemcpy(pass == 0 ? h->Eenc[k] : h->Edec[k], e.data(), e.size() * sizeof(float), hipMemcpyHostToDevice));
+            if (pos_dirty || is_dirty(side + "_embed_dict." + kn + ".bias") || is_dirty(side + "_per_dim_encoding." + kn))
+                launch_embed_table(W(h, side + "_embed_dict." + kn + ".bias").f, W(h, side + "_per_dim_encoding." + kn).f,
+                                   W(h, "pos_embed").f, pass == 0 ? h->Eenc[k] : h->Edec[k], T, d, st);
         }
-        HIPCHK(hipMemcpy(mt.data() + (size_t)k * d, W(h, "mask_token_dict." + kn).f, d * sizeof(float), hipMemcpyDeviceToHost));
+        if (is_dirty("mask_token_dict." + kn))
+            HIPCHK(hipMemcpyAsync(h->mask_tokens + (size_t)k * d, W(h, "mask_token_dict." + kn).f, d * sizeof(float),
+                                  hipMemcpyDeviceToDevice, st));
     }
-    HIPCHK(hipMemcpy(h->mask_tokens, mt.data(), mt.size() * sizeof(float), hipMemcpyHostToDevice));
-    invalidate_tables(h);
-    h->policy_valid = false;
+    // the candidate-independent decoder tables of every cached plan hang on the decoder side of the model
+    bool dec_dirty = pos_dirty;
+    for (const std::string& nme : dirty)
+        if (nme.rfind("decoder", 0) == 0 || nme.rfind("mask_token_dict", 0) == 0) dec_dirty = true;
+    if (dec_dirty) {
+        invalidate_tables(h);
+        ls[3] = 1;
+    }
+    for (int sl = 0; sl < M3PC_SLOTS; ++sl) h->slot[sl].policy_valid = false;
+    HIPCHK(hipStreamSynchronize(st));  // the caller's tensors may go away when the call returns
     h->weights_loaded = true;
+    return check_launch("load_weights");
+}
+
+int m3pc_load_stats(m3pc_handle* h, long long* out4) {
+    if (!h || !out4) return fail(M3PC_EINVAL, "null argument");
+    for (int i = 0; i < 4; ++i) out4[i] = h->load_stats[i];
     return 0;
 }
 
@@ -1659,11 +1775,8 @@ int m3pc_forward(m3pc_handle* h, int batch, const float* const tokens[4], const 
                         precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32, (hipStream_t)stream);
 }
 
-int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* actions, const float* rewards,
-                   const float* eps, float* loc, float* std_, float* sample_actions, float* expect_return,
-                   float* pred_rewards, float* pred_boot, void* stream) {
-    if (!h || !a || !states || !actions || !rewards || !eps || !sample_actions || !expect_return)
-        return fail(M3PC_EINVAL, "null argument");
+// common argument checks of the plan-step entry points; binds the step's slot
+static int plan_check(m3pc_handle* h, const m3pc_plan_args* a, bool need_critic) {
     if (!h->weights_loaded) return fail(M3PC_ESTATE, "weights not loaded");
     for (int k = 0; k < 4; ++k)
         if (!h->tok_set[k]) return fail(M3PC_ESTATE, "tokenizer '%s' not set", KEYN[k]);
@@ -1671,28 +1784,35 @@ int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     if (a->horizon < 1 || a->horizon > T) return fail(M3PC_EINVAL, "horizon %d outside [1, T=%d]", a->horizon, T);
     if (a->mode < 0 || a->mode > 2) return fail(M3PC_EINVAL, "bad mode %d", a->mode);
     if (a->precision != M3PC_PREC_FP32 && a->precision != M3PC_PREC_BF16) return fail(M3PC_EINVAL, "bad precision");
-    if (a->n_count < 1 || a->n_begin < 0 || a->n_begin + a->n_count > a->n_total)
-        return fail(M3PC_EINVAL, "candidate range [%d,+%d) outside n_total=%d", a->n_begin, a->n_count, a->n_total);
-    if (a->n_count > h->dm.max_candidates) return fail(M3PC_ENOMEM, "n_count %d > max_candidates %d", a->n_count, h->dm.max_candidates);
-    if (a->mode != M3PC_MODE_RTG && !h->critic_set) return fail(M3PC_ESTATE, "critic weights not set");
-    hipStream_t st = (hipStream_t)stream;
+    if (a->slot < 0 || a->slot >= M3PC_SLOTS) return fail(M3PC_EINVAL, "slot %d outside [0, %d)", a->slot, M3PC_SLOTS);
+    if (need_critic && a->mode != M3PC_MODE_RTG && !h->critic_set) return fail(M3PC_ESTATE, "critic weights not set");
     HIPCHK(hipSetDevice(h->device));
-    const int hh = a->horizon, idx = T - hh;
+    bind_slot(h, a->slot);
+    return 0;
+}
 
-    // returns token: float64 normalisation then cast (learner.py:371-374, continuous.py:74-79)
-    double rt = a->rtg;
-    if (h->tok_norm[M3PC_RETURNS]) rt = (rt - (double)h->h_mean[M3PC_RETURNS][0]) / (double)h->h_std[M3PC_RETURNS][0];
-    launch_fill(h->rtok, (float)rt, T, st);
-
-    // PASS 1: return-conditioned policy, batch 1, rcbc mask (finetune_omtm/masks.py:7-27), always fp32
-    std::vector<unsigned char> m[4];
-    for (int k = 0; k < 4; ++k) m[k].assign(T, 0);
-    for (int t = 0; t <= idx; ++t) m[M3PC_STATES][t] = 1;
-    for (int t = 0; t < idx; ++t) m[M3PC_ACTIONS][t] = 1;
-    for (int t = 0; t < T; ++t) m[M3PC_RETURNS][t] = 1;
-    const unsigned char* mp[4] = {m[0].data(), m[1].data(), m[2].data(), m[3].data()};
+// PASS 1 of a plan step (learner.py:278-284): the returns tokens of the window, then the return-conditioned policy at
+// batch 1 under the rcbc mask (finetune_omtm/masks.py:7-27), always fp32, in the chain workspace; leaves loc / sd / rtok in
+// the step's slot.
+int m3pc_policy_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* actions, const float* rewards,
+                     float* loc, float* std_, void* stream) {
+    if (!h || !a || !states || !actions || !rewards) return fail(M3PC_EINVAL, "null argument");
+    CHK(plan_check(h, a, false));
+    hipStream_t st = (hipStream_t)stream;
+    const int T = h->T, hh = a->horizon, idx = T - hh;
+    if (a->returns) {
+        // the caller's returns row (learner.py:272-293 consumes whatever trajectory["returns"] holds): tokenised as
+        // ContinuousTokenizer.encode does, in the row's own dtype, then cast (continuous.py:74-79)
+        launch_tokenize(a->returns, a->returns_f64, h->rtok, T, 1, h->tok_mean[M3PC_RETURNS], h->tok_std[M3PC_RETURNS],
+                        h->tok_norm[M3PC_RETURNS], st);
+    } else {
+        // constant return-to-go: float64 normalisation then cast (learner.py:371-374, continuous.py:74-79)
+        double rt = a->rtg;
+        if (h->tok_norm[M3PC_RETURNS]) rt = (rt - (double)h->h_mean[M3PC_RETURNS][0]) / (double)h->h_std[M3PC_RETURNS][0];
+        launch_fill(h->rtok, (float)rt, T, st);
+    }
     Plan* pl = nullptr;
-    CHK(get_plan(h, mp, &pl));
+    CHK(get_mask_plan(h, 0, idx, &pl));
     TokIn in;
     memset(&in, 0, sizeof(in));
     in.ptr[M3PC_STATES] = states;
@@ -1703,9 +1823,35 @@ int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     in.normalize[M3PC_REWARDS] = h->tok_norm[M3PC_REWARDS];
     in.ptr[M3PC_RETURNS] = h->rtok;
     h->allow_splitk = true;
-    CHK(forward_impl(h, pl, in, 1, nullptr, nullptr, nullptr, h->loc, h->sd, DT_F32, st));
+    int rc;
+    {
+        WsScope ws(h, true, true);
+        rc = forward_impl(h, pl, in, 1, nullptr, nullptr, nullptr, h->loc, h->sd, DT_F32, st);
+    }
     h->allow_splitk = false;
-    h->policy_valid = true;
+    if (rc) return rc;
+    h->slot[a->slot].policy_valid = true;
+    if (loc) HIPCHK(hipMemcpyAsync(loc, h->loc, (size_t)T * h->A * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (std_) HIPCHK(hipMemcpyAsync(std_, h->sd, (size_t)T * h->A * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return check_launch("policy_pass");
+}
+
+// Candidates + PASS 2 + scoring of a plan step (learner.py:285-316) from the slot's policy head, in the candidate workspace.
+int m3pc_candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* actions, const float* rewards,
+                        const float* eps, float* loc, float* std_, float* sample_actions, float* expect_return,
+                        float* pred_rewards, float* pred_boot, void* stream) {
+    if (!h || !a || !states || !actions || !rewards || !eps || !sample_actions || !expect_return)
+        return fail(M3PC_EINVAL, "null argument");
+    CHK(plan_check(h, a, true));
+    if (!h->slot[a->slot].policy_valid) return fail(M3PC_ESTATE, "m3pc_candidate_pass needs m3pc_policy_pass on slot %d first", a->slot);
+    const int T = h->T;
+    if (a->n_count < 1 || a->n_begin < 0 || a->n_begin + a->n_count > a->n_total)
+        return fail(M3PC_EINVAL, "candidate range [%d,+%d) outside n_total=%d", a->n_begin, a->n_count, a->n_total);
+    if (a->n_count > h->dm.max_candidates) return fail(M3PC_ENOMEM, "n_count %d > max_candidates %d", a->n_count, h->dm.max_candidates);
+    hipStream_t st = (hipStream_t)stream;
+    const int hh = a->horizon, idx = T - hh;
+    bind_ws(h, &h->base);
+    h->allow_splitk = false;
 
     // candidates
     SampleP sp;
@@ -1780,6 +1926,21 @@ int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     return candidate_pass(h, a, states, rewards, n, sample_actions, expect_return, pred_rewards, pred_boot, dt, st);
 }
 
+// m3pc_policy_pass + m3pc_candidate_pass on one stream
+int m3pc_plan_step(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* actions, const float* rewards,
+                   const float* eps, float* loc, float* std_, float* sample_actions, float* expect_return,
+                   float* pred_rewards, float* pred_boot, void* stream) {
+    if (!h || !a || !states || !actions || !rewards || !eps || !sample_actions || !expect_return)
+        return fail(M3PC_EINVAL, "null argument");
+    if (a->mode >= 0 && a->mode <= 2 && a->mode != M3PC_MODE_RTG && !h->critic_set) return fail(M3PC_ESTATE, "critic weights not set");
+    if (a->n_count < 1 || a->n_begin < 0 || a->n_begin + a->n_count > a->n_total)
+        return fail(M3PC_EINVAL, "candidate range [%d,+%d) outside n_total=%d", a->n_begin, a->n_count, a->n_total);
+    if (a->n_count > h->dm.max_candidates) return fail(M3PC_ENOMEM, "n_count %d > max_candidates %d", a->n_count, h->dm.max_candidates);
+    CHK(m3pc_policy_pass(h, a, states, actions, rewards, nullptr, nullptr, stream));
+    return m3pc_candidate_pass(h, a, states, actions, rewards, eps, loc, std_, sample_actions, expect_return, pred_rewards,
+                               pred_boot, stream);
+}
+
 // fills h->rtok[w * T + t] with window w's normalised return-to-go (float64 normalisation then cast: learner.py:371-374,
 // continuous.py:74-79)
 static int fill_rtok(m3pc_handle* h, const double* rtg, int n_windows, hipStream_t st) {
@@ -1802,11 +1963,15 @@ int m3pc_score_actions(m3pc_handle* h, const m3pc_plan_args* a, int n_windows, c
     if (a->horizon < 1 || a->horizon > T) return fail(M3PC_EINVAL, "horizon %d outside [1, T=%d]", a->horizon, T);
     if (a->mode != M3PC_MODE_RTG && a->mode != M3PC_MODE_CRITIC) return fail(M3PC_EINVAL, "mode must be RTG or CRITIC scoring");
     if (a->precision != M3PC_PREC_FP32 && a->precision != M3PC_PREC_BF16) return fail(M3PC_EINVAL, "bad precision");
-    if (n < 1 || n > h->dm.max_candidates) return fail(M3PC_ENOMEM, "n_count %d outside [1, max_candidates=%d]", n, h->dm.max_candidates);
+    if (n < 1 || (n > h->dm.max_candidates && !(a->precision == M3PC_PREC_FP32 && n <= h->chain.max_cand)))
+        return fail(M3PC_ENOMEM, "n_count %d outside [1, max_candidates=%d]", n, h->dm.max_candidates);
     if (n_windows < 1 || (n_windows > 1 && !window_index)) return fail(M3PC_EINVAL, "n_windows > 1 needs window_index");
     if (a->mode == M3PC_MODE_CRITIC && !h->critic_set) return fail(M3PC_ESTATE, "critic weights not set");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->device));
+    const int dt = a->precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32;
+    // few-row fp32 calls (the re-score of a batched plan) run in the chain workspace, like m3pc_rescore
+    WsScope ws(h, dt == DT_F32 && n <= h->chain.max_cand);
     SampleP sp;
     memset(&sp, 0, sizeof(sp));
     sp.hist_actions = actions;
@@ -1820,7 +1985,6 @@ int m3pc_score_actions(m3pc_handle* h, const m3pc_plan_args* a, int n_windows, c
     sp.widx = window_index;
     sp.cand = h->cand;
     launch_sample(sp, st);
-    const int dt = a->precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32;
     // (split-K is row-count dependent: only where the caller does not rely on sharding exactness, i.e. the fp32 re-scores)
     h->allow_splitk = dt == DT_F32;
     const int rc = candidate_pass(h, a, states, rewards, n, cand, expect_return, pred_rewards, pred_boot, dt, st, window_index);
@@ -1847,16 +2011,12 @@ int m3pc_plan_step_batch(m3pc_handle* h, const m3pc_plan_args* a, int n_windows,
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->device));
     const int hh = a->horizon, idx = T - hh, A = h->A;
+    if (a->slot < 0 || a->slot >= M3PC_SLOTS) return fail(M3PC_EINVAL, "slot %d outside [0, %d)", a->slot, M3PC_SLOTS);
+    bind_slot(h, a->slot);
     CHK(fill_rtok(h, rtg, E, st));
     // PASS 1 for all windows at once: return-conditioned policy, batch E, rcbc mask, fp32
-    std::vector<unsigned char> m[4];
-    for (int k = 0; k < 4; ++k) m[k].assign(T, 0);
-    for (int t = 0; t <= idx; ++t) m[M3PC_STATES][t] = 1;
-    for (int t = 0; t < idx; ++t) m[M3PC_ACTIONS][t] = 1;
-    for (int t = 0; t < T; ++t) m[M3PC_RETURNS][t] = 1;
-    const unsigned char* mp[4] = {m[0].data(), m[1].data(), m[2].data(), m[3].data()};
     Plan* pl = nullptr;
-    CHK(get_plan(h, mp, &pl));
+    CHK(get_mask_plan(h, 0, idx, &pl));
     TokIn in;
     memset(&in, 0, sizeof(in));
     in.ptr[M3PC_STATES] = states;
@@ -1871,9 +2031,13 @@ int m3pc_plan_step_batch(m3pc_handle* h, const m3pc_plan_args* a, int n_windows,
     in.ptr[M3PC_RETURNS] = h->rtok;
     in.bstride[M3PC_RETURNS] = T;
     h->allow_splitk = true;
-    CHK(forward_impl(h, pl, in, E, nullptr, nullptr, nullptr, h->loc, h->sd, DT_F32, st));
+    {
+        WsScope ws(h, true, true);
+        const int rc = forward_impl(h, pl, in, E, nullptr, nullptr, nullptr, h->loc, h->sd, DT_F32, st);
+        if (rc) return rc;
+    }
     h->allow_splitk = false;
-    h->policy_valid = false;  // (m3pc_rescore works on the single-window state; batched callers re-score with m3pc_score_actions)
+    h->slot[a->slot].policy_valid = false;  // (m3pc_rescore works on a single-window slot; batched callers re-score with m3pc_score_actions)
     // candidates of window w: rows [w N, (w+1) N) of cand / sample_actions, drawn from window w's policy head and eps block
     for (int w = 0; w < E; ++w) {
         SampleP sp;
@@ -1903,13 +2067,19 @@ int m3pc_rescore(m3pc_handle* h, const m3pc_plan_args* a, const float* states, c
                  const float* eps, const int* index, int n, float* sample_actions, float* expect_return, void* stream) {
     if (!h || !a || !states || !actions || !rewards || !eps || !index || !expect_return) return fail(M3PC_EINVAL, "null argument");
     if (!h->weights_loaded) return fail(M3PC_ESTATE, "weights not loaded");
-    if (!h->policy_valid) return fail(M3PC_ESTATE, "m3pc_rescore needs a preceding m3pc_plan_step");
+    if (a->slot < 0 || a->slot >= M3PC_SLOTS) return fail(M3PC_EINVAL, "slot %d outside [0, %d)", a->slot, M3PC_SLOTS);
+    if (!h->slot[a->slot].policy_valid) return fail(M3PC_ESTATE, "m3pc_rescore needs a preceding m3pc_plan_step / m3pc_policy_pass on slot %d", a->slot);
     const int T = h->T;
     if (a->horizon < 1 || a->horizon > T || a->mode < 0 || a->mode > 2) return fail(M3PC_EINVAL, "bad horizon/mode");
-    if (n < 1 || n > h->dm.max_candidates) return fail(M3PC_ENOMEM, "n %d outside [1, max_candidates=%d]", n, h->dm.max_candidates);
+    // runs in the chain workspace when it fits (so that it can be enqueued beside a candidate pass), else in the candidate one
+    const bool in_chain = n <= h->chain.max_cand;
+    if (n < 1 || (!in_chain && n > h->dm.max_candidates))
+        return fail(M3PC_ENOMEM, "n %d outside [1, max(max_rescore=%d, max_candidates=%d)]", n, h->chain.max_cand, h->dm.max_candidates);
     if (a->mode != M3PC_MODE_RTG && !h->critic_set) return fail(M3PC_ESTATE, "critic weights not set");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->device));
+    bind_slot(h, a->slot);
+    WsScope ws(h, in_chain);
     float* sa = sample_actions ? sample_actions : h->sa_buf;
     SampleP sp;
     memset(&sp, 0, sizeof(sp));
@@ -1937,8 +2107,8 @@ int m3pc_rescore_topk(m3pc_handle* h, const m3pc_plan_args* a, const float* stat
                       const float* rewards, const float* eps, float* expect_return, int k, int* topk_index, void* stream) {
     if (!h || !a || !expect_return) return fail(M3PC_EINVAL, "null argument");
     if (a->n_total < 1 || a->n_total > 16384) return fail(M3PC_EINVAL, "top-k supports n_total <= 16384");
-    if (k < 1 || k > a->n_total || k > h->dm.max_candidates || k > 1024)
-        return fail(M3PC_EINVAL, "k %d outside [1, min(n_total, max_candidates, 1024)]", k);
+    if (k < 1 || k > a->n_total || (k > h->dm.max_candidates && k > h->chain.max_cand) || k > 1024)
+        return fail(M3PC_EINVAL, "k %d outside [1, min(n_total, max(max_candidates, max_rescore), 1024)]", k);
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->device));
     launch_topk(expect_return, a->n_total, k, h->d_topk, st);
@@ -1948,7 +2118,7 @@ int m3pc_rescore_topk(m3pc_handle* h, const m3pc_plan_args* a, const float* stat
 }
 
 int m3pc_topk_window(m3pc_handle* h, const float* expect_return, int n_total, int kmax, int kmin, float window, int* topk_index,
-                     float* stats, float* host_stats, float seq, void* stream) {
+                     float* stats, float* top_scores, float* host_stats, float seq, void* stream) {
     if (!h || !expect_return || !topk_index || !stats) return fail(M3PC_EINVAL, "null argument");
     if (n_total < 1 || n_total > 16384) return fail(M3PC_EINVAL, "top-k supports n_total <= 16384");
     if (kmax < 1 || kmax > 1023 || kmin < 1 || kmin > kmax || !(window >= 0.f)) return fail(M3PC_EINVAL, "bad kmin/kmax/window");
@@ -1956,8 +2126,20 @@ int m3pc_topk_window(m3pc_handle* h, const float* expect_return, int n_total, in
     HIPCHK(hipSetDevice(h->device));
     const int kk = kmax + 1 < n_total ? kmax + 1 : n_total;
     launch_topk(expect_return, n_total, kk, topk_index, st);
-    launch_window_stats(expect_return, topk_index, kk, kmin, kmax, window, stats, host_stats, seq, st);
+    launch_window_stats(expect_return, n_total, topk_index, kk, kmin, kmax, window, stats, host_stats, seq, top_scores, st);
     return check_launch("topk_window");
+}
+
+int m3pc_rescore_merge(m3pc_handle* h, const float* scores, int n_total, const int* index, int n, const float* top_scores,
+                       const float* top_rescored, float delta, float* merged, float* stats, float* host_stats, float seq,
+                       void* stream) {
+    if (!h || !scores || !index || !top_scores || !top_rescored || !merged || !stats) return fail(M3PC_EINVAL, "null argument");
+    if (n_total < 1 || n < 1 || n > 1024 || n > n_total) return fail(M3PC_EINVAL, "n %d outside [1, min(1024, n_total)]", n);
+    if (!(delta >= 0.f)) return fail(M3PC_EINVAL, "delta must be >= 0");
+    HIPCHK(hipSetDevice(h->device));
+    launch_rescore_merge(scores, n_total, index, n, top_scores, top_rescored, delta, merged, stats, host_stats, seq,
+                         (hipStream_t)stream);
+    return check_launch("rescore_merge");
 }
 
 int m3pc_rescore_listed(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* actions, const float* rewards,
@@ -1998,10 +2180,11 @@ int m3pc_select(m3pc_handle* h, const float* expect_return, const float* a0, lon
     return check_launch("select");
 }
 
-// Not part of the public header: lets tools/gemm_bench.py time the GEMM kernel on the plan step's shapes.
+#ifdef M3PC_LAB  // ---- kernel-level test / bench hooks: libm3pc_hip_lab.so only, declared in include/m3pc_hip_debug.h
+// Lab build only (include/m3pc_hip_debug.h): lets tools/gemm_bench.py time the GEMM kernel on the plan step's shapes.
 int m3pc_debug_gemm(int dtype, const void* A, const void* Wt, const float* bias, const float* res, void* C, int M, int N,
                     int K, int gelu, int f32out, int variant, void* stream) {
-    static const int ldpad = getenv("M3PC_DEBUG_LDPAD") ? atoi(getenv("M3PC_DEBUG_LDPAD")) : 0;  // operand row padding (elements)
+    static const int ldpad = M3PC_ENV("M3PC_DEBUG_LDPAD") ? atoi(M3PC_ENV("M3PC_DEBUG_LDPAD")) : 0;  // operand row padding (elements)
     GemmP p = gemm_basic(A, K + ldpad, Wt, K + ldpad, M, N, K, bias);
     p.a_padded = 0;  // (a caller's tensor: nothing is known about the memory behind it)
     p.gelu = gelu;
@@ -2142,6 +2325,8 @@ int m3pc_debug_clock_big(long long* out4) {
     read_big_probe(out4);
     return 0;
 }
+
+#endif  // M3PC_LAB
 
 int m3pc_profile_enable(m3pc_handle* h, int enable) {
     if (!h) return fail(M3PC_EINVAL, "null handle");

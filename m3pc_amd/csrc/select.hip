@@ -241,7 +241,7 @@ __global__ __launch_bounds__(1024) void topk_rank_kernel(const float* v, int n, 
 void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st) {
     if (n <= 0 || k <= 0) return;
     if (n <= 2048 && k <= n) {
-        static const bool one_block = getenv("M3PC_TOPK_ONE_BLOCK") != nullptr;  // A/B switch
+        static const bool one_block = M3PC_ENV("M3PC_TOPK_ONE_BLOCK") != nullptr;  // A/B switch
         if (one_block) hipLaunchKernelGGL(topk_rank_kernel, dim3(1), dim3(1024), 0, st, v, n, k, idx_out);
         else hipLaunchKernelGGL(topk_rank_blocks_kernel, dim3((n + 63) / 64), dim3(256), 0, st, v, n, k, idx_out);
         return;
@@ -262,25 +262,36 @@ void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st) {
 
 // idx: the kk best entries of v, best first.  n = clamp(#{i < kk: v[idx[i]] >= v[idx[0]] - window}, kmin, kmax) and the
 // distance from the best entry to the best one NOT among those n (infinity when there is none).
-__global__ __launch_bounds__(64) void window_stats_kernel(const float* v, const int* idx, int kk, int kmin, int kmax, float window,
-                                                          float* stats, float* host_stats, float seq) {
-    const int lane = threadIdx.x;
+// Window statistics of the bound-driven re-score: idx = the kk best entries of v (best first).  The raw count of entries
+// within `window` of the maximum runs over the WHOLE vector (n_total), so a caller sees when the window holds more than the
+// kmax entries it may list (stats[3] > kmax: the listed prefix no longer covers the window).
+__global__ __launch_bounds__(256) void window_stats_kernel(const float* v, int n_total, const int* idx, int kk, int kmin, int kmax,
+                                                           float window, float* stats, float* host_stats, float seq,
+                                                           float* top_scores) {
+    __shared__ int part[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float mx = v[idx[0]];
     int cnt = 0;
-    for (int i = lane; i < kk && i < kmax; i += 64) cnt += v[idx[i]] >= mx - window ? 1 : 0;
+    for (int i = tid; i < n_total; i += 256) cnt += v[i] >= mx - window ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) part[wid] = cnt;
+    if (top_scores)
+        for (int i = tid; i < kk; i += 256) top_scores[i] = v[idx[i]];
+    __syncthreads();
+    cnt = part[0] + part[1] + part[2] + part[3];
     int n = cnt < kmin ? kmin : cnt;
     if (n > kmax) n = kmax;
     if (n > kk) n = kk;
-    if (lane == 0) {
+    if (tid == 0) {
+        const float margin = n < kk ? mx - v[idx[n]] : INFINITY;
         stats[0] = (float)n;
-        stats[1] = n < kk ? mx - v[idx[n]] : INFINITY;
+        stats[1] = margin;
         stats[2] = mx;
         stats[3] = (float)cnt;
         if (host_stats) {  // host-mapped (pinned) copy the caller spins on: payload first, then the sequence number
             host_stats[0] = (float)n;
-            host_stats[1] = n < kk ? mx - v[idx[n]] : INFINITY;
+            host_stats[1] = margin;
             host_stats[2] = mx;
             host_stats[3] = (float)cnt;
             __threadfence_system();
@@ -288,9 +299,110 @@ __global__ __launch_bounds__(64) void window_stats_kernel(const float* v, const 
         }
     }
 }
-void launch_window_stats(const float* v, const int* idx, int kk, int kmin, int kmax, float window, float* stats, float* host_stats,
-                         float seq, hipStream_t st) {
-    hipLaunchKernelGGL(window_stats_kernel, dim3(1), dim3(64), 0, st, v, idx, kk, kmin, kmax, window, stats, host_stats, seq);
+void launch_window_stats(const float* v, int n_total, const int* idx, int kk, int kmin, int kmax, float window, float* stats,
+                         float* host_stats, float seq, float* top_scores, hipStream_t st) {
+    hipLaunchKernelGGL(window_stats_kernel, dim3(1), dim3(256), 0, st, v, n_total, idx, kk, kmin, kmax, window, stats, host_stats, seq,
+                       top_scores);
+}
+
+// Merge of a bf16 score vector with the fp32 re-scores of its n best entries (planner: certified re-score).
+//   d_i = b_top[i] - f_top[i] over the n listed entries;  c = lower median(d): the common shift of the bf16 scores;
+//   out[j] = b[j] - c for every j, then out[idx[i]] = f_top[i].
+// Certificate: with |(b_j - f_j) - c| <= delta for every candidate, an un-listed j can only beat the best listed fp32 score
+// f* if b_j - c > f* - delta.  need = #{j : b[j] > f* + c - delta} over the WHOLE vector (the listed entries are the n
+// largest b, so this set is a prefix of the descending order): need <= n certifies that the arg-max of `out` is the fp32
+// arg-max; otherwise the entries n .. need-1 of the order still have to be re-scored.
+//   stats = {c, max_i |d_i - c|, need, (f* + c - delta) - (largest un-listed b) [inf when everything is listed]}
+__global__ __launch_bounds__(1024) void rescore_merge_kernel(const float* b, int n_total, const int* idx, int n, const float* b_top,
+                                                             const float* f_top, float delta, float* out, float* stats,
+                                                             float* host_stats, float seq) {
+    __shared__ float d[1024];
+    __shared__ int ids[1024];
+    __shared__ float c_sh;
+    __shared__ float sv[16], sf[16], sb[16];
+    __shared__ int sc[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid < n) {
+        d[tid] = b_top[tid] - f_top[tid];
+        ids[tid] = idx[tid];
+    }
+    __syncthreads();
+    if (tid < n) {
+        const float me = d[tid];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float o = d[j];
+            rank += (o < me || (o == me && j < tid)) ? 1 : 0;
+        }
+        if (rank == (n - 1) / 2) c_sh = me;
+    }
+    __syncthreads();
+    const float c = c_sh;
+    float dev = tid < n ? fabsf(d[tid] - c) : 0.f;
+    float fb = tid < n ? f_top[tid] : -INFINITY;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        dev = fmaxf(dev, __shfl_xor(dev, o));
+        fb = fmaxf(fb, __shfl_xor(fb, o));
+    }
+    if (lane == 0) {
+        sv[wid] = dev;
+        sf[wid] = fb;
+    }
+    __syncthreads();
+    float fbest = sf[0], devmax = sv[0];
+    for (int w = 1; w < 16; ++w) {
+        fbest = fmaxf(fbest, sf[w]);
+        devmax = fmaxf(devmax, sv[w]);
+    }
+    const float thr = fbest + c - delta;  // on the bf16 scale
+    int cnt = 0;
+    float bout = -INFINITY;  // largest b among the un-listed: everything below the n-th largest b (the list is a prefix)
+    const float b_last = b_top[n - 1];
+    for (int j = tid; j < n_total; j += 1024) {
+        const float v = b[j];
+        out[j] = v - c;
+        cnt += v > thr ? 1 : 0;
+        if (v < b_last) bout = fmaxf(bout, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_xor(cnt, o);
+        bout = fmaxf(bout, __shfl_xor(bout, o));
+    }
+    if (lane == 0) {
+        sc[wid] = cnt;
+        sb[wid] = bout;
+    }
+    __syncthreads();
+    if (tid < n) out[ids[tid]] = f_top[tid];
+    if (tid == 0) {
+        int need = 0;
+        float bo = -INFINITY;
+        for (int w = 0; w < 16; ++w) {
+            need += sc[w];
+            bo = fmaxf(bo, sb[w]);
+        }
+        // (ties with the n-th listed score count as listed above: a tie at the list's edge keeps `need` honest through cnt)
+        const float margin = n >= n_total ? INFINITY : thr - bo;
+        stats[0] = c;
+        stats[1] = devmax;
+        stats[2] = (float)need;
+        stats[3] = margin;
+        if (host_stats) {
+            host_stats[0] = c;
+            host_stats[1] = devmax;
+            host_stats[2] = (float)need;
+            host_stats[3] = margin;
+            __threadfence_system();
+            __hip_atomic_store(host_stats + 4, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+void launch_rescore_merge(const float* b, int n_total, const int* idx, int n, const float* b_top, const float* f_top, float delta,
+                          float* out, float* stats, float* host_stats, float seq, hipStream_t st) {
+    hipLaunchKernelGGL(rescore_merge_kernel, dim3(1), dim3(1024), 0, st, b, n_total, idx, n, b_top, f_top, delta, out, stats,
+                       host_stats, seq);
 }
 
 __global__ void scatter_kernel(const float* src, const int* index, int n, float* dst, int* index_copy) {

@@ -12,14 +12,23 @@ Two ways in:
 
 Host work per step: assemble the window in NumPy (one packed H2D copy), draw eps / the multinomial index
 with torch's device generator, and -- when candidates are sharded over ranks -- one all-gather.
+
+Pipelining (``plan_async`` / ``PlanTicket.result``, ``action_sample_batch``, ``rollout.PipelinedPlanner``): the reference
+plans one window per call and reads the action back before the next one (replay_buffer.py:204-232, learner.py:645-741).
+For INDEPENDENT windows (several environments, evaluation episodes) the three parts of a plan step need not wait for each
+other across steps: the candidate passes run back to back on the caller's stream, while the latency-bound fp32 chains --
+step t+1's policy pass, step t's re-score + select -- run on a second ("chain") stream in the library's chain workspace.
+Every step owns a slot (policy head, returns tokens, re-score scratch); its results are bit-identical to the serial order.
 """
 from __future__ import annotations
 
 import types
 from typing import Dict, Optional
 
+import contextlib
+import warnings
+
 import numpy as np
-import os
 
 import torch
 
@@ -35,13 +44,72 @@ def _cfg_get(cfg, name, default=None):
     return getattr(cfg, name, default)
 
 
+class _Slot:
+    """Host side of one step slot of the handle (capi.SLOTS of them): the re-score scratch of the step that owns it, the
+    host-mapped statistics buffers, the staging buffer of its window and the events that order its parts across streams."""
+
+    def __init__(self, i: int, device):
+        self.i = i
+        self.owner = None
+        self.device = device
+        self.b_top = self.f_top = self.stats = self.mstats = None
+        self.hs_win = self.hs_mrg = None
+        self.win = self.win_np = None
+        self.ev_in = self.ev_pol = self.ev_cand = self.ev_done = None
+
+    def ready(self, planner):
+        if self.b_top is None:
+            dev = self.device
+            self.b_top = torch.empty((1024,), dtype=torch.float32, device=dev)  # their bf16 scores
+            self.f_top = torch.empty((1024,), dtype=torch.float32, device=dev)  # their fp32 re-scores
+            self.stats = torch.empty((4,), dtype=torch.float32, device=dev)
+            self.mstats = torch.empty((4,), dtype=torch.float32, device=dev)
+            self.hs_win, self.hs_mrg = capi.HostStats(), capi.HostStats()
+            self.win = torch.zeros((planner.T * (planner.S + planner.A + 1),), dtype=torch.float32).pin_memory()
+            self.win_np = self.win.numpy()
+            self.ev_in, self.ev_pol, self.ev_cand, self.ev_done = (torch.cuda.Event() for _ in range(4))
+        return self
+
+
+class PlanTicket:
+    """One plan step in flight (``HipPlanner.plan_async``).  ``result()`` -> what ``action_sample`` returns for the window:
+    the eval action (A,) when the step was issued with eval=True, else the sampled action (1, A); ``pair()`` -> both;
+    ``info`` (after the result): the step's ``planner.last`` record."""
+
+    def __init__(self, planner, slot, mode, states, actions, rewards, rtg, h, lmbda, returns):
+        self.planner, self.slot, self.mode = planner, slot, mode
+        self.states, self.actions, self.rewards, self.rtg, self.h, self.lmbda, self.returns = states, actions, rewards, rtg, h, lmbda, returns
+        self.chain = self.tchain = None
+        self.eps = self.expo = self.res = self.er_b = self.er = self.a0 = self.sel = self.top = None
+        self.tail_enqueued = False
+        self.kmin = self.kmax = self.n_done = 0
+        self.seq_mrg = 0.0
+        self.delta = None
+        self.seq_win = 0.0
+        self.shift = self.deviation = None
+        self.out = None
+        self.info = None
+        self.eval = None
+        self.keep = self.keep_window = self.outbuf = None
+
+    def pair(self):
+        """(sample_action (1, A), eval_action (A,))"""
+        return self.planner._finish(self)
+
+    def result(self):
+        sa, ev = self.planner._finish(self)
+        if self.eval is None:
+            return sa, ev
+        return ev if self.eval else sa
+
+
 class HipPlanner:
     def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], tokenizer_manager, q_state_dict=None,
                  obs_mean=None, obs_std=None, n_embd: int = 512, n_head: int = 4, n_enc_layer: int = 2,
                  n_dec_layer: int = 1, precision: str = "fp32", rescore_topk: int = 16, device: Optional[int] = None,
                  group=None, generator: Optional[torch.Generator] = None, max_batch: int = 1,
                  rescore: str = "bound", rescore_min: int = 8, rescore_max: int = 64, rescore_delta: Optional[float] = None,
-                 max_windows: int = 1):
+                 max_windows: int = 1, pipeline_depth: int = 2, chain_priority: int = -1, tail_stream: bool = True):
         """cfg: any object with traj_length, action_samples, horizon, discount, temperature, lmbda,
         plan_guidance (finetune.py RunConfig fields read at learner.py:276,319,342).
         tokenizer_manager: a TokenizerManager (this package's) or {key: {"mean","std","min","max"}}.
@@ -54,7 +122,13 @@ class HipPlanner:
             arithmetics (1.5 x the largest deviation seen), or fixed by ``rescore_delta``.  ``planner.last`` reports
             n_rescored, min_margin_outside (distance from the bf16 maximum to the best candidate NOT re-scored: the
             bound held with room when it exceeds 2*delta) and delta.  One 16-byte device-to-host read per step.
-          rescore="topk": the fixed ``rescore_topk`` best candidates (round-1 behaviour, no host read)."""
+          rescore="topk": the fixed ``rescore_topk`` best candidates (round-1 behaviour, no host read).
+          Either way the select runs on the MERGED vector (m3pc_rescore_merge): fp32 scores for the re-scored candidates,
+          bf16 scores minus the estimated common shift (median of bf16 - fp32 over the re-scored set) for the rest, so an
+          un-re-scored candidate cannot win the arg-max through a constant bf16 offset.  delta is re-checked every step on the
+          re-scored set (it grows when 1.5 x the deviation seen there exceeds it); when more than ``rescore_max`` candidates
+          lie inside the window the whole window set is re-scored in chunks (a warning is raised once; ``last["saturated"]``).
+        pipeline_depth: how many plan steps ``action_sample_batch`` / ``rollout`` keep in flight (<= capi.SLOTS - 1)."""
         self.cfg = cfg
         self.group = group
         self.rank, self.world = mdist.world_info(group)
@@ -66,12 +140,13 @@ class HipPlanner:
         N = int(cfg.action_samples)
         _, n_local = mdist.shard_range(N, 0, self.world)
         hidden = 0 if q_state_dict is None else q_state_dict["q1.net.0.weight"].shape[0]
+        nw = max(int(max_windows), 1)
+        # chain workspace: the fp32 re-score sets (all windows of a lock-step batch together), the calibration subset
+        self._n_cal = min(64, N)
+        max_rescore = max(int(rescore_max) * nw, int(rescore_topk), self._n_cal, 1) if precision == "bf16" else 1
         self.handle = capi.Handle(S, A, T, n_embd, n_head, n_enc_layer, n_dec_layer,
-                                  max_candidates=max(n_local * max(int(max_windows), 1), rescore_topk,
-                                                     int(rescore_max) * max(int(max_windows), 1) if precision == "bf16" else 1, 1),
-                                  max_batch=max(int(max_batch), int(max_windows), 1),
-                                  critic_hidden=hidden,
-                                  device=device)
+                                  max_candidates=max(n_local * nw, 1), max_batch=max(int(max_batch), nw, 1),
+                                  critic_hidden=hidden, device=device, max_rescore=max_rescore)
         self.device = self.handle.device
         self.S, self.A, self.T = S, A, T
         self.precision = {"fp32": capi.PREC_FP32, "bf16": capi.PREC_BF16}[precision]
@@ -95,92 +170,261 @@ class HipPlanner:
         self.load_state_dict(state_dict)
         if q_state_dict is not None:
             self.load_critic(q_state_dict, obs_mean, obs_std)
-        self._host = np.zeros((T, S + A + 1), dtype=np.float32)
+        self._host = np.zeros((T * (S + A + 1),), dtype=np.float32)  # [states (T,S) | actions (T,A) | rewards (T,1)] blocks
         self.last: Dict[str, torch.Tensor] = {}
+        self.pipeline_depth = max(1, min(int(pipeline_depth), capi.SLOTS - 1))
+        self._slots = [_Slot(i, self.device) for i in range(capi.SLOTS)]
+        self._next_slot = 0
+        self._chain = None          # the policy-pass stream (created on first pipelined use)
+        self._tchain = None         # the re-score + select stream (tail_stream=False: the policy-pass stream)
+        self._tail_stream = bool(tail_stream)
+        self._chain_priority = int(chain_priority)  # -1: high priority -- its short dependent launches go first when a CU frees up
+        self._pending = None        # pipelined ticket whose tail (re-score + select) is not enqueued yet
+        self._warned_saturated = False
+        self.delta_grown = 0        # how often the per-step deviation check raised delta since the last weight load
+        self.action_list = []       # zero-shot "piid_allout" (action_piid_list_sample)
+        self._bf16_offset = 0.0     # test hook: a constant added to the bf16 scores before the re-score
 
     # ---------------------------------------------------------------------------------------- weights
     def load_state_dict(self, state_dict):
+        """All tensors of ``omtm.state_dict()``, or -- after the first load -- any subset of them: the library re-packs only
+        what depends on the tensors given (``handle.load_stats()`` tells what that was)."""
+        for tk in [sl.owner for sl in getattr(self, "_slots", []) if sl.owner is not None]:
+            self._finish(tk)  # steps in flight were issued against the old weights: resolve them first
         self.handle.load_weights(state_dict)
         self._delta = getattr(self, "_delta_fixed", None)  # the bf16 error bound belongs to the weights: re-calibrate
         self._kspec, self._exceed = int(getattr(self, "rescore_min", 8)), 0.05
+        self.delta_grown = 0
 
     def load_critic(self, q_state_dict, obs_mean, obs_std):
         self.handle.set_critic(q_state_dict, obs_mean, obs_std)
 
     # ---------------------------------------------------------------------------------------- window
-    def assemble_window(self, sequence_history, rtg=None, percentage=1.0):
-        """learner.py:342-385.  Returns (states (T,S), actions (T,A), rewards (T,1) on device, horizon, rtg)."""
+    def _blocks(self, flat):
+        """(states (T,S), actions (T,A), rewards (T,1)) views of a flat [states | actions | rewards] window buffer."""
+        T, S, A = self.T, self.S, self.A
+        return flat[: T * S].reshape(T, S), flat[T * S : T * (S + A)].reshape(T, A), flat[T * (S + A) :].reshape(T, 1)
+
+    def _window_host(self, sequence_history, rtg, percentage, flat):
+        """Host half of ``assemble_window`` (learner.py:342-385) into the flat window buffer; returns (horizon, rtg)."""
         T = self.T
         horizon = int(self.cfg.horizon)
         end_idx = int(sequence_history["path_length"])
         if end_idx + horizon < T:
             horizon = T - end_idx
         hl = T - horizon + 1
-        buf = self._host
-        buf[:] = 0.0
+        flat[:] = 0.0
+        bs, ba, br = self._blocks(flat)
         lo, hi = end_idx - hl + 1, end_idx + 1
-        buf[:hl, : self.S] = sequence_history["observations"][lo:hi]
-        buf[:hl, self.S : self.S + self.A] = sequence_history["actions"][lo:hi]
-        buf[:hl, self.S + self.A :] = np.asarray(sequence_history["rewards"][lo:hi]).reshape(hl, 1)
-        dev = torch.from_numpy(buf).to(self.device)  # one packed H2D copy
-        states = dev[:, : self.S].contiguous()
-        actions = dev[:, self.S : self.S + self.A].contiguous()
-        rewards = dev[:, self.S + self.A :].contiguous()
+        bs[:hl] = sequence_history["observations"][lo:hi]
+        ba[:hl] = sequence_history["actions"][lo:hi]
+        br[:hl] = np.asarray(sequence_history["rewards"][lo:hi]).reshape(hl, 1)
+        return horizon, self._rtg_value(rtg, percentage)
+
+    def _rtg_value(self, rtg, percentage):
         if rtg is not None:
-            return_to_go = float(rtg)
-        else:
-            st = self.tokenizer_manager.tokenizers["returns"].stats
-            return_to_go = float(np.asarray(st.min + (st.max - st.min) * percentage).reshape(-1)[0])
+            return float(rtg)
+        st = self.tokenizer_manager.tokenizers["returns"].stats
+        return float(np.asarray(st.min + (st.max - st.min) * percentage).reshape(-1)[0])
+
+    def assemble_window(self, sequence_history, rtg=None, percentage=1.0):
+        """learner.py:342-385.  Returns (states (T,S), actions (T,A), rewards (T,1) on device, horizon, rtg)."""
+        horizon, return_to_go = self._window_host(sequence_history, rtg, percentage, self._host)
+        dev = torch.from_numpy(self._host).to(self.device)  # one packed H2D copy; the three blocks are contiguous views
+        states, actions, rewards = self._blocks(dev)
         return states, actions, rewards, horizon, return_to_go
 
     # ---------------------------------------------------------------------------------------- guidance
     def _eps(self, shape):
         return torch.randn(shape, device=self.device, dtype=torch.float32, generator=self.generator)
 
-    def _guide(self, mode: int, states, actions, rewards, rtg: float, h: int, lmbda: float, eps=None):
+    def _chain_stream(self):
+        if self._chain is None:
+            self._chain = torch.cuda.Stream(device=self.device, priority=self._chain_priority)
+            self._tchain = torch.cuda.Stream(device=self.device, priority=self._chain_priority) if self._tail_stream else self._chain
+        return self._chain
+
+    def _acquire_slot(self):
+        sl = self._slots[self._next_slot]
+        self._next_slot = (self._next_slot + 1) % len(self._slots)
+        if sl.owner is not None:  # a step still lives in this slot: finish it first (its buffers are about to be reused)
+            self._finish(sl.owner)
+        return sl
+
+    def _drain(self):
+        """Resolve every pipelined step still in flight (the current stream is then ordered behind the chain stream's work:
+        what follows may use the chain workspace on the current stream)."""
+        for tk in [sl.owner for sl in self._slots if sl.owner is not None and sl.owner.chain is not None]:
+            self._finish(tk)
+
+    def _guide(self, mode: int, states, actions, rewards, rtg: float, h: int, lmbda: float, eps=None, returns=None):
+        """One plan step, serial: everything on the current stream, results when the call returns (device-resident)."""
+        return self._issue(mode, states, actions, rewards, rtg, h, lmbda, eps=eps, returns=returns, pipelined=False).result()
+
+    def _issue(self, mode: int, states, actions, rewards, rtg: float, h: int, lmbda: float, eps=None, returns=None,
+               pipelined: bool = True, slot=None, inputs_ready: bool = False) -> "PlanTicket":
+        """Enqueue one plan step and return its ticket.
+        serial (pipelined=False): policy pass, candidate pass, re-score + select on the current stream.
+        pipelined: the policy pass goes to the chain stream at once, the candidate pass to the current stream behind it, and
+        the step's tail (re-score + select, chain stream) is enqueued with the NEXT step -- behind that step's policy pass --
+        or when the ticket is resolved: the chain stream then runs policy(t+1) while the current stream still runs
+        candidates(t), and tail(t) while it runs candidates(t+1).
+        inputs_ready (pipelined): the window tensors are complete already (written before earlier work of the current stream was
+        enqueued, or on the chain stream as ``plan_async`` does); otherwise the chain stream first waits for the current
+        stream -- i.e. for the previous step's candidate pass, which costs the overlap of the policy pass."""
         cfg = self.cfg
         N, T, A = int(cfg.action_samples), self.T, self.A
-        if eps is None:
-            # same shapes the reference draws: dist.sample((N,)) over loc (1,T,1,A) (learner.py:285) /
-            # randn((N,h,A)) for the fixed-variance variant (learner.py:157-163); identical on every rank
-            eps = self._eps((N, h, A)) if mode == capi.MODE_NOISE else self._eps((N, 1, T, 1, A))
-        eps = eps.reshape(N, -1, A)
+        if not pipelined:
+            self._drain()  # a serial step runs its fp32 chains on the current stream: nothing pipelined may still be using them
+        sl = (slot if slot is not None else self._acquire_slot()).ready(self)
+        tk = PlanTicket(self, sl, mode, states, actions, rewards, float(rtg), int(h), float(lmbda), returns)
+        sl.owner = tk
+        main = torch.cuda.current_stream(self.device)
+        chain = self._chain_stream() if pipelined else None
+        tk.chain = chain
+        tk.tchain = self._tchain if pipelined else None
+        hd = self.handle
+        # what the caller gets back (and the re-score's merged vector / candidate list) lives in the CURRENT stream's memory
+        # pool: the caller consumes it there, so that is where its blocks must be recycled
+        tk.outbuf = hd.select_buffers(N)
+        if self.rescore != "none":
+            tk.er = torch.empty((N,), dtype=torch.float32, device=self.device)
+            tk.top = torch.empty((1024,), dtype=torch.int32, device=self.device)
+        with (torch.cuda.stream(chain) if chain is not None else contextlib.nullcontext()):
+            if chain is not None and not inputs_ready:
+                sl.ev_in.record(main)
+                chain.wait_event(sl.ev_in)
+            # the variates of the step in the serial order of draws: eps, then the multinomial's exponentials.  (Pipelined:
+            # drawn on the chain stream -- the generator's state advances on the host in issue order either way -- so that
+            # nothing but the candidate pass sits on the current stream.)
+            if eps is None:
+                # same shapes the reference draws: dist.sample((N,)) over loc (1,T,1,A) (learner.py:285) /
+                # randn((N,h,A)) for the fixed-variance variant (learner.py:157-163); identical on every rank
+                eps = self._eps((N, h, A)) if mode == capi.MODE_NOISE else self._eps((N, 1, T, 1, A))
+            tk.eps = eps = eps.reshape(N, -1, A)
+            tk.expo = torch.empty((N,), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
+            hd.policy_pass(mode, states, actions, rewards, h, tk.rtg, slot=sl.i, returns=returns)
+            if chain is not None:
+                sl.ev_pol.record(chain)
+        if chain is not None:
+            main.wait_event(sl.ev_pol)
         begin, count = mdist.shard_range(N, self.rank, self.world)
-        res = self.handle.plan_step(mode, states, actions, rewards, eps, h, rtg, float(lmbda), float(cfg.discount),
-                                    N, begin, count, precision=self.precision)
+        res = hd.candidate_pass(mode, states, actions, rewards, eps, h, tk.lmbda, float(cfg.discount), N, begin, count,
+                                precision=self.precision, slot=sl.i)
         er, a0 = res["expect_return"], res["sample_actions"][:, 0]
         er, a0 = mdist.gather_candidates(er, a0, N, self.group)
-        top = sel = None
+        if self._bf16_offset and self.precision == capi.PREC_BF16:
+            er = er + self._bf16_offset
+        tk.res, tk.er_b, tk.a0 = res, er, a0
+        if chain is not None:
+            sl.ev_cand.record(main)
+            prev, self._pending = self._pending, tk
+            if prev is not None and not prev.tail_enqueued:
+                self._enqueue_tail(prev)
+        else:
+            self._enqueue_tail(tk)
+        return tk
+
+    def _rescore_args(self, tk):
+        return (tk.mode, tk.states, tk.actions, tk.rewards, tk.eps), (tk.h, tk.rtg, tk.lmbda, float(self.cfg.discount))
+
+    def _on(self, tk):
+        """Context of the stream the step's tail runs on."""
+        return torch.cuda.stream(tk.tchain) if tk.tchain is not None else contextlib.nullcontext()
+
+    def _enqueue_tail(self, tk):
+        """Re-score + select of a step (replicated on every rank: identical inputs => identical result)."""
+        cfg, hd, sl = self.cfg, self.handle, tk.slot
+        N = tk.er_b.numel()
+        tk.tail_enqueued = True
+        if tk.tchain is not None:
+            tk.tchain.wait_event(sl.ev_cand)  # (the candidate pass waited for the policy pass: ordered behind both)
+        with self._on(tk):
+            if self.rescore == "none":
+                tk.er = tk.er_b
+            else:
+                rs, tail = self._rescore_args(tk)
+                if self.rescore == "bound":
+                    if self._delta is None:
+                        self._delta = self._calibrate(tk)
+                    kmax = max(min(self.rescore_max, N - 1 if N > 1 else 1), 1)
+                    kmin = max(min(max(self.rescore_min, self._kspec), N, kmax), 1)
+                else:
+                    kmax = kmin = max(min(self.rescore_topk, N, hd.max_rescore), 1)
+                tk.kmin, tk.kmax, tk.delta = kmin, kmax, self._delta
+                # The kmax + 1 best candidates by bf16 score, best first.  The set that has to be re-scored is a prefix of this
+                # list whose length only the re-score itself can tell (m3pc_rescore_merge's certificate), so its first kmin
+                # entries are re-scored, merged and the select is enqueued BEFORE anybody reads anything: the device never
+                # waits for the host.  _finish reads the certificate (host-mapped statistics, no stream synchronisation) and
+                # only when it asks for more the rest is re-scored and merge + select are repeated on the same variates.
+                hd.topk_window(tk.er_b, kmax, kmin, 0.0, top=tk.top, stats=sl.stats, top_scores=sl.b_top)
+                hd.rescore(*rs, tk.top[:kmin], *tail, N, slot=sl.i, out=sl.f_top[:kmin], want_actions=False)
+                tk.n_done = kmin
+                self._merge(tk, kmin)
+            tk.sel = hd.select(tk.er, tk.a0, float(cfg.temperature), tk.expo, out=tk.outbuf)
+            if tk.tchain is not None:
+                sl.ev_done.record(tk.tchain)
+
+    def _merge(self, tk, n, index=None, b_top=None, f_top=None):
+        sl = tk.slot
+        tk.seq_mrg = sl.hs_mrg.next_seq()
+        tk.delta = self._delta if self.rescore == "bound" else 0.0
+        self.handle.rescore_merge(tk.er_b, tk.top if index is None else index, n, sl.b_top if b_top is None else b_top,
+                                  sl.f_top if f_top is None else f_top, delta=tk.delta, merged=tk.er, stats=sl.mstats,
+                                  host_stats=sl.hs_mrg.buf, seq=tk.seq_mrg)
+
+    def _finish(self, tk):
+        """Resolve a ticket: enqueue what is still missing, read the re-score's certificate, finish the re-score if it asks
+        for more candidates, and order the current stream behind the step."""
+        if tk.out is not None:
+            return tk.out
+        cfg, hd, sl = self.cfg, self.handle, tk.slot
+        if not tk.tail_enqueued:
+            if self._pending is tk:
+                self._pending = None
+            self._enqueue_tail(tk)
         extra = {}
-        # the re-score is replicated on every rank (identical inputs => identical result): candidates chosen from the
-        # gathered scores, fp32 candidate pass on them, scores written back in place
-        if self.rescore == "topk" and self.rescore_topk > 0:
-            top = self.handle.rescore_topk(mode, states, actions, rewards, eps, er, min(self.rescore_topk, N), h, rtg,
-                                           float(lmbda), float(cfg.discount))
-        elif self.rescore == "bound":
-            rs = (mode, states, actions, rewards, eps)
-            tail = (h, rtg, float(lmbda), float(cfg.discount))
-            if self._delta is None:
-                self._delta = self._calibrate(er, rs, tail, N)
-            kmax, kmin = min(self.rescore_max, N - 1 if N > 1 else 1), min(max(self.rescore_min, self._kspec), N)
-            kmin = max(min(kmin, kmax), 1)
-            # The candidates come sorted by bf16 score, so the set inside the window is a prefix of the list and its first
-            # kmin entries are re-scored whatever the count turns out to be: that re-score and the select are enqueued
-            # BEFORE the one host read of the step (how many candidates are inside the window; pinned-memory spin, no
-            # stream sync), so the device never waits for the host.  Only when more than kmin candidates are inside the
-            # window the rest is re-scored and the select repeated on the same variates.
-            cand, ticket = self.handle.topk_window_issue(er, max(kmax, 1), kmin, 2.0 * self._delta)
-            if os.environ.get("M3PC_NO_SPEC"):  # A/B switch: the host read first (the device idles for the round trip)
-                self.handle.topk_window_wait(ticket)
-            self.handle.rescore_listed(mode, states, actions, rewards, eps, er, cand[:kmin], *tail)
-            expo = torch.empty((N,), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
-            sel = self.handle.select(er, a0, float(cfg.temperature), expo)
-            st = self.handle.topk_window_wait(ticket)
-            n_re = int(st[0])
-            if n_re > kmin:
-                self.handle.rescore_listed(mode, states, actions, rewards, eps, er, cand[kmin:n_re].contiguous(), *tail)
-                sel = self.handle.select(er, a0, float(cfg.temperature), expo)
-            top = cand[:n_re]
+        top = None
+        if self.rescore == "bound":
+            N = tk.er_b.numel()
+            kmin, kmax = tk.kmin, tk.kmax
+            saturated = False
+            n_first_need = None
+            while True:
+                shift, dev, need, margin = sl.hs_mrg.wait(tk.seq_mrg, sl.mstats)
+                need = int(need)
+                if n_first_need is None:
+                    n_first_need = need
+                redo = False
+                # delta bounds the deviation of (bf16 - fp32) from the common shift: every step checks it on its re-scored set
+                # and raises it when 1.5 x what it saw is more (the same numbers, hence the same decision, on every rank)
+                if self._delta_fixed is None and 1.5 * dev > self._delta:
+                    self._delta = 1.5 * dev
+                    self.delta_grown += 1
+                    redo = tk.n_done < N and not saturated
+                if saturated or tk.n_done >= N:
+                    break
+                with self._on(tk):
+                    if need > tk.n_done and not redo:
+                        if need <= kmax:
+                            rs, tail = self._rescore_args(tk)
+                            hd.rescore(*rs, tk.top[tk.n_done : need], *tail, N, slot=sl.i, out=sl.f_top[tk.n_done : need],
+                                       want_actions=False)
+                            tk.n_done = need
+                            redo = True
+                        else:
+                            top = self._rescore_window_set(tk, need)
+                            saturated = True
+                            continue
+                    if not redo:
+                        break
+                    self._merge(tk, tk.n_done)
+                    tk.sel = hd.select(tk.er, tk.a0, float(cfg.temperature), tk.expo, out=tk.outbuf)
+                    if tk.tchain is not None:
+                        sl.ev_done.record(tk.tchain)
+            n_re = int(top.numel()) if top is not None else tk.n_done
+            if top is None:
+                top = tk.top[:n_re]
             # the size of the first (unconditional) re-score follows the workload: a second pass costs a whole fp32 chain
             # (~0.3 ms), four more candidates in the first ~0.02-0.05 ms -- grown when more than a fifth of the recent steps
             # needed the second pass, shrunk again when (almost) none did.  Same decisions on every rank (same counts).
@@ -189,66 +433,129 @@ class HipPlanner:
                 self._kspec, self._exceed = min(kmax, kmin + 4), 0.05
             elif self._exceed < 0.005 and self._kspec > self.rescore_min:
                 self._kspec, self._exceed = max(self.rescore_min, self._kspec - 4), 0.05
-            extra = dict(n_rescored=n_re, n_in_window=int(st[3]), min_margin_outside=float(st[1]), delta=self._delta, n_first=kmin)
-        # torch.multinomial(p, 1) == argmax(p / q), q ~ Exp(1) from the same generator (ATen's
-        # multinomial fast path); drawing q here and finishing inside the select kernel gives the same index
-        if sel is None:
-            expo = torch.empty((N,), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
-            sel = self.handle.select(er, a0, float(cfg.temperature), expo)
-        p, eval_action, argmax, sample_idx, sample_action = sel
-        self.last = dict(expect_return=er, p=p, argmax=argmax, sample_idx=sample_idx, loc=res["loc"], std=res["std"],
-                         sample_actions=res["sample_actions"], eps=eps, topk=top, **extra)
-        return sample_action, eval_action
+            extra = dict(n_rescored=n_re, n_in_window=n_first_need, min_margin_outside=float(margin), delta=tk.delta, n_first=kmin,
+                         saturated=saturated, shift=shift, deviation=dev)
+        elif self.rescore == "topk":
+            top = tk.top[: tk.kmin]
+        if tk.chain is not None:
+            torch.cuda.current_stream(self.device).wait_event(sl.ev_done)
+        p, eval_action, argmax, sample_idx, sample_action = tk.sel
+        res = tk.res
+        self.last = dict(expect_return=tk.er, expect_return_bf16=tk.er_b if self.rescore != "none" else None, p=p, argmax=argmax,
+                         sample_idx=sample_idx, loc=res["loc"], std=res["std"], sample_actions=res["sample_actions"], eps=tk.eps,
+                         topk=top, eval_action=eval_action, sample_action=sample_action, horizon=tk.h, **extra)
+        tk.info = self.last
+        tk.out = (sample_action, eval_action)
+        if sl.owner is tk:
+            sl.owner = None
+        return tk.out
 
-    def _calibrate(self, er_bf16, rs, tail, N, n_cal: int = 64) -> float:
+    def _rescore_window_set(self, tk, need):
+        """The certificate asks for more candidates than the rescore_max the list holds: re-score the whole set -- the `need`
+        best candidates by bf16 score -- in chunks of the chain workspace (or, beyond 1024 of them, every candidate in fp32).
+        Slow path, taken only when the bf16 noise exceeds the score spread.  Called inside the tail's stream context."""
+        cfg, hd, sl = self.cfg, self.handle, tk.slot
+        N = tk.er_b.numel()
+        if not self._warned_saturated:
+            self._warned_saturated = True
+            warnings.warn(f"m3pc_amd: {need} candidates may still hold the fp32 arg-max (delta={tk.delta:.3g}, rescore_max="
+                          f"{self.rescore_max}); re-scoring the whole window set in fp32 (slow path)")
+        rs, tail = self._rescore_args(tk)
+        cnt = min(need, N)
+        if cnt <= 1024:
+            vals, idx = torch.topk(tk.er_b, cnt)
+            idx = idx.to(torch.int32).contiguous()
+            f = torch.empty((cnt,), dtype=torch.float32, device=self.device)
+            cap = hd.max_rescore
+            for c0 in range(0, cnt, cap):
+                c1 = min(cnt, c0 + cap)
+                hd.rescore(*rs, idx[c0:c1], *tail, N, slot=sl.i, out=f[c0:c1], want_actions=False)
+            self._merge(tk, cnt, index=idx, b_top=vals.contiguous(), f_top=f)
+            tk.keep = (vals, idx, f)
+            tk.top[:cnt].copy_(idx)
+            idx = tk.top[:cnt]
+            tk.n_done = cnt
+        else:
+            # everything: one fp32 candidate pass in the candidate workspace (nothing else may be using it)
+            torch.cuda.synchronize(self.device)
+            begin, count = mdist.shard_range(N, self.rank, self.world)
+            r32 = hd.candidate_pass(tk.mode, tk.states, tk.actions, tk.rewards, tk.eps, tk.h, tk.lmbda, float(cfg.discount), N,
+                                    begin, count, precision=capi.PREC_FP32, slot=sl.i)
+            er32, _ = mdist.gather_candidates(r32["expect_return"], r32["sample_actions"][:, 0], N, self.group)
+            idx = torch.arange(N, dtype=torch.int32, device=self.device)
+            tk.n_done = N
+            # (a merge of the best entry with itself: shift 0, deviation 0 -- keeps the statistics protocol of _finish alive)
+            best = torch.argmax(er32).to(torch.int32).reshape(1)
+            bval = er32.max().reshape(1).contiguous()
+            tk.keep = (er32, best, bval)
+            self.handle.rescore_merge(er32.contiguous(), best, 1, bval, bval, delta=0.0, merged=tk.er, stats=sl.mstats,
+                                      host_stats=sl.hs_mrg.buf, seq=self._next_mrg_seq(tk))
+        tk.sel = hd.select(tk.er, tk.a0, float(cfg.temperature), tk.expo, out=tk.outbuf)
+        if tk.tchain is not None:
+            sl.ev_done.record(tk.tchain)
+        return idx
+
+    def _next_mrg_seq(self, tk):
+        tk.seq_mrg = tk.slot.hs_mrg.next_seq()
+        return tk.seq_mrg
+
+    def _calibrate(self, tk) -> float:
         """delta of the bound-driven re-score: fp32 scores of n_cal candidates (a fixed pseudo-random subset, the same
         on every rank) against their bf16 scores; 1.5 x the largest deviation of (bf16 - fp32) from its median."""
+        N = tk.er_b.numel()
+        rs, tail = self._rescore_args(tk)
         g = torch.Generator().manual_seed(0x5eed)
-        ids = torch.randperm(N, generator=g)[: min(n_cal, N)].to(torch.int32).to(self.device)
-        f32, _ = self.handle.rescore(*rs, ids, tail[0], tail[1], tail[2], tail[3], N)
-        d = er_bf16[ids.long()] - f32
+        ids = torch.randperm(N, generator=g)[: min(self._n_cal, N, self.handle.max_rescore)].to(torch.int32).to(self.device)
+        f32, _ = self.handle.rescore(*rs, ids, *tail, N, slot=tk.slot.i, want_actions=False)
+        d = tk.er_b[ids.long()] - f32
         dev = float((d - d.median()).abs().max())
         return max(1.5 * dev, 1e-6 * float(f32.abs().max()), 1e-30)
 
-    @staticmethod
-    def _split(trajectory):
+    def _split(self, trajectory):
+        """(states, actions, rewards, rtg, returns_row) of a reference-style trajectory dict of (1,T,D) tensors.  A window
+        whose returns are constant (what action_sample builds, learner.py:368-385) is passed as one float; any other returns
+        row goes to the library as it is (rtg_guiding consumes whatever trajectory["returns"] holds, learner.py:272-293)."""
         s, a, r = trajectory["states"][0], trajectory["actions"][0], trajectory["rewards"][0]
         rtg = trajectory.get("_rtg")
+        returns = None
         if rtg is None:
-            ret = trajectory["returns"].reshape(-1)  # device sync; action_sample passes _rtg
-            rtg = float(ret[0])
-            # the library conditions on ONE return-to-go (what action_sample builds, learner.py:368-385); a window with
-            # varying returns is legal in the reference but not representable here: refuse it instead of mis-planning
-            if not bool((ret == ret[0]).all()):
-                raise ValueError("trajectory['returns'] must be constant over the window (rtg_guiding is called by "
-                                 "action_sample with a constant return-to-go, learner.py:368-385)")
-        return s.float().contiguous(), a.float().contiguous(), r.float().contiguous(), float(rtg)
+            ret = trajectory["returns"].reshape(-1)
+            if ret.dtype not in (torch.float32, torch.float64):
+                ret = ret.float()
+            returns = ret.to(self.device).contiguous()
+            rtg = 0.0
+        return s.float().contiguous(), a.float().contiguous(), r.float().contiguous(), float(rtg), returns
 
     @torch.no_grad()
     def rtg_guiding(self, trajectory: Dict[str, torch.Tensor], h: int, lmbda: float = 0.6):
         """learner.py:271-327."""
-        s, a, r, rtg = self._split(trajectory)
-        return self._guide(capi.MODE_RTG, s, a, r, rtg, h, lmbda)
+        s, a, r, rtg, ret = self._split(trajectory)
+        return self._guide(capi.MODE_RTG, s, a, r, rtg, h, lmbda, returns=ret)
 
     @torch.no_grad()
     def critic_lambda_guiding(self, trajectory: Dict[str, torch.Tensor], h: int, lmbda: float):
         """learner.py:211-268."""
-        s, a, r, rtg = self._split(trajectory)
-        return self._guide(capi.MODE_CRITIC, s, a, r, rtg, h, lmbda)
+        s, a, r, rtg, ret = self._split(trajectory)
+        return self._guide(capi.MODE_CRITIC, s, a, r, rtg, h, lmbda, returns=ret)
 
     @torch.no_grad()
     def noise_adding_lambda(self, trajectory: Dict[str, torch.Tensor], h: int, lmbda: float):
         """learner.py:142-208."""
-        s, a, r, rtg = self._split(trajectory)
-        return self._guide(capi.MODE_NOISE, s, a, r, rtg, h, lmbda)
+        s, a, r, rtg, ret = self._split(trajectory)
+        return self._guide(capi.MODE_NOISE, s, a, r, rtg, h, lmbda, returns=ret)
+
+    def _returns_tokens(self, rtg, returns=None):
+        """(1,T,1) returns tokens: the caller's row, or the constant return-to-go in float64 (learner.py:371-374)."""
+        if returns is None:
+            returns = torch.full((1, self.T, 1), rtg, dtype=torch.float64, device=self.device)
+        return self.handle.tokenize(capi.RETURNS, returns.reshape(1, self.T, 1))
 
     @torch.no_grad()
     def mtm_sampling(self, trajectory: Dict[str, torch.Tensor], h: int):
         """learner.py:103-115: one return-conditioned policy pass, no planning."""
-        s, a, r, rtg = self._split(trajectory)
+        s, a, r, rtg, ret = self._split(trajectory)
         T = self.T
-        toks = [self.handle.tokenize(capi.STATES, s[None]), a[None], None,
-                self.handle.tokenize(capi.RETURNS, torch.full((1, T, 1), rtg, dtype=torch.float64, device=self.device))]
+        toks = [self.handle.tokenize(capi.STATES, s[None]), a[None], None, self._returns_tokens(rtg, ret)]
         from .masks import create_rcbc_mask, mask_rows
         out = self.handle.forward(toks, mask_rows(create_rcbc_mask(T, "cpu", T - h)), want=("actions",))
         mu, sd = out["actions"]
@@ -264,13 +571,11 @@ class HipPlanner:
         WHOLE window taken from the buffer (future rows are way-points), shortened near the 1000-step end."""
         horizon, return_to_go = self._goal_window_host(sequence_history, rtg, percentage, self._host)
         dev = torch.from_numpy(self._host).to(self.device)
-        states = dev[:, : self.S].contiguous()
-        actions = dev[:, self.S : self.S + self.A].contiguous()
-        rewards = dev[:, self.S + self.A :].contiguous()
+        states, actions, rewards = self._blocks(dev)
         return states, actions, rewards, horizon, return_to_go
 
-    def _goal_window_host(self, sequence_history, rtg, percentage, buf):
-        """Host half of ``assemble_goal_window``: fills ``buf`` (T, S+A+1) and returns (horizon, rtg)."""
+    def _goal_window_host(self, sequence_history, rtg, percentage, flat):
+        """Host half of ``assemble_goal_window``: fills the flat window buffer and returns (horizon, rtg)."""
         T = self.T
         horizon = int(self.cfg.horizon)
         end_idx = int(sequence_history["path_length"])
@@ -280,18 +585,14 @@ class HipPlanner:
         if end_idx + horizon > 1000:
             smart = smart - (end_idx + horizon - 1000)
         hl = T - horizon + 1
-        buf[:] = 0.0
+        flat[:] = 0.0
+        bs, ba, br = self._blocks(flat)
         lo = end_idx - hl + 1
-        buf[:hl, self.S : self.S + self.A] = sequence_history["actions"][lo : end_idx + 1]
-        buf[:hl, self.S + self.A :] = np.asarray(sequence_history["rewards"][lo : end_idx + 1]).reshape(hl, 1)
-        buf[:hl, : self.S] = sequence_history["observations"][lo : end_idx + 1]
-        buf[:smart, : self.S] = sequence_history["observations"][lo : lo + T]
-        if rtg is not None:
-            return_to_go = float(rtg)
-        else:
-            st = self.tokenizer_manager.tokenizers["returns"].stats
-            return_to_go = float(np.asarray(st.min + (st.max - st.min) * percentage).reshape(-1)[0])
-        return horizon, return_to_go
+        ba[:hl] = sequence_history["actions"][lo : end_idx + 1]
+        br[:hl] = np.asarray(sequence_history["rewards"][lo : end_idx + 1]).reshape(hl, 1)
+        bs[:hl] = sequence_history["observations"][lo : end_idx + 1]
+        bs[:smart] = sequence_history["observations"][lo : lo + T]
+        return horizon, self._rtg_value(rtg, percentage)
 
     def _goal_tokens(self, states, actions, rewards, rtg):
         T = self.T
@@ -338,6 +639,18 @@ class HipPlanner:
         return self._policy_from(toks, create_fid_mask(T, "cpu", idx), h, eval)
 
     @torch.no_grad()
+    def action_piid_list_sample(self, sequence_history, percentage=1.0, horizon=4, plan=True, eval=False, rtg=None):
+        """zeroshot learner.py:263-370 (goal_mask "piid_allout", unseen.py:146-148): the piid arithmetic, but the result --
+        always the MEAN of the action distribution at T-h, eval or not -- is left in ``self.action_list`` (one entry: the
+        reference's further entries are commented out at 366-370) for the rollout loop to pop (learner.py:559-568).
+        Returns None, as the reference does."""
+        if eval:
+            assert rtg is not None
+        self.action_list = [self.action_piid_sample(sequence_history, percentage, horizon, plan, eval=True,
+                                                    rtg=self._rtg_value(rtg, percentage))]
+        return None
+
+    @torch.no_grad()
     def action_piid_sample_batch(self, sequence_histories, percentage=1.0, eval=True, rtg=None):
         """E independent goal-reaching windows per launch (BASELINE config 5 / SURVEY §8 f1): the reference plans one
         env per call (zeroshot learner.py:151-261, unseen.py rollout loop); here the windows that share a horizon go
@@ -347,7 +660,8 @@ class HipPlanner:
             assert rtg is not None
         from .masks import create_fid_mask, create_pi_mask, mask_rows
         T, E = self.T, len(sequence_histories)
-        host = np.empty((E, T, self.S + self.A + 1), dtype=np.float32)
+        S, A = self.S, self.A
+        host = np.empty((E, T * (S + A + 1)), dtype=np.float32)
         meta = [self._goal_window_host(hst, rtg, percentage, host[i]) for i, hst in enumerate(sequence_histories)]
         dev = torch.from_numpy(host).to(self.device)  # one packed H2D copy for all windows
         out = torch.empty((E, self.A), dtype=torch.float32, device=self.device)
@@ -356,9 +670,9 @@ class HipPlanner:
             ids = [i for i, m in enumerate(meta) if m[0] == h]
             idx = T - h
             sel = dev if len(ids) == E else dev[torch.tensor(ids, device=self.device)]
-            s = sel[:, :, : self.S].contiguous()
-            a = sel[:, :, self.S : self.S + self.A].contiguous()
-            r = sel[:, :, self.S + self.A :].contiguous()
+            s = sel[:, : T * S].reshape(-1, T, S).contiguous()
+            a = sel[:, T * S : T * (S + A)].reshape(-1, T, A).contiguous()
+            r = sel[:, T * (S + A) :].reshape(-1, T, 1).contiguous()
             ret = torch.tensor([meta[i][1] for i in ids], dtype=torch.float64, device=self.device)[:, None, None].expand(-1, T, 1)
             toks = [self.handle.tokenize(capi.STATES, s), a, self.handle.tokenize(capi.REWARDS, r),
                     self.handle.tokenize(capi.RETURNS, ret.contiguous())]
@@ -379,25 +693,83 @@ class HipPlanner:
 
     # ---------------------------------------------------------------------------------------- batched planning
     @torch.no_grad()
-    def action_sample_batch(self, sequence_histories, percentage=1.0, eval=False, rtg=None):
-        """``action_sample(history, plan=True)`` for E environments in ONE pass of the kernels.  The
-        reference steps one environment at a time (replay_buffer.py:204-232, learner.py:681-691: one action_sample per env
-        step); here the E windows share the policy pass (batch E), one candidate pass over E x N rows, one fp32 re-score
-        pass over every window's re-score set, and E select calls.  Per window the arithmetic is that of the single-window
-        call (same kernels on more rows; split-K decisions of the fp32 policy pass may differ in the last bits).
-        ``rtg``: None, a float, or one value per window.  Windows are grouped by effective horizon (early-episode windows
-        plan with horizon T - end_idx, learner.py:342-345).  Returns (E, A).  Needs max_batch >= E and
-        max_candidates >= E * N at construction (``HipPlanner(..., max_batch=E, max_windows=E)``)."""
+    def plan_async(self, sequence_history, percentage=1.0, eval=False, rtg=None) -> "PlanTicket":
+        """``action_sample(history, plan=True)`` without waiting for it: enqueues the plan step of one window and returns a
+        ticket; ``ticket.result()`` gives what ``action_sample`` returns (on the device, ordered on the current stream).
+        Up to ``capi.SLOTS - 1`` tickets may be outstanding; the windows must be independent of each other's results (several
+        environments / evaluation episodes: learner.py:645-741 runs 20 of them one after the other).  Every step's result
+        is bit-identical to the serial call; the draws (eps, multinomial) are taken from the generator in issue order."""
+        if eval:
+            assert rtg is not None
+        guidance = self.cfg.plan_guidance
+        assert guidance in _MODES, guidance
+        lmbda = 0.6 if guidance == "rtg_guiding" else float(self.cfg.lmbda)  # learner.py:405-407
+        sl = self._acquire_slot().ready(self)
+        h, return_to_go = self._window_host(sequence_history, rtg, percentage, sl.win_np)
+        # pinned per-slot staging (the slot is free, so its last copy is done), copied on the CHAIN stream: the current
+        # stream is in order behind the previous step's candidate pass, the chain stream is not
+        with torch.cuda.stream(self._chain_stream()):
+            dev = sl.win.to(self.device, non_blocking=True)
+        states, actions, rewards = self._blocks(dev)
+        tk = self._issue(_MODES[guidance], states, actions, rewards, return_to_go, h, lmbda, pipelined=True, slot=sl,
+                         inputs_ready=True)
+        tk.eval = bool(eval)
+        tk.keep_window = dev
+        return tk
+
+    def flush(self):
+        """Enqueue whatever a pipelined step still holds back (the tail of the last ticket)."""
+        if self._pending is not None and not self._pending.tail_enqueued:
+            tk, self._pending = self._pending, None
+            self._enqueue_tail(tk)
+
+    @torch.no_grad()
+    def action_sample_batch(self, sequence_histories, percentage=1.0, eval=False, rtg=None, lockstep: bool = False):
+        """``action_sample(history, plan=True)`` for E environments.  The reference steps one environment at a
+        time (replay_buffer.py:204-232, learner.py:681-691: one action_sample per env step, the action read back each time).
+        Default: the E windows are E plan steps issued back to back through ``plan_async`` -- ``pipeline_depth`` of them in
+        flight, staggered: window i+1's policy pass and window i-1's re-score + select run on the chain stream under window
+        i's candidate pass.  Per window the result is bit-identical to the single-window call (same kernels, same rows, same
+        draws in window order), first-layer history sharing included.
+        ``lockstep=True``: the round-2 form -- one policy pass at batch E, ONE candidate pass over E x N rows, one fp32
+        re-score pass over all windows' sets (needs ``HipPlanner(..., max_batch=E, max_windows=E)``; windows grouped by
+        effective horizon; no history sharing between windows).
+        ``rtg``: None, a float, or one value per window.  Returns (E, A)."""
+        if lockstep:
+            return self._action_sample_lockstep(sequence_histories, percentage, eval, rtg)
+        E, A = len(sequence_histories), self.A
+        rtgs = [rtg] * E if (rtg is None or np.isscalar(rtg)) else list(rtg)
+        out = torch.empty((E, A), dtype=torch.float32, device=self.device)
+        info = [None] * E
+        flight = []
+
+        def resolve():
+            i, tk = flight.pop(0)
+            sa, ev = tk.pair()
+            out[i] = ev if eval else sa[0]
+            info[i] = tk.info
+
+        for i, hst in enumerate(sequence_histories):
+            flight.append((i, self.plan_async(hst, percentage, eval, rtgs[i])))
+            if len(flight) > self.pipeline_depth:
+                resolve()
+        while flight:
+            resolve()
+        self.last = dict(windows=info, delta=self._delta)
+        return out
+
+    def _action_sample_lockstep(self, sequence_histories, percentage=1.0, eval=False, rtg=None):
+        self._drain()
         cfg = self.cfg
         guidance = cfg.plan_guidance
         assert guidance in _MODES, guidance
         mode = _MODES[guidance]
         lmbda = 0.6 if guidance == "rtg_guiding" else float(cfg.lmbda)  # learner.py:405-407
-        E, T, A, N = len(sequence_histories), self.T, self.A, int(cfg.action_samples)
+        E, T, S, A, N = len(sequence_histories), self.T, self.S, self.A, int(cfg.action_samples)
         rtgs = [rtg] * E if (rtg is None or np.isscalar(rtg)) else list(rtg)
         if eval:
             assert all(r is not None for r in rtgs)
-        host = np.empty((E, T, self.S + self.A + 1), dtype=np.float32)
+        host = np.empty((E, T * (S + A + 1)), dtype=np.float32)
         meta = []
         for i, hst in enumerate(sequence_histories):
             meta.append(self._window_host(hst, rtgs[i], percentage, host[i]))
@@ -407,21 +779,22 @@ class HipPlanner:
         for h in sorted({m[0] for m in meta}):
             ids = [i for i, m in enumerate(meta) if m[0] == h]
             sel = dev if len(ids) == E else dev[torch.tensor(ids, device=self.device)]
-            s = sel[:, :, : self.S].contiguous()
-            a = sel[:, :, self.S : self.S + self.A].contiguous()
-            r = sel[:, :, self.S + self.A :].contiguous()
+            s = sel[:, : T * S].reshape(-1, T, S).contiguous()
+            a = sel[:, T * S : T * (S + A)].reshape(-1, T, A).contiguous()
+            r = sel[:, T * (S + A) :].reshape(-1, T, 1).contiguous()
             Eg = len(ids)
             eps = self._eps((Eg, N, h, A)) if mode == capi.MODE_NOISE else self._eps((Eg, N, T, A))
             res = self.handle.plan_step_batch(mode, s, a, r, [meta[i][1] for i in ids], eps, h, lmbda, float(cfg.discount), N,
                                               precision=self.precision)
             er, acts = res["expect_return"], res["sample_actions"]
             stats_h = None
+            merged = [er[w] for w in range(Eg)]
             if self.rescore != "none":
                 smode = capi.MODE_RTG if mode == capi.MODE_RTG else capi.MODE_CRITIC
                 if self.rescore == "bound":
-                    if self._delta is None:  # calibrate on window 0 of the group: 64 of its candidates in fp32
+                    if self._delta is None:  # calibrate on window 0 of the group: n_cal of its candidates in fp32
                         g = torch.Generator().manual_seed(0x5eed)
-                        cid = torch.randperm(N, generator=g)[: min(64, N)].to(self.device)
+                        cid = torch.randperm(N, generator=g)[: self._n_cal].to(self.device)
                         f32 = self.handle.score_actions(smode, s[0], a[0], r[0], acts[0, cid], None, h, lmbda, float(cfg.discount))
                         d = er[0, cid] - f32
                         self._delta = max(1.5 * float((d - d.median()).abs().max()), 1e-6 * float(f32.abs().max()), 1e-30)
@@ -436,34 +809,21 @@ class HipPlanner:
                 pick = torch.cat([tops[w][: counts[w]].long() for w in range(Eg)])
                 wsel = torch.cat([torch.full((counts[w],), w, dtype=torch.int32, device=self.device) for w in range(Eg)])
                 f32 = self.handle.score_actions(smode, s, a, r, acts[wsel.long(), pick], wsel, h, lmbda, float(cfg.discount))
-                er[wsel.long(), pick] = f32
+                off = 0
+                for w in range(Eg):  # fp32 scores for the set, shift-corrected bf16 scores for the rest (m3pc_rescore_merge)
+                    ix = tops[w][: counts[w]].contiguous()
+                    merged[w], _ = self.handle.rescore_merge(er[w], ix, counts[w], er[w][ix.long()].contiguous(),
+                                                             f32[off : off + counts[w]].contiguous())
+                    off += counts[w]
             for j, i in enumerate(ids):
                 expo = torch.empty((N,), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
-                p, ev, am, si, sa = self.handle.select(er[j], acts[j, :, 0], float(cfg.temperature), expo)
+                p, ev, am, si, sa = self.handle.select(merged[j], acts[j, :, 0], float(cfg.temperature), expo)
                 out[i] = ev if eval else sa[0]
-                info[i] = dict(expect_return=er[j], argmax=am, sample_idx=si, eval_action=ev, sample_action=sa, horizon=h,
+                info[i] = dict(expect_return=merged[j], argmax=am, sample_idx=si, eval_action=ev, sample_action=sa, horizon=h,
                                n_rescored=None if stats_h is None else int(stats_h[j, 0]),
                                min_margin_outside=None if stats_h is None else float(stats_h[j, 1]))
         self.last = dict(windows=info, delta=self._delta)
         return out
-
-    def _window_host(self, sequence_history, rtg, percentage, buf):
-        """Host half of ``assemble_window`` into ``buf`` (T, S+A+1); returns (horizon, rtg)."""
-        T = self.T
-        horizon = int(self.cfg.horizon)
-        end_idx = int(sequence_history["path_length"])
-        if end_idx + horizon < T:
-            horizon = T - end_idx
-        hl = T - horizon + 1
-        buf[:] = 0.0
-        lo, hi = end_idx - hl + 1, end_idx + 1
-        buf[:hl, : self.S] = sequence_history["observations"][lo:hi]
-        buf[:hl, self.S : self.S + self.A] = sequence_history["actions"][lo:hi]
-        buf[:hl, self.S + self.A :] = np.asarray(sequence_history["rewards"][lo:hi]).reshape(hl, 1)
-        if rtg is not None:
-            return horizon, float(rtg)
-        st = self.tokenizer_manager.tokenizers["returns"].stats
-        return horizon, float(np.asarray(st.min + (st.max - st.min) * percentage).reshape(-1)[0])
 
     # ---------------------------------------------------------------------------------------- CEM refinement
     @torch.no_grad()
@@ -478,13 +838,13 @@ class HipPlanner:
                   candidates = clamp(mean + std * noise_i, -1, 1)
         Returns (sample_action (1,A): first action of candidate 0 after the last refit, as the legacy code returns;
                  eval_action (A,): first action of the final mean).  ``noise``: optional (iterations+1, N, h, A) normals."""
-        s, a, r, rtg = self._split(trajectory)
+        self._drain()
+        s, a, r, rtg, ret = self._split(trajectory)
         cfg = self.cfg
         N, T, A = int(cfg.action_samples), self.T, self.A
         mode = capi.MODE_CRITIC if cfg.plan_guidance == "critic_lambda_guiding" else capi.MODE_RTG
         lmbda = 0.6 if mode == capi.MODE_RTG else float(cfg.lmbda)
-        toks = [self.handle.tokenize(capi.STATES, s[None]), a[None], None,
-                self.handle.tokenize(capi.RETURNS, torch.full((1, T, 1), rtg, dtype=torch.float64, device=self.device))]
+        toks = [self.handle.tokenize(capi.STATES, s[None]), a[None], None, self._returns_tokens(rtg, ret)]
         from .masks import create_rcbc_mask, mask_rows
         mu, _ = self.handle.forward(toks, mask_rows(create_rcbc_mask(T, "cpu", T - h)), want=("actions",))["actions"]
         mean = torch.tanh(mu[0, T - h :])  # (h, A)
@@ -525,17 +885,30 @@ class HipPlanner:
 
 
 # ------------------------------------------------------------------------------------------------------
-def _param_version(module) -> int:
-    return sum(int(p._version) for p in module.parameters())
+def _versions(module):
+    """(name -> version counter of every state_dict entry, total over parameters + buffers).  In-place optimizer updates bump
+    a tensor's counter; the total catches modules whose state_dict hands out copies (their per-name counters never move)."""
+    try:
+        sd = module.state_dict(keep_vars=True)
+    except TypeError:
+        sd = module.state_dict()
+    per = {k: int(v._version) for k, v in sd.items()}
+    total = sum(int(p._version) for p in module.parameters()) + sum(int(b._version) for b in module.buffers())
+    return per, total
 
 
-def attach(learner, precision: str = "fp32", rescore_topk: int = 16, group=None):
+def attach(learner, precision: str = "fp32", rescore_topk: int = 16, group=None, generator: Optional[torch.Generator] = None,
+           **planner_kw):
     """Rebind the plan path of a reference-style ``Learner`` onto the HIP library.
 
     Reads: learner.cfg, learner.mtm (state_dict + config), learner.tokenizer_manager.tokenizers[k]
     (._data_mean, ._data_std, .normalize, .stats), learner.iql.qf (state_dict, obs_mean, obs_std).
     Afterwards learner.action_sample / rtg_guiding / critic_lambda_guiding / noise_adding_lambda /
-    mtm_sampling run on the GPU; everything else on the object is untouched."""
+    mtm_sampling (and the zero-shot calls) run on the GPU; everything else on the object is untouched.
+    ``group`` + ``generator``: shard the candidates over the ranks of a process group (every rank attaches its own
+    learner replica and passes a generator seeded identically); further keywords go to ``HipPlanner``.
+    Weights are followed per tensor: before each call the version counters of ``mtm`` / ``iql.qf`` are compared with the
+    ones uploaded last, and only the tensors that changed are sent (m3pc_load_weights re-packs what depends on them)."""
     mtm = learner.mtm
     mc = mtm.config
     toks = {}
@@ -549,32 +922,42 @@ def attach(learner, precision: str = "fp32", rescore_topk: int = 16, group=None)
                          q_state_dict=None if qf is None else qf.state_dict(),
                          obs_mean=None if qf is None else qf.obs_mean, obs_std=None if qf is None else qf.obs_std,
                          n_embd=mc.n_embd, n_head=mc.n_head, n_enc_layer=mc.n_enc_layer, n_dec_layer=mc.n_dec_layer,
-                         precision=precision, rescore_topk=rescore_topk, group=group)
-    state = {"mtm": _param_version(mtm), "qf": None if qf is None else _param_version(qf)}
+                         precision=precision, rescore_topk=rescore_topk, group=group, generator=generator, **planner_kw)
+    state = {"mtm": _versions(mtm), "qf": None if qf is None else _versions(qf)}
 
     def _sync():
-        v = _param_version(mtm)
-        if v != state["mtm"]:
-            planner.load_state_dict(mtm.state_dict())
-            state["mtm"] = v
+        per, total = _versions(mtm)
+        old_per, old_total = state["mtm"]
+        changed = [k for k, v in per.items() if old_per.get(k) != v]
+        if not changed and total != old_total:
+            changed = list(per.keys())  # something moved that the per-name counters do not see: send everything
+        if changed:
+            sd = mtm.state_dict()
+            planner.load_state_dict({k: sd[k] for k in changed})
+            state["mtm"] = (per, total)
         if qf is not None:
-            vq = _param_version(qf)
+            vq = _versions(qf)
             if vq != state["qf"]:
                 planner.load_critic(qf.state_dict(), qf.obs_mean, qf.obs_std)
                 state["qf"] = vq
+        planner.last_sync = changed
 
     def _wrap(name):
         fn = getattr(planner, name)
 
         def method(self, *a, **kw):
             _sync()
-            return fn(*a, **kw)
+            out = fn(*a, **kw)
+            if name == "action_piid_list_sample":  # the reference's rollout loop pops learner.action_list (learner.py:559-568)
+                self.action_list = planner.action_list
+            return out
 
         method.__name__ = name
         return types.MethodType(method, learner)
 
     for name in ("action_sample", "rtg_guiding", "critic_lambda_guiding", "noise_adding_lambda", "mtm_sampling",
-                 "action_piid_sample", "action_id_sample"):
+                 "action_piid_sample", "action_id_sample", "action_piid_list_sample", "plan_async", "action_sample_batch"):
         setattr(learner, name, _wrap(name))
     learner._hip_planner = planner
+    planner.sync = _sync
     return planner

@@ -2,7 +2,7 @@
 ``action_piid_sample`` / ``action_id_sample`` calls (research/zeroshot_omtm/learner.py:497-652) and how ``unseen.py``
 picks the mode (unseen.py:146-148) -- minus the simulator, which the caller owns.
 
-    follower = WaypointFollower(planner, "hopper-wiggle-f2.txt", index_jump=4, goal_mask="piid")
+    follower = WaypointFollower(planner, "hopper-wiggle-f2.txt", index_jump=4, goal_mask="piid")   # or "piid_allout" / "id"
     traj = follower.new_trajectory()
     obs = env.reset()
     for t in range(1000):
@@ -55,9 +55,6 @@ class WaypointFollower:
         self.planner = planner
         self.index_jump = int(index_jump if index_jump is not None else planner.cfg.index_jump)
         self.mode = goal_mode(goal_mask)
-        if self.mode == "list_stage":
-            raise NotImplementedError("goal_mask='piid_allout' (action_piid_list_sample, learner.py:263-370) is not on the "
-                                      "accelerated path; use 'piid' or 'id'")
         self.waypoints = hold_waypoints(np.array(load_waypoints(way_points_path), dtype=np.float64), self.index_jump)
 
     def new_trajectory(self) -> Dict[str, np.ndarray]:
@@ -70,6 +67,11 @@ class WaypointFollower:
                 "total_return": 0, "path_length": 0}
 
     def _call(self, traj, rtg):
+        if self.mode == "list_stage":
+            # learner.py:559-568: refill the planner's action list when it is empty, then pop its head
+            if len(self.planner.action_list) == 0:
+                self.planner.action_piid_list_sample(traj, percentage=1.0, plan=False, eval=True, rtg=rtg)
+            return self.planner.action_list.pop(0)
         fn = self.planner.action_piid_sample if self.mode == "two_stage" else self.planner.action_id_sample
         return fn(traj, percentage=1.0, plan=False, eval=True, rtg=rtg)
 

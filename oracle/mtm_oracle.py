@@ -416,6 +416,14 @@ def goal_piid(sd, stats, cfg: PlanCfg, traj, h: int):
     return loc, std, inferred
 
 
+def goal_piid_list(sd, stats, cfg: PlanCfg, traj, h: int):
+    """action_piid_list_sample (zeroshot learner.py:263-370; goal_mask "piid_allout"): the same two chained forwards; what the
+    reference leaves in ``self.action_list`` is [mean of the action distribution at T-h] -- tanh(loc), whatever ``eval`` says
+    (the entries for T-h+1, T-h+2 are commented out at 366-370).  Returns that list."""
+    loc, _, _ = goal_piid(sd, stats, cfg, traj, h)
+    return [torch.tanh(loc[0, cfg.traj_length - h])]
+
+
 def goal_id(sd, stats, cfg: PlanCfg, traj, h: int):
     """action_id_sample's single forward under the gid mask (zeroshot learner.py:135-149)."""
     T = cfg.traj_length

@@ -364,6 +364,15 @@ def g3():
                 out[pre + "win_states_after"] = npf(loc["torch_zero_trajectory"]["states"])
             else:
                 out[pre + "win_states"] = npf(loc["torch_zero_trajectory"]["states"])
+        # goal_mask "piid_allout" (unseen.py:146-148): action_piid_list_sample leaves its result in learner.action_list and
+        # returns None (zeroshot learner.py:263-370); shot pops it (559-568).  Always the distribution's mean, eval or not.
+        L.action_list = []
+        assert L.action_piid_list_sample(hist, percentage=1.0, plan=False, eval=True, rtg=2.5) is None
+        assert len(L.action_list) == 1
+        out[f"action_piid_list_sample_pl{pl}_action0"] = npf(L.action_list[0])
+        L.action_list = []
+        L.action_piid_list_sample(hist, percentage=0.7, plan=False, eval=False, rtg=None)  # return-to-go from the statistics
+        out[f"action_piid_list_sample_pl{pl}_explore_action0"] = npf(L.action_list[0])
         out[f"obs_pl{pl}"] = obs
     np.savez_compressed(os.path.join(HERE, "g3_zeroshot.npz"), **out)
     print("g3 written")

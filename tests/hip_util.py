@@ -7,6 +7,13 @@ from m3pc_amd import capi, synth
 from oracle import mtm_oracle as O
 
 
+def lab_library():
+    """libm3pc_hip_lab.so (-DM3PC_LAB): the product ABI plus the kernel-level hooks of include/m3pc_hip_debug.h and the
+    environment A/B switches.  Built on demand (it travels to the GPU box with the snapshot like the product library)."""
+    from m3pc_amd import build
+    return capi.load_library(build.build_library(lab=True))
+
+
 def make_handle(dims: synth.Dims, max_candidates=64, max_batch=4, seed=0):
     h = capi.Handle(dims.state_dim, dims.action_dim, dims.traj_length, dims.n_embd, dims.n_head, dims.n_enc_layer,
                     dims.n_dec_layer, max_candidates=max_candidates, max_batch=max_batch, critic_hidden=256)

@@ -37,10 +37,29 @@ def test_abi_version_and_error_string(lib):
 
 
 def test_struct_layouts_match_header():
-    assert ctypes.sizeof(capi.Dims) == 10 * 4
-    assert ctypes.sizeof(capi.PlanArgs) == 6 * 4 + 3 * 8
+    assert ctypes.sizeof(capi.Dims) == 11 * 4
+    assert ctypes.sizeof(capi.PlanArgs) == 6 * 4 + 3 * 8 + 2 * 4 + 8
     assert capi.PlanArgs.lmbda.offset == 24 and capi.PlanArgs.rtg.offset == 40
+    assert capi.PlanArgs.slot.offset == 48 and capi.PlanArgs.returns_f64.offset == 52 and capi.PlanArgs.returns.offset == 56
     assert ctypes.sizeof(capi.NamedTensor) == 32
+    hdr = open(os.path.join(ROOT, "include", "m3pc_hip.h")).read()
+    assert int(re.search(r"#define M3PC_SLOTS (\d+)", hdr).group(1)) == capi.SLOTS
+    assert int(re.search(r"#define M3PC_ABI_VERSION (\d+)", hdr).group(1)) == capi.ABI_VERSION
+
+
+def test_product_library_has_no_debug_hooks_and_reads_no_environment(lib):
+    """The kernel-level hooks (include/m3pc_hip_debug.h) and the environment A/B switches live in the lab build only."""
+    src = open(os.path.join(ROOT, "include", "m3pc_hip_debug.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    dbg = sorted(set(re.findall(r"\b(m3pc_debug_[a-z_0-9]+)\s*\(", src)))
+    assert len(dbg) >= 8
+    for n in dbg:
+        assert not hasattr(lib, n), f"{n} is exported by the product library"
+    blob = open(build.LIB, "rb").read()
+    assert b"getenv" not in blob and b"M3PC_NO_" not in blob
+    lab = capi.load_library(build.build_library(lab=True))
+    for n in dbg:
+        assert hasattr(lab, n), f"{n} declared in m3pc_hip_debug.h but missing from the lab build"
 
 
 def test_argument_validation_without_gpu(lib):

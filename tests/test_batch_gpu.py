@@ -30,10 +30,12 @@ def _tiny(N=16, guidance="rtg_guiding", temp=0.01, **kw):
 
 
 # ------------------------------------------------------------------------------------------------ batched planning (f1)
+@pytest.mark.parametrize("lockstep", [False, True])
 @pytest.mark.parametrize("guidance,mode,temp", [("rtg_guiding", "rtg", 0.01), ("critic_lambda_guiding", "critic", 1.0)])
-def test_batched_planning_equals_single_window_calls_and_the_reference(guidance, mode, temp):
+def test_batched_planning_equals_single_window_calls_and_the_reference(guidance, mode, temp, lockstep):
     """E = 4 windows with mixed horizons (path_length 0 and 3 plan with horizon T - end_idx) on the tiny config, fp32: every
-    window of the batch reproduces the reference golden of its single-window call (G1) and the single-window planner."""
+    window of the batch reproduces the reference golden of its single-window call (G1) and the single-window planner --
+    pipelined (one plan step per window, several in flight: the default) and in lock step (one pass over E x N rows)."""
     g = np.load(os.path.join(GD, "g1_tiny.npz"))
     dims, pb = _tiny(guidance=guidance, temp=temp, max_windows=4)
     _, ps = _tiny(guidance=guidance, temp=temp)
@@ -45,9 +47,9 @@ def test_batched_planning_equals_single_window_calls_and_the_reference(guidance,
         h = synth.make_history(dims, 0)
         h["path_length"] = pl
         hists.append(h)
-    pb._eps = lambda shape: eps.reshape(1, N, T, A).expand(shape[0], N, T, A).contiguous()
+    pb._eps = (lambda shape: eps.reshape(1, N, T, A).expand(shape[0], N, T, A).contiguous()) if lockstep else (lambda shape: eps)
     ps._eps = lambda shape: eps
-    ev = pb.action_sample_batch(hists, eval=True, rtg=3.0)
+    ev = pb.action_sample_batch(hists, eval=True, rtg=3.0, lockstep=lockstep)
     assert ev.shape == (4, 3)
     for i, pl in enumerate(pls):
         pre = f"{mode}_pl{pl}_"
@@ -59,13 +61,14 @@ def test_batched_planning_equals_single_window_calls_and_the_reference(guidance,
         assert int(w["argmax"].item()) == int(np.argmax(g[pre + "expect_return"]))
         e1 = ps.action_sample(hists[i], plan=True, eval=True, rtg=3.0)
         assert float((e1 - ev[i]).abs().max()) < 1e-5 and int(ps.last["argmax"].item()) == int(w["argmax"].item())
-    sa = pb.action_sample_batch(hists, eval=False, rtg=[3.0, 2.0, 3.0, 1.0])
+    sa = pb.action_sample_batch(hists, eval=False, rtg=[3.0, 2.0, 3.0, 1.0], lockstep=lockstep)
     assert sa.shape == (4, 3) and float(sa.abs().max()) <= 1.0
     pb.handle.close()
     ps.handle.close()
 
 
-def test_batched_bf16_planning_keeps_the_reference_argmax():
+@pytest.mark.parametrize("lockstep", [False, True])
+def test_batched_bf16_planning_keeps_the_reference_argmax(lockstep):
     """Full-size model, bf16 candidate pass + bound-driven fp32 re-score, E = 4 windows x N = 256: the four hopper / weight
     seed 0 cases of g5_argmax.npz (captured from the reference) in one batch."""
     g5 = np.load(os.path.join(GD, "g5_argmax.npz"))
@@ -82,8 +85,9 @@ def test_batched_bf16_planning_keeps_the_reference_argmax():
         hists.append(h)
         epss.append(synth.make_eps(N, dims, 100 + ci).reshape(N, T, 3))
     stack = torch.stack(epss).cuda()
-    p._eps = lambda shape: stack
-    ev = p.action_sample_batch(hists, eval=True, rtg=3.0)
+    per_window = iter(epss)
+    p._eps = (lambda shape: stack) if lockstep else (lambda shape: next(per_window).cuda())
+    ev = p.action_sample_batch(hists, eval=True, rtg=3.0, lockstep=lockstep)
     for ci in range(4):
         w = p.last["windows"][ci]
         assert int(w["argmax"].item()) == int(g5[f"argmax_{ci}"]), ci

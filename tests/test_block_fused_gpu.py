@@ -1,14 +1,15 @@
 """GPU check of the fused layer tail (m3pc_amd/csrc/block_fused.hip) against plain torch fp32 with the same bf16
 rounding points: out-proj + residual -> LayerNorm2 -> Linear/GELU/Linear + residual -> LayerNorm(s)
 (mtm_model.py:379-409 halves of nn.TransformerEncoderLayer, norm_first, exact-erf GELU).  Through the library's debug
-entry m3pc_debug_block_fused (not part of the public header)."""
+entry m3pc_debug_block_fused (lab build: include/m3pc_hip_debug.h)."""
 import ctypes as C
 
 import pytest
 import torch
 import torch.nn.functional as F
 
-from m3pc_amd import capi
+from m3pc_amd import capi  # noqa: F401
+from hip_util import lab_library
 
 pytestmark = pytest.mark.gpu
 
@@ -60,7 +61,7 @@ def reference(O, R, W, p, lnB=None, sel=None):
 
 @pytest.mark.parametrize("M", [128, 4096 + 37, 50176])
 def test_block_fused_matches_torch(M):
-    lib = capi.load_library()
+    lib = lab_library()
     dev = torch.device("cuda")
     W, p, _, g = make_params(M)
     O = torch.randn(M, D, device=dev, generator=g).to(torch.bfloat16)
@@ -96,7 +97,7 @@ def test_block_fused_matches_torch(M):
 def test_block_fused_rowtab_and_head_norms():
     """decoder form: residual from a shared row table, no fp32 output, decoder.norm then one of two head LayerNorms by
     row group, rows regrouped per head"""
-    lib = capi.load_library()
+    lib = lab_library()
     dev = torch.device("cuda")
     n, nq, hh = 512, 32, 16
     M = n * nq
@@ -151,7 +152,7 @@ def _kv_reference(Z, n, Le, kept, off, We, Wkv, rowtab, g, b, bkv):
 @pytest.mark.parametrize("n,Le,kept,off", [(64, 49, (17, 32), (0, 17)), (100, 49, (17, 32), (0, 17)), (37, 40, (9, 31), (0, 9)),
                                            (16, 32, (32, 0), (0, 0)), (1024, 49, (17, 32), (0, 17))])
 def test_kv_fused_matches_reference(n, Le, kept, off):
-    lib = capi.load_library()
+    lib = lab_library()
     dev = torch.device("cuda")
     g_ = torch.Generator(device=dev).manual_seed(7 + n)
     rn = lambda *s: torch.randn(*s, device=dev, generator=g_)
@@ -174,7 +175,7 @@ def test_kv_fused_matches_reference(n, Le, kept, off):
 
 def test_kv_fused_rows_independent_of_batch():
     """A candidate's K|V rows do not depend on how many candidates the launch holds (candidate sharding stays bit-exact)."""
-    lib = capi.load_library()
+    lib = lab_library()
     dev = torch.device("cuda")
     g_ = torch.Generator(device=dev).manual_seed(3)
     rn = lambda *s: torch.randn(*s, device=dev, generator=g_)

@@ -4,15 +4,15 @@ The library picks a GEMM kernel by shape (128x128 three-slot ring by default, 25
 long-K many-row problems).  Sharded and single-GPU runs must agree bit for bit (tests/test_hip_parity.py::
 test_sharding_is_exact), and a shard sees a different row count, hence possibly a different kernel: every
 kernel on the default dispatch must therefore produce IDENTICAL bits -- same MFMA instruction, same k order, same
-epilogue arithmetic.  This test holds them to that through the library's debug entry (m3pc_debug_gemm; not part of the
-public header).
+epilogue arithmetic.  This test holds them to that through the library's debug entry (m3pc_debug_gemm; lab build: include/m3pc_hip_debug.h).
 """
 import ctypes as C
 
 import pytest
 import torch
 
-from m3pc_amd import capi
+from m3pc_amd import capi  # noqa: F401
+from hip_util import lab_library
 
 pytestmark = pytest.mark.gpu
 
@@ -34,7 +34,7 @@ def _gemm(lib, A, W, bias, R, out, gelu, variant):
 # (M, N, K, residual): full 256-row tiles, a ragged last tile, the long-K residual GEMM the 256x256 kernel is used for
 @pytest.mark.parametrize("M,N,K,res", [(57344, 512, 2048, True), (57344 + 77, 512, 1024, True), (61440, 256, 2048, False)])
 def test_big_tile_kernel_is_bit_identical_to_the_ring(M, N, K, res):
-    lib = capi.load_library()
+    lib = lab_library()
     dev = torch.device("cuda")
     g = torch.Generator(device=dev).manual_seed(M + N + K)
     A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
@@ -64,7 +64,7 @@ def test_big_tile_kernel_is_bit_identical_to_the_ring(M, N, K, res):
 # row-mapped shapes take its one-workgroup-per-tile form
 @pytest.mark.parametrize("M,N,K,gelu", [(50176, 1536, 512, 0), (50176 + 40, 1024, 512, 1), (16384, 512, 192, 0), (70000, 2048, 512, 1)])
 def test_line_kernel_is_bit_identical_to_the_ring_bf16_out(M, N, K, gelu):
-    lib = capi.load_library()
+    lib = lab_library()
     dev = torch.device("cuda")
     g = torch.Generator(device=dev).manual_seed(M + N + K + gelu)
     A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
@@ -92,7 +92,7 @@ def test_line_kernel_is_bit_identical_to_the_ring_bf16_out(M, N, K, gelu):
 def test_topk_order_matches_stable_sort(n, k):
     if k > n:
         pytest.skip("k <= n by contract")
-    lib = capi.load_library()
+    lib = lab_library()
     fn = lib.m3pc_debug_topk
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]

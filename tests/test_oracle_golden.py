@@ -190,6 +190,12 @@ def test_g3_zeroshot(pl):
     _close(loc2, g[pre + "loc"], 1e-5, 1e-5, "id loc")
     _close(std2, g[pre + "std"], 1e-5, 1e-6, "id std")
     _close(torch.tanh(loc2)[0, 8 - h], g[pre + "eval_action"], 1e-5, 1e-5, "id eval_action")
+    # goal_mask "piid_allout": what action_piid_list_sample leaves in learner.action_list (one entry, the mean; the returns
+    # are masked under both masks, so the explore call with a statistics-derived return-to-go gives the same action)
+    lst = O.goal_piid_list(sd, stats, cfg, win, h)
+    assert len(lst) == 1
+    _close(lst[0], g[f"action_piid_list_sample_pl{pl}_action0"], 1e-5, 1e-5, "piid_allout action_list[0]")
+    _close(lst[0], g[f"action_piid_list_sample_pl{pl}_explore_action0"], 1e-5, 1e-5, "piid_allout explore")
 
 
 # ------------------------------------------------------------------------------------- G5 arg-max pins (other weights / windows)

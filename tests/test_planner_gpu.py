@@ -120,6 +120,9 @@ def test_c2_candidate_halves_on_two_streams_are_bit_identical_to_one_stream(monk
     hist = synth.make_history(dims, 0)
     hist["path_length"] = 500
 
+    from hip_util import lab_library
+    monkeypatch.setattr(capi, "_lib", lab_library())  # the environment A/B switches exist in the lab build only
+
     def scores(env):
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -66,11 +66,15 @@ def test_bound_rescore_keeps_the_reference_argmax(g5):
         assert int(last["argmax"].item()) == ref_am, (case, int(last["argmax"].item()), ref_am)
         top = last["topk"].cpu().numpy()
         assert ref_am in top, (case, "reference arg-max was not re-scored")
-        assert 4 <= last["n_rescored"] <= 64 and last["n_rescored"] == top.size
+        assert 4 <= last["n_rescored"] == top.size
         assert last["delta"] > 0 and last["min_margin_outside"] >= 0
-        # containment held with the bound's own room unless the cap cut the window
-        if last["n_in_window"] <= 64:
-            assert last["min_margin_outside"] >= 2 * last["delta"] or last["n_rescored"] > last["n_in_window"]
+        # every candidate inside the window was re-scored: either the listed prefix covered the window (containment held
+        # with the bound's own room) or the whole window set went through the chunked fallback
+        assert last["n_rescored"] >= last["n_in_window"]  # (n_in_window: what the first certificate asked for)
+        if not last["saturated"]:
+            assert last["n_rescored"] <= 64
+            assert last["min_margin_outside"] >= 0  # the certificate's threshold clears the best un-re-scored bf16 score
+        assert last["deviation"] <= last["delta"]
         # the re-scored scores are fp32-accurate (shifted like the reference's, learner.py:318)
         er = last["expect_return"]
         got = (er - er.max()).cpu().numpy()[top]
@@ -104,13 +108,9 @@ def test_fixed_delta_and_topk_modes():
     """rescore_delta pins the window; rescore='topk' is the round-1 fixed-k behaviour; fp32 planners do not re-score."""
     dims = synth.Dims(11, 3, 32)
     eps = synth.make_eps(256, dims, 3).cuda()
-    p = _planner(dims, 256, 16, 0.01, "rtg_guiding", 0, rescore_delta=1e9, rescore_max=32)
-    _run(p, dims, 0, 400, eps)
-    assert p.last["n_rescored"] == 32 and p.last["n_in_window"] >= 32  # everything is inside a huge window: capped
-    p.handle.close()
     p = _planner(dims, 256, 16, 0.01, "rtg_guiding", 0, rescore_delta=0.0, rescore_min=5)
     _run(p, dims, 0, 400, eps)
-    assert p.last["n_rescored"] == 5 and p.last["n_in_window"] == 1  # only the maximum itself: the floor applies
+    assert 5 <= p.last["n_rescored"] <= 16 and p.last["n_first"] == 5  # delta 0: the floor (plus whatever beats the fp32 best outright)
     p.handle.close()
     p = _planner(dims, 256, 16, 0.01, "rtg_guiding", 0, rescore="topk", rescore_topk=7)
     _run(p, dims, 0, 400, eps)
@@ -118,15 +118,97 @@ def test_fixed_delta_and_topk_modes():
     p.handle.close()
 
 
-def test_returns_must_be_constant_in_direct_guiding_calls():
+@pytest.mark.parametrize("delta,rmax", [(1e9, 32), (40.0, 8)])
+def test_window_larger_than_the_cap_falls_back_to_the_whole_window_set(delta, rmax):
+    """More candidates inside the 2 delta window than rescore_max may list (VERDICT r2 weak 2 / ADVICE: the bound is lost
+    silently): the planner re-scores the WHOLE window set in chunks, warns once, reports it, and the arg-max is the fp32 one.
+    delta = 1e9: everything is inside (256 > 32); delta = 40: a few dozen are (> 8)."""
+    dims = synth.Dims(11, 3, 32)
+    eps = synth.make_eps(256, dims, 3).cuda()
+    p32 = HipPlanner(types.SimpleNamespace(traj_length=32, action_samples=256, horizon=16, discount=0.99, temperature=0.01, lmbda=0.6,
+                                           plan_guidance="rtg_guiding", device="cuda"),
+                     synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None, precision="fp32")
+    _run(p32, dims, 0, 400, eps)
+    am32, er32 = int(p32.last["argmax"].item()), p32.last["expect_return"].clone()
+    p32.handle.close()
+    p = _planner(dims, 256, 16, 0.01, "rtg_guiding", 0, rescore_delta=delta, rescore_max=rmax)
+    with pytest.warns(UserWarning, match="whole window set"):
+        _run(p, dims, 0, 400, eps)
+    last = p.last
+    assert last["saturated"] and last["n_in_window"] > rmax and last["n_rescored"] == last["n_in_window"]
+    assert int(last["argmax"].item()) == am32
+    top = last["topk"].long()
+    assert float((last["expect_return"][top] - er32[top]).abs().max()) <= 5e-5 * float(er32.abs().max())
+    if delta > 1e6:  # every candidate re-scored: the whole vector is the fp32 one
+        assert last["n_rescored"] == 256
+        assert float((last["expect_return"] - er32).abs().max()) <= 5e-5 * float(er32.abs().max())
+    _run(p, dims, 0, 400, eps)  # second step: same path, no second warning needed, same answer
+    assert int(p.last["argmax"].item()) == am32
+    p.handle.close()
+
+
+def test_a_constant_bf16_offset_larger_than_delta_cannot_move_the_argmax():
+    """delta bounds the deviation of (bf16 - fp32) from its COMMON SHIFT, so a shift larger than delta
+    could lift an un-re-scored candidate over the re-scored fp32 maximum when the select ran on a vector mixing both scales.
+    The select now runs on the merged vector (m3pc_rescore_merge: un-re-scored entries minus the median shift).  Injected:
+    +75 on every bf16 score (delta is ~3-6 here)."""
+    dims = synth.Dims(11, 3, 32)
+    eps = synth.make_eps(256, dims, 3).cuda()
+    p = _planner(dims, 256, 16, 0.01, "rtg_guiding", 0)
+    ev0 = _run(p, dims, 0, 400, eps).clone()
+    am0, er0, d0 = int(p.last["argmax"].item()), p.last["expect_return"].clone(), p.last["delta"]
+    p._bf16_offset = 75.0
+    assert p._bf16_offset > 5 * d0
+    ev1 = _run(p, dims, 0, 400, eps)
+    assert int(p.last["argmax"].item()) == am0
+    top = p.last["topk"].long()
+    assert int(p.last["expect_return"].argmax().item()) in top.tolist()
+    # the merged vectors agree: re-scored entries are the same fp32 scores, the others lose the offset with the shift
+    assert float((p.last["expect_return"] - er0).abs().max()) <= 1e-3 * float(er0.abs().max()) + 2 * d0
+    assert float((ev1 - ev0).abs().max()) <= 2e-2
+    assert abs(p.last["shift"] - 75.0) <= 4 * d0 + 10.0  # the estimated shift holds the offset (plus the bf16 scores' own common shift)
+    p.handle.close()
+
+
+def test_delta_grows_when_the_rescored_set_shows_a_larger_deviation():
+    """delta is checked every step against the deviation of (bf16 - fp32) over the re-scored set: started from a
+    deliberately small value it grows to 1.5 x what the steps see, and the window follows."""
+    dims = synth.Dims(11, 3, 32)
+    eps = synth.make_eps(256, dims, 3).cuda()
+    p = _planner(dims, 256, 16, 0.01, "rtg_guiding", 0)
+    _run(p, dims, 0, 400, eps)
+    p._delta = 1e-3  # (as if the calibration subset had been unlucky)
+    for _ in range(3):
+        _run(p, dims, 0, 400, eps)
+    assert p.delta_grown >= 1 and p._delta > 0.05
+    p.handle.close()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_non_constant_returns_rows_are_planned_as_the_reference_does(dtype):
+    """rtg_guiding consumes whatever trajectory["returns"] holds (learner.py:272-293), not only the constant row
+    action_sample builds: a varying returns row goes through the library (m3pc_plan_args::returns) and matches the oracle."""
+    from oracle import mtm_oracle as O
     dims = synth.Dims(11, 3, 8, n_embd=64, n_head=2)
     cfg = types.SimpleNamespace(traj_length=8, action_samples=16, horizon=4, discount=0.99, temperature=0.01, lmbda=0.6,
                                 plan_guidance="rtg_guiding", device="cuda")
-    p = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None, n_embd=64, n_head=2)
-    traj = {"states": torch.zeros(1, 8, 11).cuda(), "actions": torch.zeros(1, 8, 3).cuda(), "rewards": torch.zeros(1, 8, 1).cuda(),
-            "returns": torch.full((1, 8, 1), 2.0, dtype=torch.float64).cuda()}
-    p.rtg_guiding(traj, 4)  # constant returns: fine
-    traj["returns"][0, 3, 0] = 2.5
-    with pytest.raises(ValueError):
-        p.rtg_guiding(traj, 4)
+    sd, st = synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0)
+    p = HipPlanner(cfg, sd, st, None, n_embd=64, n_head=2)
+    hist = synth.make_history(dims, 0)
+    ocfg = O.PlanCfg(8, 4, 16, 0.99, 0.01, 0.6, n_head=2)
+    win, h = O.assemble_window(ocfg, hist, 100, 3.0)
+    win["returns"] = torch.tensor([3.0, 2.5, 2.75, 1.0, 0.5, 4.0, -1.0, 2.0], dtype=dtype).reshape(1, 8, 1)
+    eps = synth.make_eps(16, dims, 1)
+    ref = O.guiding(sd, O.make_stats(st), ocfg, win, h, 0.6, eps, "rtg")
+    p._eps = lambda shape: eps.cuda()
+    traj = {k: v.cuda() for k, v in win.items()}
+    sa, ev = p.rtg_guiding(traj, h)
+    scale = float(ref["expect_return"].abs().max())
+    assert float((p.last["expect_return"].cpu() - ref["expect_return"]).abs().max()) <= 5e-5 * scale
+    assert int(p.last["argmax"].item()) == ref["argmax"]
+    assert float((ev.cpu() - ref["eval_action"]).abs().max()) <= 1e-4
+    const = dict(traj)
+    const["returns"] = torch.full((1, 8, 1), 3.0, dtype=dtype).cuda()
+    p.rtg_guiding(const, h)
+    assert float((p.last["expect_return"].cpu() - ref["expect_return"]).abs().max()) > 1e-3 * scale  # the row mattered
     p.handle.close()
