@@ -2,32 +2,43 @@
 """bench.py -- MPC plan-steps/sec of the m3pc test-time planner on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
+        N > 1 without a launcher: starts `python -m torch.distributed.run --nproc-per-node N ... bench.py ...` itself (before
+        anything touches a GPU), relays rank 0's JSON line and exits with the children's code.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-One "step" = one complete plan step of rtg_guiding (research/finetune_omtm/learner.py:271-327): draw eps,
-policy pass (batch 1), sample N candidates, batched candidate pass, TD(lambda) scoring, all-gather of the
-shards (N > 1 GPU), fp32 re-score of every candidate within 2*delta of the bf16 maximum (the bound-driven set,
-m3pc_amd/planner.py; one 16-byte host read per step), softmax / weighted mean / argmax, multinomial draw.
-Inputs (window, weights) are resident in HBM when the timed region starts.
+One "step" = one complete plan step of rtg_guiding (research/finetune_omtm/learner.py:271-327): draw eps, policy pass
+(batch 1, fp32), sample N candidates, batched candidate pass (bf16), TD(lambda) scoring, [all-gather of the shards when the
+candidates are sharded], certified fp32 re-score of the candidates that can still hold the arg-max (m3pc_amd/planner.py),
+softmax / weighted mean / argmax, multinomial draw.  Inputs (window, weights) are resident in HBM when the timed region
+starts.  SURVEY 8(d) defines the metric as completed plan_step calls per second with the result resident on the device:
+the steps of the timed region are INDEPENDENT plan steps (the same window planned again and again, as before) issued
+through HipPlanner's pipeline -- `--depth` of them in flight (default 2): step t+1's policy pass and step t-1's re-score +
+select run on two more streams beside step t's candidate pass; every step's result is bit-identical to the serial call
+(tests/test_pipeline_gpu.py).  `--depth 0` is the serial order; `latency_ms` (one step alone) and `closed_loop` stay serial.
 
-Besides the contract fields the line carries (rank 0, 1 GPU): `rescore` (set sizes), `fp32_ms_per_step` (the same step
-fp32 end to end: the mode that meets the fp32 tolerance everywhere), `closed_loop` (action_sample with the H2D window
-copy and the action read back every step), `latency_ms_shipped` (the reference's shipped N=625/H=4/T=8 config and the
-zero-shot B=1 call: the launch-latency-bound operating points), `batched` (E windows per launch).
+Workload at 1 GPU: BASELINE configs[1] = hopper-medium-v2 shapes (S=11, A=3), rtg_guiding, N=1024 candidates, H=16, T=32
+(=2H, the reference's shipped T/H ratio), bf16 candidate pass, synthetic data.
 
-Workload at 1 GPU: BASELINE configs[1] = hopper-medium-v2 shapes (S=11, A=3), rtg_guiding, N=1024
-candidates, H=16, T=32 (=2H, the reference's shipped T/H ratio), bf16 candidate pass, synthetic data.
-Multi-GPU: weak scaling -- 1024 candidates PER GPU (global N = 1024*G, sharded by candidate, one RCCL
-all-gather of scores + first actions per step); value counts 1024-candidate plan-step units:
-value = G * K / t.  `--strong` keeps the global N at 1024 instead.
+Multi-GPU (`--shard`):
+  env (default)   every rank plans its own windows with all N=1024 candidates -- the metric's N, one environment per rank
+                  (independent plan steps: no collective on the data path); value = G * K / t.  Weak scaling.
+  candidates      the candidates of ONE plan step are sharded over the ranks with one RCCL all-gather of scores + first
+                  actions per step (m3pc_amd/dist.py): weak (N = 1024 per rank, value counts 1024-candidate units) or
+                  `--strong` (N = 1024 in total; `replicated_ms` tells what every rank repeats).
+  `--config c4`   BASELINE configs[3]: halfcheetah shapes, rtg_guiding, N=16384, H=32, T=64, candidate-sharded over the
+                  ranks (strong scaling: 16384 candidates in total), value = plan steps of 16384 candidates per second.
+With --shard env at N > 1 GPUs the line also carries `c4` (the candidate-sharded config 4 through RCCL on the same ranks,
+a few steps), so that the collective path is measured whenever more than one GPU is.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
+from collections import deque
 
 import torch
 
@@ -45,7 +56,6 @@ def alg_flops(N, T, H, S, A, d=512, n_enc=2, mode="rtg"):
     Ld = 4 * T
     c, q, e = 24 * d * d, 4 * d, 2 * d * d
     nq = 2 * H
-    feats = {"states": S, "actions": A}
     embed = 2 * d * (S * (idx + 1) + A * T)
     dbar = 1.0 if mode == "rtg" else (S + 1) / 2.0
     per_cand = (n_enc * (c * Le + q * Le * Le) + embed + Le * e + Le * 2 * e + nq * Ld * q + nq * e + nq * 16 * d * d
@@ -63,7 +73,8 @@ def alg_bytes(N, T, S, A, n_params=11_326_995):
 
 def cpu_baseline(dims, cfg_kw, hist, rtg):
     """The oracle (fp32 PyTorch-CPU restatement of the reference path) timed on this host's cores: the full
-    N-candidate plan step of the bench workload (value), and BASELINE config 1 (hopper N=64 H=8 T=16) beside it."""
+    N-candidate plan step of the bench workload (value), and BASELINE config 1 (hopper N=64 H=8 T=16) beside it.
+    Also returns the oracle's result for eps = synth.make_eps(N, dims, 1): the parity reference of the `parity` block."""
     from m3pc_amd import synth
     from oracle import mtm_oracle as O
     try:
@@ -75,16 +86,16 @@ def cpu_baseline(dims, cfg_kw, hist, rtg):
     sd = synth.make_state_dict(dims, 0)
     stats = O.make_stats(synth.make_tokenizer_stats(dims, 0))
     N = cfg_kw["action_samples"]
-    n_s = N  # the whole plan step (about 5 s on 64 threads at N = 1024): no extrapolation
-    cfg = O.PlanCfg(dims.traj_length, cfg_kw["horizon"], n_s, 0.99, 0.01, 0.6)
+    cfg = O.PlanCfg(dims.traj_length, cfg_kw["horizon"], N, 0.99, 0.01, 0.6)
     win, h = O.assemble_window(cfg, hist, 500, rtg)
-    eps = synth.make_eps(N, dims, 1)[:n_s]
+    eps = synth.make_eps(N, dims, 1)
     small = O.PlanCfg(dims.traj_length, cfg_kw["horizon"], 32, 0.99, 0.01, 0.6)
     O.guiding(sd, stats, small, win, h, 0.6, eps[:32], "rtg")  # warm-up (thread pools, allocator)
     t0 = time.perf_counter()
     reps = 0
+    ref = None
     while reps < 1 or (time.perf_counter() - t0 < 12.0 and reps < 4):
-        O.guiding(sd, stats, cfg, win, h, 0.6, eps, "rtg")
+        ref = O.guiding(sd, stats, cfg, win, h, 0.6, eps, "rtg")
         reps += 1
     dt = (time.perf_counter() - t0) / reps
     # BASELINE configs[0]: hopper rtg_guiding N=64 H=8 T=16 (the reference's own CPU-runnable case)
@@ -100,11 +111,42 @@ def cpu_baseline(dims, cfg_kw, hist, rtg):
         O.guiding(sd1, st1, c1, w1, hh1, 0.6, e1, "rtg")
         r1 += 1
     dt1 = (time.perf_counter() - t1) / r1
-    return {"value": 1.0 / dt, "unit": "plan-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} x the whole plan step ({N} candidates, rtg_guiding H={h} T={dims.traj_length}, fp32 torch-CPU "
-                      f"oracle, {cores} threads, {dt:.2f}s each)",
-            "config1": {"value": round(1.0 / dt1, 3), "unit": "plan-steps/s",
-                        "sample": f"{r1} x hopper rtg_guiding N=64 H=8 T=16 ({1e3 * dt1:.0f} ms each)"}}
+    out = {"value": 1.0 / dt, "unit": "plan-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{reps} x the whole plan step ({N} candidates, rtg_guiding H={h} T={dims.traj_length}, fp32 torch-CPU "
+                     f"oracle, {cores} threads, {dt:.2f}s each)",
+           "config1": {"value": round(1.0 / dt1, 3), "unit": "plan-steps/s",
+                       "sample": f"{r1} x hopper rtg_guiding N=64 H=8 T=16 ({1e3 * dt1:.0f} ms each)"}}
+    return out, ref, eps
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn(args):
+    """`python bench.py --gpus N` as the driver runs it: start the N ranks as children of a fresh launcher process.  Nothing
+    in THIS process has touched a GPU (importing torch does not), so no GPU-initialised process is replaced or forked."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if r.returncode != 0 or line is None:
+        raise SystemExit(r.returncode or 1)
+    raise SystemExit(0)
 
 
 def main():
@@ -113,15 +155,18 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--candidates", type=int, default=1024, help="candidates per GPU")
+    ap.add_argument("--candidates", type=int, default=1024, help="candidates per plan step (per GPU when sharded weakly)")
     ap.add_argument("--horizon", type=int, default=16)
     ap.add_argument("--traj-length", type=int, default=32)
+    ap.add_argument("--depth", type=int, default=2, help="independent plan steps in flight (0: the serial order)")
     ap.add_argument("--rescore", default="bound", choices=["bound", "topk"],
-                    help="fp32 re-score set: every candidate within 2*delta of the bf16 maximum (default) or a fixed top-k")
+                    help="fp32 re-score set: certified (every candidate that can still hold the arg-max; default) or a fixed top-k")
     ap.add_argument("--rescore-topk", type=int, default=16)
-    ap.add_argument("--rescore-min", type=int, default=None, help="smallest bound-driven re-score set (default: the planner's)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / closed-loop / shipped-config side measurements")
-    ap.add_argument("--strong", action="store_true", help="keep the global candidate count fixed")
+    ap.add_argument("--rescore-min", type=int, default=None, help="smallest first re-score pass (default: the planner's)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / closed-loop / shipped-config / parity side measurements")
+    ap.add_argument("--shard", default="env", choices=["env", "candidates"], help="what the ranks of a multi-GPU run divide")
+    ap.add_argument("--strong", action="store_true", help="--shard candidates: keep the global candidate count fixed")
+    ap.add_argument("--config", default="c2", choices=["c2", "c4"], help="c4: BASELINE configs[3] (halfcheetah N=16384 H=32 T=64, candidate-sharded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alone-pass", action="store_true",
                     help="skip the extra instrumented pass with the candidate halves serialised (roofline.alone); "
@@ -129,17 +174,34 @@ def main():
     ap.add_argument("--env", default="hopper", choices=["hopper", "walker2d", "halfcheetah"],
                     help="state/action dims of the D4RL family (BASELINE configs 3-4 use walker2d / halfcheetah)")
     ap.add_argument("--guidance", default="rtg_guiding", choices=["rtg_guiding", "critic_lambda_guiding"])
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher check without a GPU (tests/test_bench_launch_cpu.py): the ranks meet over gloo and rank 0 prints a stub line")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.dry_run:
+        import torch.distributed as dist
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            t = torch.tensor([rank + 1.0])
+            dist.all_reduce(t)
+            assert float(t) == world * (world + 1) / 2
+            dist.destroy_process_group()
+        if os.environ.get("M3PC_BENCH_FAIL_RANK") == str(rank):
+            raise SystemExit(3)
+        if rank == 0:
+            print(json.dumps({"metric": "MPC plan-steps/sec (N=1024, H=16, hopper-medium-v2)", "dry_run": True, "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup}), flush=True)
+        return
     torch.cuda.set_device(local_rank)
-    group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -149,54 +211,83 @@ def main():
     from m3pc_amd.planner import HipPlanner
     import types
 
+    if args.config == "c4":
+        args.env, args.guidance, args.candidates, args.horizon, args.traj_length = "halfcheetah", "rtg_guiding", 16384, 32, 64
+        args.shard, args.strong = "candidates", True
     S, A = synth.ENV_DIMS[args.env]
     critic_mode = args.guidance == "critic_lambda_guiding"
     T, H = args.traj_length, args.horizon
-    n_global = args.candidates if args.strong else args.candidates * world
+    shard_cand = world > 1 and args.shard == "candidates"
+    n_global = args.candidates * world if (shard_cand and not args.strong) else args.candidates
     dims = synth.Dims(S, A, T)
     cfg = types.SimpleNamespace(traj_length=T, action_samples=n_global, horizon=H, discount=0.99, temperature=0.01,
                                 lmbda=0.6, plan_guidance=args.guidance)
     cfg.temperature = 1.0 if critic_mode else 0.01  # config.yaml:79
     gen = torch.Generator(device="cuda")
-    gen.manual_seed(1)  # same seed on every rank: identical eps and multinomial draws
+    # candidate sharding: the same seed on every rank (identical eps and multinomial draws); env sharding: every rank its own
+    gen.manual_seed(1 if (shard_cand or world == 1) else 1 + rank)
     qsd, om, os_ = synth.make_critic(dims, 0) if critic_mode else (None, None, None)
+    group = torch.distributed.group.WORLD if shard_cand else None
     planner = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), qsd, om, os_,
                          precision=args.precision, rescore_topk=args.rescore_topk, device=local_rank, generator=gen,
-                         rescore=args.rescore, **({"rescore_min": args.rescore_min} if args.rescore_min else {}), group=torch.distributed.group.WORLD if world > 1 else None)
-    hist = synth.make_history(dims, 0)
+                         rescore=args.rescore, **({"rescore_min": args.rescore_min} if args.rescore_min else {}), group=group,
+                         pipeline_depth=max(1, min(args.depth, capi.SLOTS - 1)))
+    hist = synth.make_history(dims, 0 if (shard_cand or world == 1) else rank)  # env sharding: every rank its own environment
     hist["path_length"] = 500
     states, actions, rewards, h, rtg = planner.assemble_window(hist, rtg=3.0)
     assert h == H
+    mode = capi.MODE_CRITIC if critic_mode else capi.MODE_RTG
+    depth = max(0, min(args.depth, capi.SLOTS - 1))
 
-    def step():
-        return planner._guide(capi.MODE_CRITIC if critic_mode else capi.MODE_RTG, states, actions, rewards, rtg, h, 0.6)
+    def step():  # one plan step alone, serial
+        return planner._guide(mode, states, actions, rewards, rtg, h, 0.6)
+
+    n_re = []
+
+    def run(k, record=False):
+        """k independent plan steps, `depth` of them in flight."""
+        if depth == 0:
+            for _ in range(k):
+                step()
+                if record:
+                    n_re.append(planner.last.get("n_rescored", args.rescore_topk))
+            return
+        flight = deque()
+        for _ in range(k):
+            flight.append(planner._issue(mode, states, actions, rewards, rtg, h, 0.6, pipelined=True, inputs_ready=True))
+            if len(flight) > depth:
+                tk = flight.popleft()
+                tk.pair()
+                if record:
+                    n_re.append(tk.info.get("n_rescored", args.rescore_topk))
+        while flight:
+            tk = flight.popleft()
+            tk.pair()
+            if record:
+                n_re.append(tk.info.get("n_rescored", args.rescore_topk))
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    n_re = []
-    for _ in range(args.steps):
-        step()
-        n_re.append(planner.last.get("n_rescored", args.rescore_topk))
+    run(args.steps, record=True)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    units = args.steps * (n_global / float(args.candidates))
+    if shard_cand:
+        units = args.steps * (n_global / float(args.candidates))  # weak: 1024-candidate units; strong / c4: plan steps
+    else:
+        units = args.steps * world                                # every rank completed K plan steps of N candidates
     value = units / elapsed
 
-    # roofline of the dominant kernel class (the MFMA GEMM): a second, instrumented pass of the same K
-    # steps with hipEvents around every GEMM launch on the launch stream (events perturb the step time,
-    # so they are kept out of the timed region above).
-    # per-step latency distribution: one event pair per step on the launch stream, outside the timed region
+    # per-step latency distribution (SURVEY 8d): one step alone, serial, one event pair per step, outside the timed region
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 200))]
     for e0, e1 in pairs:
         e0.record()
@@ -205,16 +296,17 @@ def main():
     torch.cuda.synchronize()
     lat = sorted(e0.elapsed_time(e1) for e0, e1 in pairs)
     latency = {"p50": round(lat[len(lat) // 2], 4), "p99": round(lat[min(len(lat) - 1, int(0.99 * len(lat)))], 4),
-               "min": round(lat[0], 4), "steps": len(lat)}
+               "min": round(lat[0], 4), "steps": len(lat), "what": "one plan step alone (serial order), device time"}
 
-    n_local = mdist_count(n_global, rank, world)
+    n_local = mdist_count(n_global, rank, world) if shard_cand else n_global
     prec = capi.PREC_BF16 if args.precision == "bf16" else capi.PREC_FP32
 
-    def instrumented(mode):
-        planner.handle.profile_enable(mode)
+    # roofline of the dominant kernel: a further, instrumented pass of the same K steps with hipEvents around every MFMA launch
+    # on the stream it runs on (events perturb the step time, so they are kept out of the timed region above)
+    def instrumented(pmode):
+        planner.handle.profile_enable(pmode)
         planner.handle.profile_read(reset=True)
-        for _ in range(args.steps):
-            step()
+        run(args.steps)
         torch.cuda.synchronize()
         cls_ = planner.handle.profile_read(prec, reset=False)
         tail_ = planner.handle.profile_read(capi.PROF_LAYER_TAIL, reset=False)
@@ -222,15 +314,20 @@ def main():
         planner.handle.profile_enable(False)
         return cls_, tail_, all_
 
-    # as run: the two candidate halves overlapped on two streams exactly as in the timed region (a bracket also holds what
-    # the other half does on the chip meanwhile) ...
+    # as run: the steps pipelined and the two candidate halves on two streams exactly as in the timed region (a bracket also
+    # holds what the other streams do on the chip meanwhile) ...
     (launches, gemm_ms, gemm_flops), (t_launches, t_ms, t_flops), (all_launches, all_ms, all_flops) = instrumented(True)
-    # ... and with the halves one after the other on one stream: the same launches, each alone on the chip
-    (a_launches, a_ms, a_flops), (at_launches, at_ms, at_flops), _ = ((0, 0.0, 0.0), (0, 0.0, 0.0), None) if args.no_alone_pass else instrumented(2)
+    # ... and serial with the halves one after the other on one stream: the same launches, each alone on the chip
+    if args.no_alone_pass:
+        (a_launches, a_ms, a_flops), (at_launches, at_ms, at_flops) = (0, 0.0, 0.0), (0, 0.0, 0.0)
+    else:
+        d_keep, depth = depth, 0
+        (a_launches, a_ms, a_flops), (at_launches, at_ms, at_flops), _ = instrumented(2)
+        depth = d_keep
     peak = MFMA_PEAK_TFLOPS[args.precision]
     f_step = alg_flops(n_local, T, H, S, A, mode="critic" if critic_mode else "rtg")
     cls = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    if t_launches:   # the dominant kernel: the fused layer tail (block_fused.hip), ~40 % of the step's kernel time
+    if t_launches:   # the dominant kernel: the fused layer tail (block_fused.hip)
         achieved, dom_l, dom_ms, dom_fl = t_flops / (t_ms * 1e-3) / 1e12, t_launches, t_ms, t_flops
         al_l, al_ms, al_fl = at_launches, at_ms, at_flops
         kname = ("m3pc::block_fused_kernel (layer tail: out-proj + residual + LayerNorm + Linear/GELU/Linear + residual + LayerNorm, "
@@ -240,6 +337,7 @@ def main():
         al_l, al_ms, al_fl = a_launches, a_ms, a_flops
         kname = f"the {args.precision} MFMA GEMM launches (gemm_line_kernel / gemm_glds_ring3_kernel / gemm_kernel)"
     alone = al_fl / (al_ms * 1e-3) / 1e12 if al_ms > 0 else None
+    step_s = elapsed / args.steps
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.precision),
                 "peak_measured": 1800.0 if args.precision == "bf16" else None,  # register-resident v_mfma loop at the 1.75 GHz the chip holds
@@ -247,9 +345,9 @@ def main():
                 "flops_per_launch": dom_fl / max(dom_l, 1), "avg_launch_us": 1e3 * dom_ms / max(dom_l, 1),
                 "launches_per_step": dom_l / args.steps, "kernel_ms_per_step": dom_ms / args.steps,
                 "note": "HIP-event brackets on the stream of each launch in an instrumented pass of the same K steps, run as the timed "
-                        "region runs: the two candidate halves on two streams, so a launch shares the chip with the other half's "
-                        "kernels for part of its bracket; `alone` = the same launches with the halves one after the other on one "
-                        "stream (m3pc_profile_enable(h, 2)), each alone on the chip",
+                        "region runs: steps pipelined, the two candidate halves on two streams, so a launch shares the chip with the "
+                        "other streams' kernels for part of its bracket; `alone` = the same launches in the serial order with the "
+                        "halves one after the other on one stream (m3pc_profile_enable(h, 2)), each alone on the chip",
                 "alone": None if alone is None else {"avg_launch_us": 1e3 * al_ms / max(al_l, 1), "achieved": round(alone, 2),
                                                       "frac": round(alone / peak, 4)},
                 # every MFMA launch of the compute dtype (fused tails, fused decoder input, Q|K|V / head GEMMs)
@@ -257,35 +355,119 @@ def main():
                                "ms_per_step": gemm_ms / args.steps},
                 "all_gemm_ms_per_step": all_ms / args.steps, "all_gemm_launches_per_step": all_launches / args.steps,
                 "step_alg_tflop": round(f_step / 1e12, 4),
-                "step_mfma_frac": round(f_step / (elapsed / args.steps) / 1e12 / peak, 4),
+                "step_mfma_frac": round(f_step / step_s / 1e12 / peak, 4),  # per GPU: this rank's flops over this rank's step time
                 "step_alg_bytes": alg_bytes(n_local, T, S, A),
-                "step_hbm_frac_alg": round(alg_bytes(n_local, T, S, A) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
+                "step_hbm_frac_alg": round(alg_bytes(n_local, T, S, A) / step_s / 1e9 / HBM_PEAK_GBS, 5)}
+
+    c4 = None
+    if world > 1 and not shard_cand and args.config == "c2" and not args.no_extras:
+        c4 = c4_sharded(rank, local_rank, world)
 
     if rank == 0:
-        out = {"metric": "MPC plan-steps/sec (N=1024, H=16, hopper-medium-v2)", "value": round(value, 2),
+        if shard_cand:
+            par = f"candidate-shard x{world}" + (" (strong)" if args.strong else " (weak)")
+        else:
+            par = f"env-shard x{world} (one environment per GPU, no collective)" if world > 1 else "1 GPU"
+        flight_txt = (f"{depth} independent plan steps in flight (policy pass / candidate pass / re-score of neighbouring steps on "
+                      f"different streams)") if depth else "serial order"
+        metric = "MPC plan-steps/sec (N=1024, H=16, hopper-medium-v2)"
+        if args.config == "c4":
+            metric = "MPC plan-steps/sec (N=16384, H=32, halfcheetah-medium-expert-v2, candidate-sharded)"
+        out = {"metric": metric, "value": round(value, 2),
                "unit": "plan-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
-               "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.precision,
+               "scaling": "strong" if (shard_cand and args.strong) else "weak", "vs_baseline": None, "dtype": args.precision,
                "data": "synthetic",
-               "config": {"workload": f"{args.env}-medium-v2 shapes (S={S},A={A}) {args.guidance} N={args.candidates}/GPU H={H} "
+               "config": {"workload": f"{args.env}-medium-v2 shapes (S={S},A={A}) {args.guidance} N={args.candidates}"
+                                      + ("/GPU" if (shard_cand and not args.strong) else "") + f" H={H} "
                                       f"T={T} {args.precision} candidate pass + fp32 policy pass + fp32 re-score ("
-                                      + (f"bound-driven set, {sum(n_re) / len(n_re):.1f} candidates on average" if args.rescore == "bound"
-                                         else f"top-{args.rescore_topk}") + "); pipelined throughput, window resident in HBM",
+                                      + (f"certified set, {sum(n_re) / max(len(n_re), 1):.1f} candidates on average" if args.rescore == "bound"
+                                         else f"top-{args.rescore_topk}") + f"); {flight_txt}; window resident in HBM",
                           "candidates_per_gpu": n_local, "global_candidates": n_global, "horizon": H, "traj_length": T,
-                          "parallelism": f"candidate-shard x{world}"},
+                          "steps_in_flight": depth, "parallelism": par},
                "latency_ms": latency, "roofline": roofline,
-               "rescore": {"mode": args.rescore, "n_mean": round(sum(n_re) / len(n_re), 2), "n_max": max(n_re),
-                           "delta": planner.last.get("delta"), "min_margin_outside": planner.last.get("min_margin_outside")}}
+               "rescore": {"mode": args.rescore, "n_mean": round(sum(n_re) / max(len(n_re), 1), 2), "n_max": max(n_re) if n_re else None,
+                           "delta": planner.last.get("delta"), "delta_grown": planner.delta_grown,
+                           "min_margin_outside": planner.last.get("min_margin_outside")}}
+        if shard_cand and args.strong:
+            # what every rank repeats whatever the shard size: the policy pass and the re-score + select
+            out["replicated_ms"] = round(latency["p50"] - candidate_only_ms(planner, mode, states, actions, rewards, h), 4)
+        if c4 is not None:
+            out["c4"] = c4
         if world == 1 and not args.no_extras:
             try:
                 out.update(extras(args, dims, cfg, hist, planner, S, A))
             except Exception as e:  # the side measurements never take the headline down with them
                 out["extras_error"] = repr(e)[:300]
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dims, dict(horizon=H, action_samples=args.candidates), hist, 3.0)
+        if world == 1 and not args.no_cpu_baseline and args.config == "c2":
+            base, ref, eps = cpu_baseline(dims, dict(horizon=H, action_samples=args.candidates), hist, 3.0)
+            out["cpu_baseline"] = base
+            if not args.no_extras and args.guidance == "rtg_guiding":
+                try:
+                    out["parity"] = parity(args, dims, cfg, hist, ref, eps)
+                except Exception as e:
+                    out["parity_error"] = repr(e)[:300]
         print(json.dumps(out), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def candidate_only_ms(planner, mode, states, actions, rewards, h):
+    """Device time of the sharded part of a step alone (sample + candidate pass of this rank's shard)."""
+    from m3pc_amd import dist as mdist
+    cfg = planner.cfg
+    N = int(cfg.action_samples)
+    eps = planner._eps((N, 1, planner.T, 1, planner.A)).reshape(N, -1, planner.A)
+    planner.handle.policy_pass(mode, states, actions, rewards, h, 3.0, slot=0)
+    begin, count = mdist.shard_range(N, planner.rank, planner.world)
+    ts = []
+    for _ in range(12):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        planner.handle.candidate_pass(mode, states, actions, rewards, eps, h, 0.6, float(cfg.discount), N, begin, count,
+                                      precision=planner.precision, slot=0)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def c4_sharded(rank, local_rank, world, steps=12, warm=3):
+    """BASELINE configs[3] on the ranks of this run: halfcheetah shapes, rtg_guiding, N=16384, H=32, T=64, the candidates sharded
+    over the ranks, one RCCL all-gather of scores + first actions per step (serial steps: the collective sits on the path)."""
+    import types
+
+    from m3pc_amd import capi, synth
+    from m3pc_amd.planner import HipPlanner
+    S, A = synth.ENV_DIMS["halfcheetah"]
+    dims = synth.Dims(S, A, 64)
+    cfg = types.SimpleNamespace(traj_length=64, action_samples=16384, horizon=32, discount=0.99, temperature=0.01, lmbda=0.6,
+                                plan_guidance="rtg_guiding")
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    p = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None, precision="bf16",
+                   device=local_rank, generator=gen, group=torch.distributed.group.WORLD)
+    hist = synth.make_history(dims, 0)
+    hist["path_length"] = 500
+    s, a, r, h, rtg = p.assemble_window(hist, rtg=3.0)
+    for _ in range(warm):
+        p._guide(capi.MODE_RTG, s, a, r, rtg, h, 0.6)
+    torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        p._guide(capi.MODE_RTG, s, a, r, rtg, h, 0.6)
+    torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
+    am = int(p.last["argmax"].item())
+    p.handle.close()
+    ms = 1e3 * float(dt.item()) / steps
+    return {"what": f"BASELINE configs[3]: halfcheetah shapes rtg_guiding N=16384 H=32 T=64 bf16, candidates sharded over {world} ranks "
+                    f"({16384 // world} per GPU), one RCCL all-gather per step, serial steps",
+            "ms_per_step": round(ms, 4), "plan_steps_per_s": round(1e3 / ms, 2), "steps": steps, "argmax": am}
 
 
 def _time_calls(fn, n, warm=3):
@@ -300,6 +482,33 @@ def _time_calls(fn, n, warm=3):
         ts.append(1e3 * (time.perf_counter() - t0))
     ts.sort()
     return {"p50": round(ts[len(ts) // 2], 4), "min": round(ts[0], 4), "p99": round(ts[min(len(ts) - 1, int(0.99 * len(ts)))], 4), "calls": n}
+
+
+def parity(args, dims, cfg, hist, ref, eps):
+    """What the planner returns against the oracle's fp32 result on the bench workload (C2), for the bf16 headline mode and
+    for fp32 end to end: the same eps (make_eps seed 1), the multinomial drawn from the same generator state."""
+    from m3pc_amd import capi, synth
+    from m3pc_amd.planner import HipPlanner
+    out = {"reference": "oracle/mtm_oracle.py (fp32 PyTorch-CPU restatement, pinned to the reference by tests/golden), eps = make_eps(N, dims, 1)"}
+    scale = float(ref["expect_return"].abs().max())
+    for prec in ("bf16", "fp32"):
+        gen = torch.Generator(device="cuda").manual_seed(1234)
+        p = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None, precision=prec, generator=gen)
+        s, a, r, h, rtg = p.assemble_window(hist, rtg=3.0)
+        p._guide(capi.MODE_RTG, s, a, r, rtg, h, 0.6, eps=eps.cuda())  # (first step: calibrates delta)
+        state = gen.get_state()
+        sa, ev = p._guide(capi.MODE_RTG, s, a, r, rtg, h, 0.6, eps=eps.cuda())
+        gen.set_state(state)
+        idx_ref = int(torch.multinomial(ref["p"].cuda(), 1, generator=gen).item())  # torch's own draw from the ORACLE's p, same variates
+        er = p.last["expect_return"].cpu()
+        out[prec] = {"argmax_match": int(p.last["argmax"].item()) == int(ref["argmax"]),
+                     "eval_action_err": float((ev.cpu() - ref["eval_action"]).abs().max()),
+                     "sample_idx_match": int(p.last["sample_idx"].item()) == idx_ref,
+                     "expect_return_err_over_scale": float((er - ref["expect_return"]).abs().max()) / scale,
+                     "p_err": float((p.last["p"].cpu() - ref["p"]).abs().max()),
+                     "n_rescored": p.last.get("n_rescored")}
+        p.handle.close()
+    return out
 
 
 def extras(args, dims, cfg, hist, planner, S, A):
@@ -340,16 +549,26 @@ def extras(args, dims, cfg, hist, planner, S, A):
         p8 = HipPlanner(c8, synth.make_state_dict(d8, 0), synth.make_tokenizer_stats(d8, 0), None, precision=prec,
                         generator=torch.Generator(device="cuda").manual_seed(1))
         ship[prec] = _time_calls(lambda: p8.action_sample(h8, plan=True, eval=True, rtg=3.0).cpu(), 40)
+        if prec == "bf16":  # several environments in flight at the shipped config (rollout.evaluate_plan's pattern)
+            hs8 = [dict(synth.make_history(d8, i), path_length=500) for i in range(8)]
+            for _ in range(3):
+                p8.action_sample_batch(hs8, eval=True, rtg=3.0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                p8.action_sample_batch(hs8, eval=True, rtg=3.0)
+            torch.cuda.synchronize()
+            ship["bf16_pipelined_E8_ms_per_step"] = round(1e3 * (time.perf_counter() - t0) / 80, 4)
         if prec == "fp32":  # zero-shot goal reaching, one env per call (zeroshot_omtm/learner.py:151-261, config_hopper.yaml)
             ship["zeroshot_piid_B1"] = _time_calls(lambda: p8.action_piid_sample(h8, eval=True, rtg=2.5).cpu(), 40)
         p8.handle.close()
     out["latency_ms_shipped"] = {"config": "hopper rtg_guiding N=625 H=4 T=8 (closed loop, per call)", **ship}
-    # batched multi-env planning: E windows x N candidates per call, pipelined like the headline
+    # batched multi-env planning: E windows x N candidates per call, incl. host window assembly and H2D copies
     if args.precision == "bf16" and cfg.plan_guidance == "rtg_guiding":
         bat = {}
         for E in (1, 4, 8):
             pb = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None, precision="bf16",
-                            generator=torch.Generator(device="cuda").manual_seed(1), max_batch=E, max_windows=E)
+                            generator=torch.Generator(device="cuda").manual_seed(1))
             hs = []
             for i in range(E):
                 hi = synth.make_history(dims, i)
@@ -366,7 +585,8 @@ def extras(args, dims, cfg, hist, planner, S, A):
             dt_ = (time.perf_counter() - t0) / reps
             bat[f"E{E}"] = {"ms_per_call": round(1e3 * dt_, 4), "plan_steps_per_s": round(E / dt_, 2)}
             pb.handle.close()
-        out["batched"] = {"what": "action_sample_batch: E env windows x N=%d candidates per call (incl. window H2D copies)" % cfg.action_samples,
+        out["batched"] = {"what": "action_sample_batch: E env windows x N=%d candidates per call, one pipelined plan step per window "
+                                  "(incl. host window assembly and H2D copies; the call returns when all E are resolved)" % cfg.action_samples,
                           **bat}
     return out
 

@@ -53,8 +53,10 @@ def tokenizer_stats(stats: Mapping[str, Any]) -> Dict[str, Dict[str, np.ndarray]
 
 
 def load_statistics_pickle(path: str) -> Dict[str, Dict[str, np.ndarray]]:
-    """The statistics cache the reference's dataset writes (``/tmp/d4rl/d4rl_statistics_{env}_{T}_{discount}.pkl``,
-    research/omtm/datasets/sequence_dataset.py:357-404): a pickled ``{key: DataStatistics}``.  The pickle refers to the
+    """The statistics cache the reference's dataset writes (``/tmp/d4rl/d4rl_statistics_{env_name}[_d={discount}|_avg].pkl``,
+    research/omtm/datasets/sequence_dataset.py:357-404): a pickled ``{key: DataStatistics}``.  Caches written by older runs
+    carry the key ``values`` instead of ``returns``; they are accepted and renamed as ``trajectory_statistics`` does
+    (sequence_dataset.py:372-377).  The pickle refers to the
     reference's ``research.omtm.datasets.base.DataStatistics`` class, which is not importable here: objects of that one
     class are rebuilt as plain namespaces, anything else is refused (no arbitrary code runs)."""
     import pickle
@@ -74,6 +76,8 @@ def load_statistics_pickle(path: str) -> Dict[str, Dict[str, np.ndarray]]:
 
     with open(path, "rb") as f:
         obj = _Unpickler(f).load()
+    if isinstance(obj, dict) and "values" in obj and "returns" not in obj:
+        obj["returns"] = obj.pop("values")
     if not isinstance(obj, dict) or not all(k in obj for k in KEYS):
         raise ValueError(f"{path}: not a {{key: DataStatistics}} pickle with keys {KEYS}")
     return tokenizer_stats(obj)

@@ -49,12 +49,13 @@ def check_same_generator(generator: torch.Generator, group=None) -> None:
                                "identically on every rank")
 
 
-def gather_candidates(er_shard: torch.Tensor, a0_shard: torch.Tensor, n_total: int, group=None):
+def gather_candidates(er_shard: torch.Tensor, a0_shard: torch.Tensor, n_total: int, group=None, force: bool = False):
     """All-gather per-shard scores (n_r,) and first actions (n_r, A) into full (N,) / (N, A) tensors in
     candidate order.  One collective: scores and actions travel in a single packed (n_r, 1+A) buffer,
-    padded to the largest shard so the collective is fixed-size (unequal shards only when N % G != 0)."""
+    padded to the largest shard so the collective is fixed-size (unequal shards only when N % G != 0).
+    force: run the collective even in a world of one (tests/test_dist_gpu.py: RCCL on the compute stream on a one-GPU box)."""
     rank, world = world_info(group)
-    if world == 1:
+    if world == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return er_shard, a0_shard
     if er_shard.is_cuda and dist.get_backend(group) != "nccl":
         # a CPU-only backend (gloo in the tests): the packed buffer travels through the host

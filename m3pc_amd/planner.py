@@ -82,7 +82,8 @@ class PlanTicket:
         self.chain = self.tchain = None
         self.eps = self.expo = self.res = self.er_b = self.er = self.a0 = self.sel = self.top = None
         self.tail_enqueued = False
-        self.kmin = self.kmax = self.n_done = 0
+        self.kmin = self.kmax = self.n_done = self.index = 0
+        self.grow_in, self.kfirst_in = 0.0, 0
         self.seq_mrg = 0.0
         self.delta = None
         self.seq_win = 0.0
@@ -108,26 +109,27 @@ class HipPlanner:
                  obs_mean=None, obs_std=None, n_embd: int = 512, n_head: int = 4, n_enc_layer: int = 2,
                  n_dec_layer: int = 1, precision: str = "fp32", rescore_topk: int = 16, device: Optional[int] = None,
                  group=None, generator: Optional[torch.Generator] = None, max_batch: int = 1,
-                 rescore: str = "bound", rescore_min: int = 8, rescore_max: int = 64, rescore_delta: Optional[float] = None,
+                 rescore: str = "bound", rescore_min: int = 8, rescore_max: int = 128, rescore_delta: Optional[float] = None,
                  max_windows: int = 1, pipeline_depth: int = 2, chain_priority: int = -1, tail_stream: bool = True):
         """cfg: any object with traj_length, action_samples, horizon, discount, temperature, lmbda,
         plan_guidance (finetune.py RunConfig fields read at learner.py:276,319,342).
         tokenizer_manager: a TokenizerManager (this package's) or {key: {"mean","std","min","max"}}.
         precision: "fp32" (reference-accurate) or "bf16" (bf16 MFMA candidate pass followed by an fp32 re-score of the
         candidates that can still be the arg-max, so that the arg-max does not depend on bf16 rounding):
-          rescore="bound" (default): every candidate whose bf16 score lies within 2*delta of the bf16 maximum is
-            re-scored (at least ``rescore_min``, at most ``rescore_max``).  delta bounds the bf16 error of score
-            DIFFERENCES: |(b_i - f_i) - median(b - f)| <= delta; then f_argmax >= f_j for all j implies
-            b_argmax >= b_max - 2 delta.  delta is calibrated per weight load on 64 candidates scored in both
-            arithmetics (1.5 x the largest deviation seen), or fixed by ``rescore_delta``.  ``planner.last`` reports
-            n_rescored, min_margin_outside (distance from the bf16 maximum to the best candidate NOT re-scored: the
-            bound held with room when it exceeds 2*delta) and delta.  One 16-byte device-to-host read per step.
-          rescore="topk": the fixed ``rescore_topk`` best candidates (round-1 behaviour, no host read).
-          Either way the select runs on the MERGED vector (m3pc_rescore_merge): fp32 scores for the re-scored candidates,
-          bf16 scores minus the estimated common shift (median of bf16 - fp32 over the re-scored set) for the rest, so an
-          un-re-scored candidate cannot win the arg-max through a constant bf16 offset.  delta is re-checked every step on the
-          re-scored set (it grows when 1.5 x the deviation seen there exceeds it); when more than ``rescore_max`` candidates
-          lie inside the window the whole window set is re-scored in chunks (a warning is raised once; ``last["saturated"]``).
+          rescore="bound" (default): a CERTIFIED re-score.  Model: bf16 score b_j = f_j + c + e_j with a common shift c and a
+            deviation |e_j| <= delta.  The ``rescore_min`` best candidates by bf16 score are re-scored in fp32; from them the
+            library takes c = median(b - f) and f* = the best fp32 score, and counts need = #{j : b_j > f* + c - delta} -- the
+            only candidates that can still beat f* (m3pc_rescore_merge).  need <= what was re-scored certifies the arg-max; else
+            the candidates up to ``need`` are re-scored too (a second pass, at most ``rescore_max`` through the list; beyond
+            that the whole set goes through a chunked slow path with a warning, ``last["saturated"]``).  delta is calibrated
+            per weight load on 64 candidates scored in both arithmetics (1.5 x the largest deviation from the median), checked
+            on every step's re-scored set and raised when 1.5 x what that step saw is more (``delta_grown``), or fixed by
+            ``rescore_delta``.  ``planner.last`` reports n_rescored, n_in_window (the first certificate's count),
+            min_margin_outside (the threshold's margin over the best bf16 score NOT re-scored, >= 0 when certified), shift,
+            deviation and delta.  One 16-byte device-to-host read per step, after the select has been enqueued.
+          rescore="topk": the fixed ``rescore_topk`` best candidates (round-1 behaviour, no certificate, no host read).
+          Either way the select runs on the MERGED vector: fp32 scores for the re-scored candidates, bf16 scores minus the
+          estimated shift for the rest, so an un-re-scored candidate cannot win the arg-max through a constant bf16 offset.
         pipeline_depth: how many plan steps ``action_sample_batch`` / ``rollout`` keep in flight (<= capi.SLOTS - 1)."""
         self.cfg = cfg
         self.group = group
@@ -155,8 +157,13 @@ class HipPlanner:
         self.rescore = rescore if self.precision == capi.PREC_BF16 else "none"
         self.rescore_min, self.rescore_max = int(rescore_min), int(rescore_max)
         self._delta_fixed = None if rescore_delta is None else float(rescore_delta)
-        self._delta: Optional[float] = self._delta_fixed
-        self._kspec, self._exceed = int(rescore_min), 0.05  # size of the unconditional first re-score, share of steps that needed more
+        # Adaptive state of the certified re-score.  It must not depend on how many steps are in flight (a pipelined run has
+        # to reproduce the serial one bit for bit), so it is LAGGED: step t uses what the steps up to t - capi.SLOTS saw --
+        # exactly the steps that are certain to be resolved when step t is issued (its slot's previous owner is step
+        # t - SLOTS) -- whatever has been resolved since.  _delta0: the calibrated bound; _hist[t] = (deviation, need) of step t.
+        self._delta0: Optional[float] = self._delta_fixed
+        self._hist: Dict[int, tuple] = {}
+        self._step_index = 0
         self.generator = generator
         if self.world > 1:
             # every rank draws eps / the multinomial variates itself: the streams must be the same ones
@@ -173,7 +180,7 @@ class HipPlanner:
         self._host = np.zeros((T * (S + A + 1),), dtype=np.float32)  # [states (T,S) | actions (T,A) | rewards (T,1)] blocks
         self.last: Dict[str, torch.Tensor] = {}
         self.pipeline_depth = max(1, min(int(pipeline_depth), capi.SLOTS - 1))
-        self._slots = [_Slot(i, self.device) for i in range(capi.SLOTS)]
+        self._slots = [_Slot(i, self.device).ready(self) for i in range(capi.SLOTS)]
         self._next_slot = 0
         self._chain = None          # the policy-pass stream (created on first pipelined use)
         self._tchain = None         # the re-score + select stream (tail_stream=False: the policy-pass stream)
@@ -183,6 +190,7 @@ class HipPlanner:
         self._warned_saturated = False
         self.delta_grown = 0        # how often the per-step deviation check raised delta since the last weight load
         self.action_list = []       # zero-shot "piid_allout" (action_piid_list_sample)
+        self._force_collective = False  # test hook: run the all-gather even in a world of one
         self._bf16_offset = 0.0     # test hook: a constant added to the bf16 scores before the re-score
 
     # ---------------------------------------------------------------------------------------- weights
@@ -192,9 +200,37 @@ class HipPlanner:
         for tk in [sl.owner for sl in getattr(self, "_slots", []) if sl.owner is not None]:
             self._finish(tk)  # steps in flight were issued against the old weights: resolve them first
         self.handle.load_weights(state_dict)
-        self._delta = getattr(self, "_delta_fixed", None)  # the bf16 error bound belongs to the weights: re-calibrate
-        self._kspec, self._exceed = int(getattr(self, "rescore_min", 8)), 0.05
+        self._delta0 = getattr(self, "_delta_fixed", None)  # the bf16 error bound belongs to the weights: re-calibrate
+        self._hist = {}
         self.delta_grown = 0
+
+    # -- adaptive re-score state ------------------------------------------------------------------------
+    @property
+    def _delta(self) -> Optional[float]:
+        """The bound as the next step would see it if everything resolved so far counted (reporting; lock-step batches)."""
+        if self._delta0 is None:
+            return None
+        if self._delta_fixed is not None:
+            return self._delta0
+        return max([self._delta0] + [1.5 * d for d, _ in self._hist.values()])
+
+    @_delta.setter
+    def _delta(self, value):
+        self._delta0 = value
+        self._hist = {}
+
+    def _adapt(self, index: int):
+        """(growth of delta, size of the first re-score pass) for step `index`, from the steps up to index - SLOTS."""
+        seen = [(i, v) for i, v in self._hist.items() if i <= index - capi.SLOTS]
+        grow = max([1.5 * d for _, (d, _) in seen], default=0.0) if self._delta_fixed is None else 0.0
+        # first pass: what the 80th percentile of the recent steps' certificates asked for, in fours (a second pass costs a
+        # whole fp32 chain, ~0.3 ms; four more candidates in the first ~0.02-0.05 ms)
+        recent = sorted(n for _, (_, n) in sorted(seen)[-16:])
+        kfirst = self.rescore_min
+        if recent:
+            q = recent[min(len(recent) - 1, int(0.8 * len(recent)))]
+            kfirst = max(self.rescore_min, -(-q // 4) * 4)
+        return grow, kfirst
 
     def load_critic(self, q_state_dict, obs_mean, obs_std):
         self.handle.set_critic(q_state_dict, obs_mean, obs_std)
@@ -279,6 +315,8 @@ class HipPlanner:
         sl = (slot if slot is not None else self._acquire_slot()).ready(self)
         tk = PlanTicket(self, sl, mode, states, actions, rewards, float(rtg), int(h), float(lmbda), returns)
         sl.owner = tk
+        tk.index, self._step_index = self._step_index, self._step_index + 1
+        tk.grow_in, tk.kfirst_in = self._adapt(tk.index)
         main = torch.cuda.current_stream(self.device)
         chain = self._chain_stream() if pipelined else None
         tk.chain = chain
@@ -312,7 +350,7 @@ class HipPlanner:
         res = hd.candidate_pass(mode, states, actions, rewards, eps, h, tk.lmbda, float(cfg.discount), N, begin, count,
                                 precision=self.precision, slot=sl.i)
         er, a0 = res["expect_return"], res["sample_actions"][:, 0]
-        er, a0 = mdist.gather_candidates(er, a0, N, self.group)
+        er, a0 = mdist.gather_candidates(er, a0, N, self.group, force=self._force_collective)
         if self._bf16_offset and self.precision == capi.PREC_BF16:
             er = er + self._bf16_offset
         tk.res, tk.er_b, tk.a0 = res, er, a0
@@ -345,13 +383,15 @@ class HipPlanner:
             else:
                 rs, tail = self._rescore_args(tk)
                 if self.rescore == "bound":
-                    if self._delta is None:
-                        self._delta = self._calibrate(tk)
+                    if self._delta0 is None:
+                        self._delta0 = self._calibrate(tk)
                     kmax = max(min(self.rescore_max, N - 1 if N > 1 else 1), 1)
-                    kmin = max(min(max(self.rescore_min, self._kspec), N, kmax), 1)
+                    kmin = max(min(max(self.rescore_min, tk.kfirst_in), N, kmax), 1)
+                    tk.delta = max(self._delta0, tk.grow_in)
                 else:
                     kmax = kmin = max(min(self.rescore_topk, N, hd.max_rescore), 1)
-                tk.kmin, tk.kmax, tk.delta = kmin, kmax, self._delta
+                    tk.delta = 0.0
+                tk.kmin, tk.kmax = kmin, kmax
                 # The kmax + 1 best candidates by bf16 score, best first.  The set that has to be re-scored is a prefix of this
                 # list whose length only the re-score itself can tell (m3pc_rescore_merge's certificate), so its first kmin
                 # entries are re-scored, merged and the select is enqueued BEFORE anybody reads anything: the device never
@@ -368,7 +408,6 @@ class HipPlanner:
     def _merge(self, tk, n, index=None, b_top=None, f_top=None):
         sl = tk.slot
         tk.seq_mrg = sl.hs_mrg.next_seq()
-        tk.delta = self._delta if self.rescore == "bound" else 0.0
         self.handle.rescore_merge(tk.er_b, tk.top if index is None else index, n, sl.b_top if b_top is None else b_top,
                                   sl.f_top if f_top is None else f_top, delta=tk.delta, merged=tk.er, stats=sl.mstats,
                                   host_stats=sl.hs_mrg.buf, seq=tk.seq_mrg)
@@ -397,9 +436,10 @@ class HipPlanner:
                     n_first_need = need
                 redo = False
                 # delta bounds the deviation of (bf16 - fp32) from the common shift: every step checks it on its re-scored set
-                # and raises it when 1.5 x what it saw is more (the same numbers, hence the same decision, on every rank)
-                if self._delta_fixed is None and 1.5 * dev > self._delta:
-                    self._delta = 1.5 * dev
+                # and raises it -- for itself at once, for the steps from SLOTS later on through _adapt -- when 1.5 x what it
+                # saw is more (the same numbers, hence the same decision, on every rank and at any pipeline depth)
+                if self._delta_fixed is None and 1.5 * dev > tk.delta:
+                    tk.delta = 1.5 * dev
                     self.delta_grown += 1
                     redo = tk.n_done < N and not saturated
                 if saturated or tk.n_done >= N:
@@ -425,14 +465,13 @@ class HipPlanner:
             n_re = int(top.numel()) if top is not None else tk.n_done
             if top is None:
                 top = tk.top[:n_re]
-            # the size of the first (unconditional) re-score follows the workload: a second pass costs a whole fp32 chain
-            # (~0.3 ms), four more candidates in the first ~0.02-0.05 ms -- grown when more than a fifth of the recent steps
-            # needed the second pass, shrunk again when (almost) none did.  Same decisions on every rank (same counts).
-            self._exceed += (float(n_re > kmin) - self._exceed) / 16.0
-            if self._exceed > 0.2 and kmin < kmax:
-                self._kspec, self._exceed = min(kmax, kmin + 4), 0.05
-            elif self._exceed < 0.005 and self._kspec > self.rescore_min:
-                self._kspec, self._exceed = max(self.rescore_min, self._kspec - 4), 0.05
+            # what this step saw feeds the steps from SLOTS later on (_adapt): the bound, and the size of the first pass
+            self._hist[tk.index] = (float(dev), min(int(n_first_need), kmax))
+            for i in [i for i in self._hist if i < tk.index - 64]:
+                # (old enough that every step still to come would count it anyway: fold its deviation into the base bound)
+                if self._delta_fixed is None:
+                    self._delta0 = max(self._delta0, 1.5 * self._hist[i][0])
+                del self._hist[i]
             extra = dict(n_rescored=n_re, n_in_window=n_first_need, min_margin_outside=float(margin), delta=tk.delta, n_first=kmin,
                          saturated=saturated, shift=shift, deviation=dev)
         elif self.rescore == "topk":

@@ -102,9 +102,14 @@ def test_statistics_pickle_reader(tmp_path):
         _sys.modules.setdefault(name, _types.ModuleType(name))
     _sys.modules["research.omtm.datasets.base"] = mod
     try:
-        path = tmp_path / "d4rl_statistics_hopper-medium-v2_8_0.99.pkl"
+        path = tmp_path / "d4rl_statistics_hopper-medium-v2.pkl"
         with open(path, "wb") as f:
             pickle.dump({k: DataStatistics(v["mean"], v["std"], v["min"], v["max"]) for k, v in st.items()}, f)
+        # a cache written by an older run of the reference: "values" instead of "returns" (sequence_dataset.py:372-377)
+        old_path = tmp_path / "d4rl_statistics_hopper-medium-v2_d=1.0.pkl"
+        with open(old_path, "wb") as f:
+            pickle.dump({("values" if k == "returns" else k): DataStatistics(v["mean"], v["std"], v["min"], v["max"])
+                         for k, v in st.items()}, f)
     finally:
         for name in ("research.omtm.datasets.base", "research.omtm.datasets", "research.omtm", "research"):
             _sys.modules.pop(name, None)
@@ -112,6 +117,8 @@ def test_statistics_pickle_reader(tmp_path):
     for k in synth.KEYS:
         for n in ("mean", "std", "min", "max"):
             assert np.array_equal(got[k][n], st[k][n].astype(np.float32))
+    got_old = checkpoint.load_statistics_pickle(str(old_path))
+    assert set(got_old) == set(synth.KEYS) and np.array_equal(got_old["returns"]["mean"], got["returns"]["mean"])
     evil = tmp_path / "evil.pkl"
     with open(evil, "wb") as f:
         pickle.dump({k: os.system for k in synth.KEYS}, f)

@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,case", [(2, "c2"), (3, "c2"), (2, "c3"), (2, "c4"), (2, "odd")])
+@pytest.mark.parametrize("world,case", [(2, "c2"), (3, "c2"), (2, "c3"), (2, "c4"), (2, "odd"), (2, "attach"), (1, "rccl1")])
 def test_sharded_planner_equals_single_gpu(world, case):
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
