@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define M3PC_ABI_VERSION 2
+#define M3PC_ABI_VERSION 3
 
 #define M3PC_OK 0
 #define M3PC_EINVAL (-1)   /* bad argument / shape mismatch            */
@@ -110,7 +110,16 @@ typedef struct m3pc_plan_args {
     int returns_f64;   /* dtype of `returns`: 0 float32, 1 float64                               */
     const void* returns; /* optional device (T,) raw returns row of the window (what
                           trajectory["returns"] holds, learner.py:272-293); NULL: `rtg` everywhere */
+    int flags;         /* M3PC_PLAN_* bits (m3pc_candidate_pass); 0 = none                       */
+    int reserved;      /* 0                                                                      */
 } m3pc_plan_args;
+
+/* m3pc_plan_args::flags.  M3PC_PLAN_DEFER_JOIN (m3pc_candidate_pass only): a large bf16 pass runs its candidate
+ * parts on the caller's stream and on streams of the handle; by default the caller's stream waits for all of them
+ * before the call returns to it (outputs complete in stream order).  With this bit it does not: the outputs of the
+ * parts that ran elsewhere are complete only behind m3pc_candidate_join(h, slot, stream), and the caller's stream is
+ * free to start the next step's first part while the last part of this one still runs (no idle tail per step). */
+#define M3PC_PLAN_DEFER_JOIN 1
 
 const char* m3pc_last_error(void);
 int m3pc_abi_version(void);
@@ -170,6 +179,10 @@ int m3pc_policy_pass(m3pc_handle* h, const m3pc_plan_args* args, const float* st
 int m3pc_candidate_pass(m3pc_handle* h, const m3pc_plan_args* args, const float* states, const float* actions,
                         const float* rewards, const float* eps, float* loc, float* std, float* sample_actions,
                         float* expect_return, float* pred_rewards, float* pred_boot, void* stream);
+/* Orders `stream` behind every part of the last m3pc_candidate_pass(M3PC_PLAN_DEFER_JOIN) of step slot `slot`
+ * (no-op when that pass joined by itself or ran in one part).  The consumer of a step's scores -- the re-score +
+ * select of learner.py:318-325 -- calls it on its own stream. */
+int m3pc_candidate_join(m3pc_handle* h, int slot, void* stream);
 
 /* One MPC plan step up to (not including) the cross-candidate select:
  * rtg_guiding / critic_lambda_guiding / noise_adding_lambda (learner.py:142-316).

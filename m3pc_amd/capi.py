@@ -21,13 +21,13 @@ KEYS = ("states", "actions", "rewards", "returns")
 MODE_RTG, MODE_CRITIC, MODE_NOISE = 0, 1, 2
 PREC_FP32, PREC_BF16 = 0, 1
 PROF_LAYER_TAIL = 16  # m3pc_profile_read: the fused layer-tail launches only
-ABI_VERSION = 2
+ABI_VERSION = 3
 SLOTS = 4  # M3PC_SLOTS: plan steps in flight per handle
 
 EXPORTS = (
     "m3pc_last_error", "m3pc_abi_version", "m3pc_create", "m3pc_destroy", "m3pc_load_weights", "m3pc_load_stats",
     "m3pc_set_tokenizer", "m3pc_set_critic", "m3pc_tokenize", "m3pc_detokenize", "m3pc_forward",
-    "m3pc_policy_pass", "m3pc_candidate_pass",
+    "m3pc_policy_pass", "m3pc_candidate_pass", "m3pc_candidate_join",
     "m3pc_plan_step", "m3pc_plan_step_batch", "m3pc_score_actions", "m3pc_rescore", "m3pc_rescore_topk", "m3pc_topk_window",
     "m3pc_rescore_listed", "m3pc_rescore_merge", "m3pc_select",
     "m3pc_profile_enable",
@@ -48,7 +48,11 @@ class NamedTensor(C.Structure):
 class PlanArgs(C.Structure):
     _fields_ = [("mode", C.c_int), ("precision", C.c_int), ("horizon", C.c_int), ("n_total", C.c_int),
                 ("n_begin", C.c_int), ("n_count", C.c_int), ("lmbda", C.c_double), ("discount", C.c_double),
-                ("rtg", C.c_double), ("slot", C.c_int), ("returns_f64", C.c_int), ("returns", C.c_void_p)]
+                ("rtg", C.c_double), ("slot", C.c_int), ("returns_f64", C.c_int), ("returns", C.c_void_p),
+                ("flags", C.c_int), ("reserved", C.c_int)]
+
+
+PLAN_DEFER_JOIN = 1
 
 
 class M3pcError(RuntimeError):
@@ -84,6 +88,7 @@ def load_library(path: Optional[str] = None):
         "m3pc_forward": [vp, i, C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp, vp, i, vp],
         "m3pc_policy_pass": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, vp],
         "m3pc_candidate_pass": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "m3pc_candidate_join": [vp, i, vp],
         "m3pc_plan_step": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_plan_step_batch": [vp, C.POINTER(PlanArgs), i, vp, vp, vp, C.POINTER(d), vp, vp, vp, vp, vp, vp, vp],
         "m3pc_score_actions": [vp, C.POINTER(PlanArgs), i, vp, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -273,7 +278,7 @@ class Handle:
         return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
 
     def _args(self, mode, precision, horizon, n_total, n_begin, n_count, lmbda, discount, rtg, slot=0, returns=None):
-        a = PlanArgs(mode, precision, horizon, n_total, n_begin, n_count, lmbda, discount, rtg, slot, 0, None)
+        a = PlanArgs(mode, precision, horizon, n_total, n_begin, n_count, lmbda, discount, rtg, slot, 0, None, 0, 0)
         if returns is not None:
             assert returns.is_cuda and returns.is_contiguous() and returns.numel() == self.T
             assert returns.dtype in (torch.float32, torch.float64)
@@ -291,9 +296,11 @@ class Handle:
 
     def candidate_pass(self, mode: int, states, actions, rewards, eps, horizon: int, lmbda: float, discount: float,
                        n_total: int, n_begin: int = 0, n_count: Optional[int] = None, precision: int = PREC_FP32, slot: int = 0,
-                       want_debug: bool = False, out=None):
+                       want_debug: bool = False, out=None, defer_join: bool = False):
         """Candidates + PASS 2 + scores of a plan step on the current stream (candidate workspace) from ``slot``'s policy
-        head.  ``out``: optional dict of preallocated loc / std / sample_actions / expect_return."""
+        head.  ``out``: optional dict of preallocated loc / std / sample_actions / expect_return.  ``defer_join``: the
+        current stream does not wait for the parts of the pass that run on the handle's own streams; the consumer of the
+        scores calls ``candidate_join(slot)`` on its stream (M3PC_PLAN_DEFER_JOIN)."""
         n_count = n_total - n_begin if n_count is None else n_count
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -312,6 +319,7 @@ class Handle:
         pr = torch.empty((n_count, horizon), **f32) if want_debug else None
         pb = torch.empty((n_count, horizon), **f32) if want_debug else None
         args = self._args(mode, precision, horizon, n_total, n_begin, n_count, lmbda, discount, 0.0, slot)
+        args.flags = PLAN_DEFER_JOIN if defer_join else 0
         ins = [self._f32(t) for t in (states, actions, rewards, eps)]
         check(self.lib.m3pc_candidate_pass(self._h, C.byref(args), _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), _ptr(ins[3]),
                                            _ptr(loc), _ptr(std), _ptr(acts), _ptr(er), _ptr(pr), _ptr(pb), _stream(dev)))
@@ -319,6 +327,10 @@ class Handle:
         if want_debug:
             res["pred_rewards"], res["pred_boot"] = pr, pb
         return res
+
+    def candidate_join(self, slot: int):
+        """Order the current stream behind every part of ``slot``'s last candidate pass enqueued with ``defer_join``."""
+        check(self.lib.m3pc_candidate_join(self._h, int(slot), _stream(self.device)))
 
     def plan_step(self, mode: int, states, actions, rewards, eps, horizon: int, rtg: float, lmbda: float,
                   discount: float, n_total: int, n_begin: int = 0, n_count: Optional[int] = None,

@@ -168,6 +168,16 @@ struct m3pc_handle {
     std::vector<hipStream_t> auxs;   // auxs[0] == aux
     std::vector<hipEvent_t> ev_joins;
     std::vector<int> stream_split;
+    // Deferred joins (M3PC_PLAN_DEFER_JOIN): the parts of a candidate pass that ran on the handle's own streams are joined by
+    // the consumer of the step (m3pc_candidate_join) instead of the caller's stream.  slot_join[s][i]: recorded behind part
+    // i + 1 of the last deferred pass of slot s; aux_unjoined[i]: stream auxs[i] holds candidate-workspace work nobody
+    // waited for on behalf of the workspace (ws_sync); defer_parts: the part sizes of the passes in flight -- a pass with the
+    // same sizes touches, per stream, the very rows that stream's earlier work touched, and needs no cross-stream order.
+    hipEvent_t slot_join[M3PC_SLOTS][3] = {};
+    int slot_join_n[M3PC_SLOTS] = {};
+    hipEvent_t aux_tail[3] = {};
+    bool aux_unjoined[3] = {false, false, false};
+    std::vector<int> defer_parts;
     std::map<std::string, std::unique_ptr<Plan>> plans;
     Plan* mask_plan[2][65] = {};  // get_mask_plan cache: [rcbc | fd][idx]
     // packed MFMA-fragment weight streams of the fused layer tails (block_fused.hip), by block prefix
@@ -237,6 +247,18 @@ void bind_slot(m3pc_handle* h, int s) {
     h->loc = h->slot[s].loc;
     h->sd = h->slot[s].sd;
     h->rtok = h->slot[s].rtok;
+}
+
+// Orders `st` behind the deferred parts of earlier candidate passes: every call that touches the candidate workspace
+// in any other shape than those passes starts with it.
+int ws_sync(m3pc_handle* h, hipStream_t st) {
+    for (int i = 0; i < 3; ++i)
+        if (h->aux_unjoined[i]) {
+            HIPCHK(hipStreamWaitEvent(st, h->aux_tail[i], 0));
+            h->aux_unjoined[i] = false;
+        }
+    h->defer_parts.clear();
+    return 0;
 }
 
 int alloc_ws(m3pc_handle* h, m3pc_handle::Base& b, long long R_, int max_cand, long long splitk_bytes) {
@@ -1488,6 +1510,9 @@ int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out) {
     HIPCHK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    for (int s = 0; s < M3PC_SLOTS; ++s)
+        for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreateWithFlags(&h->slot_join[s][i], hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreateWithFlags(&h->aux_tail[i], hipEventDisableTiming));
     if (const char* e = M3PC_ENV("M3PC_TWO_STREAM")) h->two_stream = atoi(e) != 0;
     h->auxs.push_back(h->aux);
     h->ev_joins.push_back(h->ev_join);
@@ -1554,6 +1579,11 @@ int m3pc_destroy(m3pc_handle* h) {
         hipStreamDestroy(h->auxs[i]);
         hipEventDestroy(h->ev_joins[i]);
     }
+    for (int s = 0; s < M3PC_SLOTS; ++s)
+        for (int i = 0; i < 3; ++i)
+            if (h->slot_join[s][i]) hipEventDestroy(h->slot_join[s][i]);
+    for (int i = 0; i < 3; ++i)
+        if (h->aux_tail[i]) hipEventDestroy(h->aux_tail[i]);
     if (h->aux) hipStreamDestroy(h->aux);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -1591,6 +1621,7 @@ int m3pc_load_weights(m3pc_handle* h, const m3pc_named_tensor* tensors, int n, v
     if (!h || !tensors) return fail(M3PC_EINVAL, "null argument");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->device));
+    CHK(ws_sync(h, st));  // (deferred candidate parts still read the weights this call is about to replace)
     // The first call must bring every tensor; later calls may bring any subset (fine-tuning changes the weights between
     // rollouts, finetune.py:306): only what depends on a tensor that came is re-derived.
     const bool first = !h->weights_loaded;
@@ -1771,6 +1802,7 @@ int m3pc_forward(m3pc_handle* h, int batch, const float* const tokens[4], const 
         in.bstride[k] = (long long)h->T * h->feat[k];
     }
     h->allow_splitk = true;
+    CHK(ws_sync(h, (hipStream_t)stream));
     return forward_impl(h, pl, in, batch, out_states, out_rewards, out_returns, out_mu, out_std,
                         precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32, (hipStream_t)stream);
 }
@@ -1853,25 +1885,29 @@ int m3pc_candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* st
     bind_ws(h, &h->base);
     h->allow_splitk = false;
 
-    // candidates
-    SampleP sp;
-    memset(&sp, 0, sizeof(sp));
-    sp.hist_actions = actions;
-    sp.loc = h->loc;
-    sp.sd = h->sd;
-    sp.eps = eps;
-    sp.mode = a->mode == M3PC_MODE_NOISE ? 1 : 0;
-    sp.T = T;
-    sp.A = h->A;
-    sp.idx = idx;
-    sp.h = hh;
-    sp.n_begin = a->n_begin;
-    sp.n_count = a->n_count;
-    sp.cand = h->cand;
-    sp.sample_actions = sample_actions;
-    sp.loc_out = loc;  // the caller's copies of the policy head ride on this launch
-    sp.sd_out = std_;
-    launch_sample(sp, st);
+    // candidates of [c0, c0 + cnt) (relative to n_begin), on the stream of the part that scores them
+    auto sample = [&](int c0, int cnt, hipStream_t s) {
+        SampleP sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.hist_actions = actions;
+        sp.loc = h->loc;
+        sp.sd = h->sd;
+        sp.eps = eps;
+        sp.mode = a->mode == M3PC_MODE_NOISE ? 1 : 0;
+        sp.T = T;
+        sp.A = h->A;
+        sp.idx = idx;
+        sp.h = hh;
+        sp.n_begin = a->n_begin + c0;
+        sp.n_count = cnt;
+        sp.cand = h->base.cand + (size_t)c0 * T * h->A;
+        sp.sample_actions = sample_actions + (size_t)c0 * hh * h->A;
+        if (c0 == 0) {  // the caller's copies of the policy head ride on the first launch
+            sp.loc_out = loc;
+            sp.sd_out = std_;
+        }
+        launch_sample(sp, s);
+    };
 
     // PASS 2 + scoring.  Large bf16 batches are cut into two candidate halves that run the same kernel chain
     // on two HIP streams over disjoint workspace halves.  The fused layer tails work in 128-row tiles, one per CU:
@@ -1880,6 +1916,7 @@ int m3pc_candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* st
     // independent, results are identical to the one-stream order.
     const int dt = a->precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32;
     const int n = a->n_count;
+    h->slot_join_n[a->slot] = 0;
     // (only when one half alone fills the chip with fused-tail tiles: more than 256 tiles of 128 rows in the whole pass)
     if (h->two_stream && dt == DT_BF16 && n >= 512 && (long long)n * (2 * T - hh + 1) > 256 * 128) {
         // part sizes: M3PC_STREAM_SPLIT=a,b,c (lab) or two halves
@@ -1896,6 +1933,11 @@ int m3pc_candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* st
             int n0 = ((n / 2 + 127) / 128) * 128;
             parts = {n0, n - n0};
         }
+        // M3PC_PLAN_DEFER_JOIN: the caller's stream does not wait for the other parts (m3pc_candidate_join does, for the
+        // consumer), and a pass of the same part sizes as the deferred ones before it starts without waiting for them either:
+        // per stream it touches the rows that stream's own earlier work touched.
+        const bool defer = (a->flags & M3PC_PLAN_DEFER_JOIN) != 0 && !h->prof_serial && parts.size() <= 4;
+        if (!(defer && parts == h->defer_parts)) CHK(ws_sync(h, st));
         HIPCHK(hipEventRecord(h->ev_fork, st));
         int rc = 0;
         // enqueued stage by stage, alternating between the parts: the host needs ~1.5 us per launch, and a part whose 45
@@ -1907,23 +1949,44 @@ int m3pc_candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* st
             int c0 = 0;
             for (size_t i = 0; i < parts.size() && rc == 0; ++i) {
                 hipStream_t s = i == 0 || h->prof_serial ? st : h->auxs[i - 1];
-                if (s != st && stg == 0) HIPCHK(hipStreamWaitEvent(s, h->ev_fork, 0));
+                if (stg == 0) {
+                    if (s != st) HIPCHK(hipStreamWaitEvent(s, h->ev_fork, 0));
+                    sample(c0, parts[i], s);
+                }
                 set_view(h, c0, parts[i]);
                 rc = candidate_pass(h, a, states, rewards, parts[i], sample_actions + (size_t)c0 * hh * h->A, expect_return + c0,
                                     pred_rewards ? pred_rewards + (size_t)c0 * hh : nullptr,
                                     pred_boot ? pred_boot + (size_t)c0 * hh : nullptr, dt, s, nullptr,
                                     h->prof_serial ? 0 : stg, h->prof_serial ? 1 << 30 : stg + 1, &lnst[i]);
-                if (s != st && stg == n_stage - 1) {
-                    HIPCHK(hipEventRecord(h->ev_joins[i - 1], s));
-                    HIPCHK(hipStreamWaitEvent(st, h->ev_joins[i - 1], 0));
+                if (s != st && stg == n_stage - 1 && rc == 0) {
+                    if (defer) {
+                        HIPCHK(hipEventRecord(h->slot_join[a->slot][i - 1], s));
+                        HIPCHK(hipEventRecord(h->aux_tail[i - 1], s));
+                        h->aux_unjoined[i - 1] = true;
+                        h->slot_join_n[a->slot] = (int)i;
+                    } else {
+                        HIPCHK(hipEventRecord(h->ev_joins[i - 1], s));
+                        HIPCHK(hipStreamWaitEvent(st, h->ev_joins[i - 1], 0));
+                    }
                 }
                 c0 += parts[i];
             }
         }
+        if (defer && rc == 0) h->defer_parts = parts;
         set_view(h, 0, h->dm.max_candidates);
         return rc;
     }
+    CHK(ws_sync(h, st));
+    sample(0, n, st);
     return candidate_pass(h, a, states, rewards, n, sample_actions, expect_return, pred_rewards, pred_boot, dt, st);
+}
+
+int m3pc_candidate_join(m3pc_handle* h, int slot, void* stream) {
+    if (!h) return fail(M3PC_EINVAL, "null handle");
+    if (slot < 0 || slot >= M3PC_SLOTS) return fail(M3PC_EINVAL, "slot %d outside [0, %d)", slot, M3PC_SLOTS);
+    for (int i = 0; i < h->slot_join_n[slot]; ++i) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->slot_join[slot][i], 0));
+    h->slot_join_n[slot] = 0;
+    return 0;
 }
 
 // m3pc_policy_pass + m3pc_candidate_pass on one stream
@@ -1972,6 +2035,7 @@ int m3pc_score_actions(m3pc_handle* h, const m3pc_plan_args* a, int n_windows, c
     const int dt = a->precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32;
     // few-row fp32 calls (the re-score of a batched plan) run in the chain workspace, like m3pc_rescore
     WsScope ws(h, dt == DT_F32 && n <= h->chain.max_cand);
+    if (h->cur == &h->base) CHK(ws_sync(h, st));
     SampleP sp;
     memset(&sp, 0, sizeof(sp));
     sp.hist_actions = actions;
@@ -2038,6 +2102,7 @@ int m3pc_plan_step_batch(m3pc_handle* h, const m3pc_plan_args* a, int n_windows,
     }
     h->allow_splitk = false;
     h->slot[a->slot].policy_valid = false;  // (m3pc_rescore works on a single-window slot; batched callers re-score with m3pc_score_actions)
+    CHK(ws_sync(h, st));
     // candidates of window w: rows [w N, (w+1) N) of cand / sample_actions, drawn from window w's policy head and eps block
     for (int w = 0; w < E; ++w) {
         SampleP sp;
@@ -2080,6 +2145,7 @@ int m3pc_rescore(m3pc_handle* h, const m3pc_plan_args* a, const float* states, c
     HIPCHK(hipSetDevice(h->device));
     bind_slot(h, a->slot);
     WsScope ws(h, in_chain);
+    if (!in_chain) CHK(ws_sync(h, st));
     float* sa = sample_actions ? sample_actions : h->sa_buf;
     SampleP sp;
     memset(&sp, 0, sizeof(sp));

@@ -82,6 +82,7 @@ class PlanTicket:
         self.chain = self.tchain = None
         self.eps = self.expo = self.res = self.er_b = self.er = self.a0 = self.sel = self.top = None
         self.tail_enqueued = False
+        self.deferred = False
         self.kmin = self.kmax = self.n_done = self.index = 0
         self.grow_in, self.kfirst_in = 0.0, 0
         self.seq_mrg = 0.0
@@ -110,7 +111,8 @@ class HipPlanner:
                  n_dec_layer: int = 1, precision: str = "fp32", rescore_topk: int = 16, device: Optional[int] = None,
                  group=None, generator: Optional[torch.Generator] = None, max_batch: int = 1,
                  rescore: str = "bound", rescore_min: int = 8, rescore_max: int = 128, rescore_delta: Optional[float] = None,
-                 max_windows: int = 1, pipeline_depth: int = 2, chain_priority: int = -1, tail_stream: bool = True):
+                 max_windows: int = 1, pipeline_depth: int = 2, chain_priority: int = -1, tail_stream: bool = True,
+                 defer_join: bool = True):
         """cfg: any object with traj_length, action_samples, horizon, discount, temperature, lmbda,
         plan_guidance (finetune.py RunConfig fields read at learner.py:276,319,342).
         tokenizer_manager: a TokenizerManager (this package's) or {key: {"mean","std","min","max"}}.
@@ -185,6 +187,7 @@ class HipPlanner:
         self._chain = None          # the policy-pass stream (created on first pipelined use)
         self._tchain = None         # the re-score + select stream (tail_stream=False: the policy-pass stream)
         self._tail_stream = bool(tail_stream)
+        self._defer_join = bool(defer_join)  # pipelined steps: the step's tail, not the current stream, joins the candidate parts
         self._chain_priority = int(chain_priority)  # -1: high priority -- its short dependent launches go first when a CU frees up
         self._pending = None        # pipelined ticket whose tail (re-score + select) is not enqueued yet
         self._warned_saturated = False
@@ -347,8 +350,13 @@ class HipPlanner:
         if chain is not None:
             main.wait_event(sl.ev_pol)
         begin, count = mdist.shard_range(N, self.rank, self.world)
+        # pipelined, one rank: the current stream does not wait for the candidate parts that run on the library's own streams
+        # -- the step's tail joins them on its stream (_enqueue_tail) -- so the next step's first part starts right behind this
+        # step's first part while the last part still runs.  (A sharded run gathers the scores on the current stream: joined.)
+        tk.deferred = bool(chain is not None and self.world == 1 and not self._force_collective and not self._bf16_offset
+                           and self._defer_join)
         res = hd.candidate_pass(mode, states, actions, rewards, eps, h, tk.lmbda, float(cfg.discount), N, begin, count,
-                                precision=self.precision, slot=sl.i)
+                                precision=self.precision, slot=sl.i, defer_join=tk.deferred)
         er, a0 = res["expect_return"], res["sample_actions"][:, 0]
         er, a0 = mdist.gather_candidates(er, a0, N, self.group, force=self._force_collective)
         if self._bf16_offset and self.precision == capi.PREC_BF16:
@@ -378,6 +386,8 @@ class HipPlanner:
         if tk.tchain is not None:
             tk.tchain.wait_event(sl.ev_cand)  # (the candidate pass waited for the policy pass: ordered behind both)
         with self._on(tk):
+            if tk.deferred:
+                hd.candidate_join(sl.i)
             if self.rescore == "none":
                 tk.er = tk.er_b
             else:
