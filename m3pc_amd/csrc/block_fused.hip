@@ -5,7 +5,8 @@
 //     a  = LayerNorm2(X')                 (bf16)
 //     H  = gelu(a W1^T + b1)              (bf16, never leaves the registers)
 //     X''= X' + b2 + H W2^T               FFN2 + residual
-//     Hout = bf16(LN_B?(LN_A(X'')))       the LayerNorm(s) that consume the block output
+//     Hout = bf16(LN_A(X''))  [LN_B on top]  the LayerNorm(s) that consume the block output, or -- an encoder layer followed by
+//     QKV  = bf16(LN_A(X'') Wqkv^T + bqkv)    another -- the next layer's whole Q|K|V projection (Hout then never exists)
 //
 // d = 512, ff = 2048.  A workgroup owns 128 token rows, each of its four waves (one per SIMD, the whole 512-entry
 // register file) a strip of 32 of them -- through the whole chain, so nothing but O, the residual rows and the
@@ -66,6 +67,8 @@ constexpr int NCH = BFF / 64;                    // 32 hidden chunks of 64
 constexpr int FR_OUT = NT * KS;                  // 512 out-proj fragments
 constexpr int FR_TOTAL = FR_OUT + NCH * 128;     // 4608
 constexpr int RS_FR = 32, RS_B = RS_FR * 1024, NRS = FR_TOTAL / RS_FR;  // 144 ring stages (= phases) of 32 KiB
+constexpr int QKV_FR = 3 * FR_OUT;                // the next layer's Q|K|V projection behind the layer's own fragments: 1536
+constexpr int NRS_QKV = NRS + QKV_FR / RS_FR;     // 192 stages
 constexpr int NSLOT = 3;
 constexpr int ACT_LDS = 8;                       // LayerNorm-2 fragments of k-steps 24..31 live in LDS: 8 KiB per wave
 constexpr int ACT_OFF = NSLOT * RS_B;
@@ -110,11 +113,27 @@ __global__ __launch_bounds__(256) void pack_block_stream_kernel(const bf16_t* __
     for (int j = 0; j < 8; ++j) o[j] = v[j];
 }
 
-size_t block_stream_bytes() { return (size_t)FR_TOTAL * 1024; }
+// fragments FR_TOTAL.. of a layer's stream: the NEXT layer's in_proj rows (Q, K, V: 512 fragments each, phase sb = k-steps
+// 2 sb, 2 sb + 1 of the 16 feature tiles, permuted k -- the other operand is the LayerNorm of an accumulator)
+__global__ __launch_bounds__(256) void pack_block_qkv_kernel(const bf16_t* __restrict__ Wqkv, bf16_t* __restrict__ out) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= QKV_FR * 64) return;
+    const int f = gid >> 6, lane = gid & 63, r = lane & 31, h = lane >> 5;
+    const int hf = f / FR_OUT, g = f % FR_OUT, sb = g / 32, kk = (g % 32) / 16, jn = g % 16, ks = 2 * sb + kk;
+    const size_t row = (size_t)(BD * hf + 32 * jn + r) * BD;
+    bf16_t* o = out + (size_t)(FR_TOTAL * 64 + gid) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = Wqkv[row + 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3)];
+}
+
+size_t block_stream_bytes() { return (size_t)(FR_TOTAL + QKV_FR) * 1024; }
 bool block_fused_supported(int d, int ff) { return d == BD && ff == BFF; }
 
 void launch_pack_block_stream(const bf16_t* Wo, const bf16_t* W1, const bf16_t* W2, bf16_t* out, hipStream_t st) {
     hipLaunchKernelGGL(pack_block_stream_kernel, dim3(FR_TOTAL * 64 / 256), dim3(256), 0, st, Wo, W1, W2, out);
+}
+void launch_pack_block_qkv(const bf16_t* Wqkv_next, bf16_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(pack_block_qkv_kernel, dim3(QKV_FR * 64 / 256), dim3(256), 0, st, Wqkv_next, out);
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
@@ -154,8 +173,10 @@ __device__ __forceinline__ void acc_touch(f32x16 (&c)[16]) {
 // DBG (timing experiments): 1 = no DMA pieces, 2 = no gelu, 3 = clocks per FFN phase kind into p.stamps[8..11],
 // 4 = VALU slice in a region of its own behind its MFMA, 5 = gelu of every second value only, 6 = no s_barrier in the
 // per-stage sync, 7 = weight fragments read once (no LDS reads in the loops).  2, 5, 6, 7 compute wrong results.  p.stamps: phase stamps (shader clocks) of one workgroup
-template <int DBG>
+// QKV: the stream goes on behind the FFN with the next layer's in_proj rows (p.QKVout)
+template <int DBG, bool QKV>
 __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
+    constexpr int NST = QKV ? NRS_QKV : NRS;  // ring stages of this stream
     __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -170,13 +191,13 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     (void)pt;
     stamps[0] = __builtin_readcyclecounter();
 
-    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream, 0, (unsigned)(FR_TOTAL * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream, 0, (unsigned)(NST * RS_B), 0x00020000);
     (void)w_rs;
     // piece pc (0..7) of stage st: fragment wu + 4 pc of that stage -> the same position of ring slot `slot` = st % 3
     auto piece = [&](int st, int slot, int pc) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc does not know this builtin)
         if (DBG == 1) return;
-        const int sw = st >= NRS ? st - NRS : st;  // past the end: the head of the stream again (never read)
+        const int sw = st >= NST ? st - NST : st;  // past the end: the head of the stream again (never read)
         const int fo = (wu + 4 * pc) * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lptr_t)(smem + slot * RS_B + fo), 16, lane16, sw * RS_B + fo, 0, 0);
 #endif
@@ -208,11 +229,11 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
             *(f32x4*)(tab + T_B2 + i) = *(const f32x4*)(p.b2 + i);
             *(f32x4*)(tab + T_G2 + i) = *(const f32x4*)(p.ln2_g + i);
             *(f32x4*)(tab + T_BE2 + i) = *(const f32x4*)(p.ln2_b + i);
-            if (p.Hout) {
+            if (p.Hout || QKV) {
                 *(f32x4*)(tab + T_GA + i) = *(const f32x4*)(p.lnA_g + i);
                 *(f32x4*)(tab + T_BA + i) = *(const f32x4*)(p.lnA_b + i);
             }
-            if (p.Hout && p.lnB_g[0]) {
+            if (!QKV && p.Hout && p.lnB_g[0]) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     *(f32x4*)(tab + T_GB + k * BD + i) = *(const f32x4*)(p.lnB_g[k] + i);
@@ -497,30 +518,123 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     }
     stamps[5] = __builtin_readcyclecounter();
     acc_touch(acc);
-    if (p.Hout) {
+    auto row_stats = [&](float& rstd, float& nmr) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float x = acc[jn][e];
+                s1 += x;
+                s2 = fmaf(x, x, s2);
+                if (e == 15) __builtin_amdgcn_sched_barrier(0);
+            }
+        s1 = half_swap_sum(s1);
+        s2 = half_swap_sum(s2);
+        const float mean = s1 * (1.0f / BD);
+        rstd = rsqrtf(fmaxf(s2 * (1.0f / BD) - mean * mean, 0.f) + 1e-5f);
+        nmr = -mean * rstd;
+    };
+    if constexpr (QKV) {
+        // ---- the next layer's Q|K|V projection: LN_A(X'') as bf16 fragments (the accumulators are free after that), then
+        // three times 16 phases with the operands SWAPPED (activations = A operand, weights = B operand: the register images
+        // are the same), so that an accumulator holds  lane & 31 = feature, registers = token rows  and one store instruction
+        // writes 64 contiguous bytes of two rows (kv_fused_kernel below has the same scheme)
+        float rstd, nmr;
+        row_stats(rstd, nmr);
+        acc_touch(acc);
+        u32x4 qa[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            asm volatile("" : "+v"(rstd), "+v"(nmr) : : "memory");  // (see LayerNorm-2)
+            __builtin_amdgcn_sched_barrier(0);
+            const int jn = s >> 1;
+            float y[8];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int q = 2 * (s & 1) + k, n = 32 * jn + 8 * q;
+                const f32x4 g = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_GA + n);
+                const f32x4 b = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_BA + n);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[4 * k + i] = fmaf(fmaf(acc[jn][4 * q + i], rstd, nmr), g[i], b[i]);
+            }
+            bf16x8 w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = (bf16_t)y[j];
+            qa[s] = __builtin_bit_cast(u32x4, w);
+            asm volatile("" : "+v"(qa[s]));
+        }
+        const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.QKVout, 0, p.qkv_bytes, 0x00020000);
+        (void)q_rs;
+        unsigned rowoff[16];  // byte offsets of the 16 token rows this lane stores (rows past the end: out of the buffer's range, dropped)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int rr = row0 + 32 * wu + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            rowoff[e] = rr < p.M ? (unsigned)rr * (unsigned)(p.ldq * 2) + (unsigned)(l31 * 2) : 0x80000000u;
+        }
+        auto bias_init = [&](int hf) {
+            float bq[NT];
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) bq[jn] = p.bqkv[BD * hf + 32 * jn + l31];
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[jn][e] = bq[jn];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto store_third = [&](int hf) {
+            acc_touch(acc);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const bf16_t w = (bf16_t)acc[jn][e];
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, w), q_rs, rowoff[e] + (BD * hf + 32 * jn) * 2, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+        };
+        // the X'' stores are out (they share vmcnt with the DMA pieces and complete out of order with respect to them); the
+        // stages 144, 145 landed before the FFN ended.  Fragment groups 0, 1 of stage 144 (slot 0):
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            R[0][k] = frag(0, k);
+            R[1][k] = frag(0, 4 + k);
+        }
+#define QKV_PH(base, sb, SL) phase((base) + (sb), SL{}, no_extra, [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], qa[2 * (sb) + i / 16], a); }, no_valu);
+        bias_init(0);  // Q: phases 144..159 (phase 144 = slot 0)
+        QKV_PH(144, 0, S0) QKV_PH(144, 1, S1) QKV_PH(144, 2, S2) QKV_PH(144, 3, S0) QKV_PH(144, 4, S1) QKV_PH(144, 5, S2)
+        QKV_PH(144, 6, S0) QKV_PH(144, 7, S1) QKV_PH(144, 8, S2) QKV_PH(144, 9, S0) QKV_PH(144, 10, S1) QKV_PH(144, 11, S2)
+        QKV_PH(144, 12, S0) QKV_PH(144, 13, S1) QKV_PH(144, 14, S2) QKV_PH(144, 15, S0)
+        mfma_done_a(acc);
+        store_third(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bias_init(1);  // K: phases 160..175 (slot 1)
+        QKV_PH(160, 0, S1) QKV_PH(160, 1, S2) QKV_PH(160, 2, S0) QKV_PH(160, 3, S1) QKV_PH(160, 4, S2) QKV_PH(160, 5, S0)
+        QKV_PH(160, 6, S1) QKV_PH(160, 7, S2) QKV_PH(160, 8, S0) QKV_PH(160, 9, S1) QKV_PH(160, 10, S2) QKV_PH(160, 11, S0)
+        QKV_PH(160, 12, S1) QKV_PH(160, 13, S2) QKV_PH(160, 14, S0) QKV_PH(160, 15, S1)
+        mfma_done_a(acc);
+        store_third(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bias_init(2);  // V: phases 176..191 (slot 2)
+        QKV_PH(176, 0, S2) QKV_PH(176, 1, S0) QKV_PH(176, 2, S1) QKV_PH(176, 3, S2) QKV_PH(176, 4, S0) QKV_PH(176, 5, S1)
+        QKV_PH(176, 6, S2) QKV_PH(176, 7, S0) QKV_PH(176, 8, S1) QKV_PH(176, 9, S2) QKV_PH(176, 10, S0) QKV_PH(176, 11, S1)
+        QKV_PH(176, 12, S2) QKV_PH(176, 13, S0) QKV_PH(176, 14, S1) QKV_PH(176, 15, S2)
+#undef QKV_PH
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the pieces issued past the end of the stream
+        mfma_done_a(acc);
+        store_third(2);
+    } else if (p.Hout) {
         int orow_h = rtok, sel = 0;
         if (p.out_mod > 0) {  // two row groups per out_mod rows: group s rows go to the s-th compact block, LN_B[s] applies
             const int w = rtok % p.out_mod;
             sel = w / p.out_grp;
             orow_h = sel * (p.M / p.out_mod) * p.out_grp + (rtok / p.out_mod) * p.out_grp + w % p.out_grp;
         }
-        auto row_stats = [&](float& rstd, float& nmr) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int jn = 0; jn < NT; ++jn)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float x = acc[jn][e];
-                    s1 += x;
-                    s2 = fmaf(x, x, s2);
-                    if (e == 15) __builtin_amdgcn_sched_barrier(0);
-                }
-            s1 = half_swap_sum(s1);
-            s2 = half_swap_sum(s2);
-            const float mean = s1 * (1.0f / BD);
-            rstd = rsqrtf(fmaxf(s2 * (1.0f / BD) - mean * mean, 0.f) + 1e-5f);
-            nmr = -mean * rstd;
-        };
         float rstd, nmr;
         row_stats(rstd, nmr);
         acc_touch(acc);
@@ -860,18 +974,23 @@ bool launch_block_fused(const BlockP& p, hipStream_t st) {
     if (p.res_L > 0 && (p.rowtab || p.Xout == p.res || p.res_nshared > p.res_L)) return false;  // (in place, the shared rows would be overwritten while read)
     if (p.Hout && (((uintptr_t)p.Hout & 7) || (p.ldh % 4))) return false;
     if (p.out_mod > 0 && (p.M % p.out_mod != 0 || p.out_mod != 2 * p.out_grp)) return false;
+    if (p.QKVout) {  // the next layer's Q|K|V rows instead of its norm1 rows
+        if (p.Hout || p.lnB_g[0] || !p.lnA_g || !p.bqkv || ((uintptr_t)p.QKVout & 3) || p.ldq < 3 * BD) return false;
+        if (p.qkv_bytes == 0 || p.qkv_bytes >= 0x80000000u || (unsigned long long)p.M * p.ldq * 2 > p.qkv_bytes) return false;
+    }
     const dim3 grid((p.M + 127) / 128), block(256);
 #ifdef M3PC_LAB  // timing experiments (tools/block_bench.py): the lab build only
-    if (p.variant == 1) hipLaunchKernelGGL(block_fused_kernel<1>, grid, block, 0, st, p);
-    else if (p.variant == 2) hipLaunchKernelGGL(block_fused_kernel<2>, grid, block, 0, st, p);
-    else if (p.variant == 3) hipLaunchKernelGGL(block_fused_kernel<3>, grid, block, 0, st, p);
-    else if (p.variant == 4) hipLaunchKernelGGL(block_fused_kernel<4>, grid, block, 0, st, p);
-    else if (p.variant == 5) hipLaunchKernelGGL(block_fused_kernel<5>, grid, block, 0, st, p);
-    else if (p.variant == 6) hipLaunchKernelGGL(block_fused_kernel<6>, grid, block, 0, st, p);
-    else if (p.variant == 7) hipLaunchKernelGGL(block_fused_kernel<7>, grid, block, 0, st, p);
+    if (p.variant == 1) hipLaunchKernelGGL((block_fused_kernel<1, false>), grid, block, 0, st, p);
+    else if (p.variant == 2) hipLaunchKernelGGL((block_fused_kernel<2, false>), grid, block, 0, st, p);
+    else if (p.variant == 3) hipLaunchKernelGGL((block_fused_kernel<3, false>), grid, block, 0, st, p);
+    else if (p.variant == 4) hipLaunchKernelGGL((block_fused_kernel<4, false>), grid, block, 0, st, p);
+    else if (p.variant == 5) hipLaunchKernelGGL((block_fused_kernel<5, false>), grid, block, 0, st, p);
+    else if (p.variant == 6) hipLaunchKernelGGL((block_fused_kernel<6, false>), grid, block, 0, st, p);
+    else if (p.variant == 7) hipLaunchKernelGGL((block_fused_kernel<7, false>), grid, block, 0, st, p);
     else
 #endif
-        hipLaunchKernelGGL(block_fused_kernel<0>, grid, block, 0, st, p);
+    if (p.QKVout) hipLaunchKernelGGL((block_fused_kernel<0, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((block_fused_kernel<0, false>), grid, block, 0, st, p);
     return true;
 }
 

@@ -109,6 +109,10 @@ struct BlockP {
                             // Hout row is s * (M / out_mod) * out_grp + (r / out_mod) * out_grp + r % out_grp and LN_B[s] applies
     bf16_t* Hout;           // optional
     int ldh;
+    bf16_t* QKVout;         // optional, instead of Hout: (M, ldq) rows of LN_A(X'') Wqkv^T + bqkv -- the NEXT layer's in_proj; the
+    int ldq;                // stream then carries that layer's in_proj fragments behind the layer's own (launch_pack_block_qkv)
+    unsigned qkv_bytes;     // size of the QKVout buffer from its base (< 2 GiB: stores go through a buffer resource)
+    const float* bqkv;      // in_proj_bias of the next layer (3 d)
     int variant;            // 0 = product kernel; 1, 2: timing experiments (tools/block_bench.py)
     long long* stamps;      // optional (4 waves, 16) shader-clock phase stamps of workgroup stamp_block
     int stamp_block;
@@ -116,6 +120,7 @@ struct BlockP {
 bool block_fused_supported(int d, int ff);
 size_t block_stream_bytes();
 void launch_pack_block_stream(const bf16_t* Wo, const bf16_t* W1, const bf16_t* W2, bf16_t* out, hipStream_t st);
+void launch_pack_block_qkv(const bf16_t* Wqkv_next, bf16_t* out, hipStream_t st);  // behind them: the next layer's in_proj
 bool launch_block_fused(const BlockP& p, hipStream_t st);  // false: arguments not covered (caller takes the unfused path)
 
 // Decoder input of the un-masked tokens as one launch (block_fused.hip: kv_fused_kernel; d = 512, bf16 operands):

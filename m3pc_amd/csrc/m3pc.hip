@@ -524,9 +524,12 @@ void invalidate_tables(m3pc_handle* h) {
 // x_dead: nothing reads X after this block except through next_ln (lets the fused tail skip the fp32 store).
 // Xnext / res_nshared (fused tail only): the block output goes to Xnext instead of X, and the first res_nshared rows of
 // every sequence of X are read from sequence 0 (the embedding kernel stored the history rows once, EmbedP::x_first_only).
+// qkv_done: the previous layer's fused tail already wrote this layer's Q|K|V rows; next_qkv: prefix of the layer whose Q|K|V
+// projection this layer's fused tail may compute (-> *next_qkv_done)
 int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L, int dt, hipStream_t st, bool ln1_done = false,
               int n_sh = 0, const LnP* next_ln = nullptr, bool* next_ln_done = nullptr, bool x_dead = false,
-              float* Xnext = nullptr, int res_nshared = 0) {
+              float* Xnext = nullptr, int res_nshared = 0, bool qkv_done = false, const std::string* next_qkv = nullptr,
+              bool* next_qkv_done = nullptr) {
     const int d = h->d, ff = h->ff;
     const int rows = batch * L;
     const int es = (int)dtype_size(dt);
@@ -557,7 +560,7 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
             ln1_done = true;
         }
     }
-    if (!ln1_done) launch_layernorm(ln, st);  // the embedding kernel already wrote norm1(X) of the first layer
+    if (!ln1_done && !qkv_done) launch_layernorm(ln, st);  // the embedding kernel already wrote norm1(X) of the first layer
     if (n_sh > 0) {
         // First layer of a candidate pass: the first n_sh tokens are the same for every candidate (history), so
         // their norm1 rows and Q|K|V projections exist once (n_sh rows behind the compact per-candidate rows in
@@ -610,7 +613,7 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
         a.scale = 1.0f / sqrtf((float)h->hd);
         launch_attention(a, dt, st);
     } else {
-    gemm(h, pqkv, dt, st);
+    if (!qkv_done) gemm(h, pqkv, dt, st);
     {
         AttnP a;
         memset(&a, 0, sizeof(a));
@@ -656,21 +659,33 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
             b.res_L = L;
             b.res_nshared = res_nshared;
         }
-        if (fuse_ln) {
+        static const bool no_qkv_fused = M3PC_ENV("M3PC_NO_QKV_FUSED") != nullptr;  // A/B switch
+        const bool fuse_qkv = fuse_ln && next_qkv && !no_qkv_fused && next_ln->Yb == (bf16_t*)h->Hn &&
+                              (size_t)rows * 3 * d * 2 < 0x7fffffffull;
+        if (fuse_qkv) {  // norm1 of the next layer never leaves the kernel: its Q|K|V rows do
+            b.lnA_g = next_ln->g1;
+            b.lnA_b = next_ln->b1;
+            b.QKVout = (bf16_t*)h->QKV;
+            b.ldq = 3 * d;
+            b.qkv_bytes = (unsigned)((size_t)rows * 3 * d * 2);
+            b.bqkv = W(h, *next_qkv + ".self_attn.in_proj_bias").f;
+        } else if (fuse_ln) {
             b.lnA_g = next_ln->g1;
             b.lnA_b = next_ln->b1;
             b.Hout = next_ln->Yb;
             b.ldh = d;
         }
+        if (next_qkv_done) *next_qkv_done = fuse_qkv;
         if (!(fuse_ln && x_dead)) {
             b.Xout = Xnext ? Xnext : X;
             b.ldx = d;
         }
-        GemmTimer t(h, st, 2.0 * rows * ((double)d * d + 2.0 * d * ff), dt, 1);
+        GemmTimer t(h, st, 2.0 * rows * ((double)d * d + 2.0 * d * ff + (fuse_qkv ? 3.0 * d * d : 0.0)), dt, 1);
         if (launch_block_fused(b, st)) {
             if (next_ln_done) *next_ln_done = fuse_ln;
             return check_launch(pfx.c_str());
         }
+        if (next_qkv_done) *next_qkv_done = false;
     }
     if (Xnext || res_nshared) return fail(M3PC_EINVAL, "%s: the fused layer tail did not take a pass set up for it", pfx.c_str());
     {
@@ -730,9 +745,13 @@ struct TokIn {
 // embed + encoder stack + encoder.norm -> EncOut (fp32) [and bf16 copy in Z when dt == bf16 and want_b]
 // n_indep: number of leading encoder tokens that are identical for every batch element (candidate pass: history)
 // layer_from / layer_to / ln_state: the pass can be enqueued in pieces (the embedding goes with layer 0, encoder.norm with the
-// last layer); *ln_state carries "norm1 of the next layer is already in Hn" from one piece to the next
+// last layer); *ln_state carries "norm1 of the next layer is already in Hn" (ln) / "its Q|K|V rows are already in QKV" (qkv)
+// from one piece to the next
+struct PieceState {
+    bool ln = true, qkv = false;
+};
 int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hipStream_t st, bool bf16_out_only = false,
-                int n_indep = 0, int layer_from = 0, int layer_to = 1 << 30, bool* ln_state = nullptr) {
+                int n_indep = 0, int layer_from = 0, int layer_to = 1 << 30, PieceState* ln_state = nullptr) {
     // first-layer pruning (run_block): whole 32-query tiles of shared tokens, bf16 candidate passes only
     int n_sh = 0;
     static const bool no_prune1 = M3PC_ENV("M3PC_NO_PRUNE1") != nullptr;  // A/B switch
@@ -788,7 +807,8 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
         ln.Yb = (bf16_t*)h->Z;  // the candidate pass consumes the encoder output only as a bf16 GEMM operand
     else
         ln.Yf = h->EncOut;
-    bool ln_done = layer_from <= 0 || !ln_state ? true : *ln_state;  // norm1 of layer 0 comes from the embedding kernel
+    bool ln_done = layer_from <= 0 || !ln_state ? true : ln_state->ln;  // norm1 of layer 0 comes from the embedding kernel
+    bool qkv_done = layer_from <= 0 || !ln_state ? false : ln_state->qkv;
     const int nl = h->dm.n_enc_layer;
     float* Xs = shared_res && layer_from > 0 ? h->Y : h->X;  // where the residual stream lives
     for (int i = layer_from > 0 ? layer_from : 0; i < nl && i < layer_to; ++i) {
@@ -803,11 +823,17 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
         }
         const bool l1 = ln_done;
         ln_done = false;
+        const std::string nq = "encoder.layers." + std::to_string(i + 1);
+        const bool q1 = qkv_done;
+        qkv_done = false;
         CHK(run_block(h, "encoder.layers." + std::to_string(i), Xs, batch, pl->Le, dt, st, l1, i == 0 ? n_sh : 0, &nxt, &ln_done,
-                      i + 1 == nl && bf16_out_only, Xn, Xn ? n_indep : 0));
+                      i + 1 == nl && bf16_out_only, Xn, Xn ? n_indep : 0, q1, i + 1 < nl ? &nq : nullptr, &qkv_done));
         if (Xn) Xs = Xn;
     }
-    if (ln_state) *ln_state = ln_done;
+    if (ln_state) {
+        ln_state->ln = ln_done;
+        ln_state->qkv = qkv_done;
+    }
     if (layer_to < nl) return check_launch("encoder");
     ln.X = Xs;
     if (!ln_done) launch_layernorm(ln, st);
@@ -1113,7 +1139,7 @@ int build_tables(m3pc_handle* h, Plan* pl, int qi, int dt, hipStream_t st) {
 // can be enqueued alternately (m3pc_plan_step)
 int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* rewards, int n,
                    const float* sample_actions, float* expect_return, float* pred_rewards, float* pred_boot, int dt,
-                   hipStream_t st, const int* widx = nullptr, int stage_from = 0, int stage_to = 1 << 30, bool* ln_state = nullptr) {
+                   hipStream_t st, const int* widx = nullptr, int stage_from = 0, int stage_to = 1 << 30, PieceState* ln_state = nullptr) {
     const int T = h->T, d = h->d, hh = a->horizon, idx = T - hh;
     const size_t es = dtype_size(dt);
     Plan* pl = nullptr;
@@ -1649,18 +1675,23 @@ int m3pc_load_weights(m3pc_handle* h, const m3pc_named_tensor* tensors, int n, v
     ls[0] = (long long)dirty.size();
     ls[1] = ls[2] = ls[3] = 0;
     if (block_fused_supported(h->d, h->ff)) {  // fragment streams of the fused layer tails (block_fused.hip)
-        auto pack = [&](const std::string& pfx) -> int {
-            if (!(is_dirty(pfx + ".self_attn.out_proj.weight") || is_dirty(pfx + ".linear1.weight") || is_dirty(pfx + ".linear2.weight")))
-                return 0;
+        // nxt: the layer whose Q|K|V projection rides behind this layer's tail (the next encoder layer), or ""
+        auto pack = [&](const std::string& pfx, const std::string& nxt) -> int {
+            const bool own = is_dirty(pfx + ".self_attn.out_proj.weight") || is_dirty(pfx + ".linear1.weight") || is_dirty(pfx + ".linear2.weight");
+            const bool qkv = !nxt.empty() && is_dirty(nxt + ".self_attn.in_proj_weight");
+            if (!own && !qkv) return 0;
             bf16_t*& ws = h->wstream[pfx];
             if (!ws) CHK(dmalloc((char**)&ws, block_stream_bytes()));
-            launch_pack_block_stream(W(h, pfx + ".self_attn.out_proj.weight").b, W(h, pfx + ".linear1.weight").b,
-                                     W(h, pfx + ".linear2.weight").b, ws, st);
+            if (own)
+                launch_pack_block_stream(W(h, pfx + ".self_attn.out_proj.weight").b, W(h, pfx + ".linear1.weight").b,
+                                         W(h, pfx + ".linear2.weight").b, ws, st);
+            if (qkv) launch_pack_block_qkv(W(h, nxt + ".self_attn.in_proj_weight").b, ws, st);
             ++ls[1];
             return 0;
         };
-        for (int i = 0; i < h->dm.n_enc_layer; ++i) CHK(pack("encoder.layers." + std::to_string(i)));
-        for (int i = 0; i < h->dm.n_dec_layer; ++i) CHK(pack("decoder.layers." + std::to_string(i)));
+        for (int i = 0; i < h->dm.n_enc_layer; ++i)
+            CHK(pack("encoder.layers." + std::to_string(i), i + 1 < h->dm.n_enc_layer ? "encoder.layers." + std::to_string(i + 1) : ""));
+        for (int i = 0; i < h->dm.n_dec_layer; ++i) CHK(pack("decoder.layers." + std::to_string(i), ""));
         if (h->dm.n_dec_layer >= 1)
             for (int k = 0; k < 4; ++k) {
                 const std::string we = std::string("decoder_embed_dict.") + KEYN[k] + ".weight";
@@ -1944,7 +1975,7 @@ int m3pc_candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* st
         // launches are all enqueued behind the other part's starts that much later on the device -- and ends that much later,
         // with the other stream idle.  (With the profiling brackets in serial mode: one part after the other.)
         const int n_stage = h->dm.n_enc_layer + 1;
-        bool lnst[4] = {true, true, true, true};
+        PieceState lnst[4];
         for (int stg = 0; stg < (h->prof_serial ? 1 : n_stage) && rc == 0; ++stg) {
             int c0 = 0;
             for (size_t i = 0; i < parts.size() && rc == 0; ++i) {
@@ -2328,6 +2359,40 @@ int m3pc_debug_block_fused(const void* O, int M, const float* res, const float* 
     b.stamps = stamps;
     if (!launch_block_fused(b, st)) return fail(M3PC_EINVAL, "block_fused: arguments not covered");
     return check_launch("debug_block_fused");
+}
+
+// the fused layer tail with the next layer's Q|K|V projection behind it: QKV (M, 1536) bf16 = LN_A(X'') Wqkv^T + bqkv
+int m3pc_debug_block_fused_qkv(const void* O, int M, const float* res, const void* Wo, const void* W1, const void* W2, const void* Wqkv,
+                               void* stream_buf, const float* bo, const float* b1, const float* b2, const float* ln2_g,
+                               const float* ln2_b, const float* lnA_g, const float* lnA_b, const float* bqkv, float* Xout, void* QKV,
+                               void* stream, long long* stamps) {
+    hipStream_t st = (hipStream_t)stream;
+    launch_pack_block_stream((const bf16_t*)Wo, (const bf16_t*)W1, (const bf16_t*)W2, (bf16_t*)stream_buf, st);
+    launch_pack_block_qkv((const bf16_t*)Wqkv, (bf16_t*)stream_buf, st);
+    BlockP b;
+    memset(&b, 0, sizeof(b));
+    b.O = (const bf16_t*)O;
+    b.ldo = 512;
+    b.M = M;
+    b.res = res;
+    b.ldr = 512;
+    b.wstream = (const bf16_t*)stream_buf;
+    b.bo = bo;
+    b.b1 = b1;
+    b.b2 = b2;
+    b.ln2_g = ln2_g;
+    b.ln2_b = ln2_b;
+    b.Xout = Xout;
+    b.ldx = 512;
+    b.lnA_g = lnA_g;
+    b.lnA_b = lnA_b;
+    b.QKVout = (bf16_t*)QKV;
+    b.ldq = 1536;
+    b.qkv_bytes = (unsigned)((size_t)M * 1536 * 2);
+    b.bqkv = bqkv;
+    b.stamps = stamps;
+    if (!launch_block_fused(b, st)) return fail(M3PC_EINVAL, "block_fused (qkv): arguments not covered");
+    return check_launch("debug_block_fused_qkv");
 }
 
 // kv_fused_kernel alone (tests/test_block_fused_gpu.py): n candidates of Le rows each in Z (n*Le, 512) bf16; group g holds

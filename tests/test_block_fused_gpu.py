@@ -118,6 +118,60 @@ def test_block_fused_rowtab_and_head_norms():
     assert float((got - y).abs().max()) <= 4e-2
 
 
+@pytest.mark.parametrize("M", [128, 3 * 1024 + 77, 25088])
+def test_block_fused_with_next_qkv(M):
+    """encoder form with the next layer's Q|K|V projection behind the tail: QKV = bf16(LN_A(X'')) Wqkv^T + bqkv; X'' as without"""
+    lib = lab_library()
+    dev = torch.device("cuda")
+    W, p, _, g = make_params(1000 + M)
+    Wqkv = (torch.randn(3 * D, D, device=dev, generator=g) / D ** 0.5).to(torch.bfloat16)
+    bqkv = 0.1 * torch.randn(3 * D, device=dev, generator=g)
+    O = torch.randn(M, D, device=dev, generator=g).to(torch.bfloat16)
+    R = torch.randn(M, D, device=dev, generator=g)
+    nbytes = lib.m3pc_debug_block_stream_bytes
+    nbytes.restype = C.c_longlong
+    sb = torch.empty(int(nbytes()), dtype=torch.uint8, device=dev)
+    fn = lib.m3pc_debug_block_fused_qkv
+    fn.restype = C.c_int
+    vp = C.c_void_p
+    fn.argtypes = [vp, C.c_int] + [vp] * 18
+
+    def call(O_, R_, Xout, QKV):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = fn(O_.data_ptr(), O_.shape[0], R_.data_ptr(), W["o"].data_ptr(), W["1"].data_ptr(), W["2"].data_ptr(), Wqkv.data_ptr(),
+                sb.data_ptr(), p["bo"].data_ptr(), p["b1"].data_ptr(), p["b2"].data_ptr(), p["g2"].data_ptr(), p["be2"].data_ptr(),
+                p["gA"].data_ptr(), p["bA"].data_ptr(), bqkv.data_ptr(), Xout.data_ptr(), QKV.data_ptr(), st, None)
+        assert rc == 0, lib.m3pc_last_error()
+        torch.cuda.synchronize()
+
+    Xout = torch.full((M, D), float("nan"), device=dev)
+    QKV = torch.full((M + 1, 3 * D), float("nan"), device=dev, dtype=torch.bfloat16)  # (one guard row behind the end)
+    call(O, R, Xout, QKV)
+    assert torch.isnan(QKV[M].float()).all(), "rows past M written"
+    QKV = QKV[:M]
+    rows = torch.arange(M, device=dev) if M <= 8192 else torch.cat([torch.arange(2048), torch.arange(M - 2048, M),
+                                                                     torch.randint(0, M, (4096,))]).to(dev)
+    x2, y = reference(O[rows], R[rows], W, p)
+    assert torch.isfinite(Xout).all() and torch.isfinite(QKV.float()).all()
+    assert float((Xout[rows] - x2).abs().max()) / float(x2.abs().max()) <= 2e-3
+    # from the kernel's own X'' (so that only the projection is compared): LN_A -> bf16 -> Wqkv
+    yk = F.layer_norm(Xout[rows], (D,), p["gA"], p["bA"], 1e-5).to(torch.bfloat16).float()
+    want = yk @ Wqkv.float().T + bqkv
+    err = float((QKV[rows].float() - want).abs().max())
+    assert err <= 6e-2, err  # bf16 output (|q| <~ 6) + LN values on a bf16 rounding boundary
+    # the tail without the projection gives the same X'' bits, and a shard of the rows the same Q|K|V bits
+    X1 = torch.empty_like(Xout)
+    H1 = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+    _call(lib, O, R, None, 1, W, sb, 0, p, [None] * 4, 0, 0, X1, H1)
+    assert torch.equal(X1, Xout)
+    if M >= 3000:
+        lo, n = 640, 1000
+        X3 = torch.empty(n, D, device=dev)
+        Q3 = torch.empty(n, 3 * D, device=dev, dtype=torch.bfloat16)
+        call(O[lo:lo + n].contiguous(), R[lo:lo + n].contiguous(), X3, Q3)
+        assert torch.equal(X3, Xout[lo:lo + n]) and torch.equal(Q3, QKV[lo:lo + n])
+
+
 # ------------------------------------------------------------------------------------------------ decoder input (kv_fused_kernel)
 def _kv_call(lib, Z, n, Le, kept, off, We, Wkv, rowtab, g, b, bkv, stamps=None):
     fn = lib.m3pc_debug_kv_fused
