@@ -167,6 +167,21 @@ int m3pc_forward(m3pc_handle* h, int batch, const float* const tokens[4], const 
                  float* out_states, float* out_rewards, float* out_returns, float* out_mu, float* out_std,
                  int precision, void* stream);
 
+/* Zero-shot goal reaching: both forwards of action_piid_sample (zeroshot_omtm/learner.py:151-261) in one call, on RAW
+ * (un-normalised) windows -- the tokenizer is applied inside, as in m3pc_plan_step:
+ *   path inference under the pi mask (zeroshot_omtm/masks.py:72-91) -> the de-tokenised predicted observations over the
+ *   window rows [0, idx] and [idx+2, T-2] (learner.py:240-246) -> inverse dynamics under the fid mask (masks.py:30-47).
+ *   batch      E independent windows (<= max_batch); states (E,T,S), actions (E,T,A), rewards (E,T,1) device
+ *   rtg        host (E,) return-to-go per window, written into every returns slot (learner.py:205-223)
+ *   masks_*    host (T,) 0/1 bytes per modality, as m3pc_forward;  idx = T - h
+ *   inferred       device out (E,T,S): the de-tokenised states head of the first forward
+ *   window_states  device out (E,T,S): the observation rows the second forward saw
+ *   out_mu/out_std device out (E,T,A): DiagGaussianActor loc / std of the second forward (mtm_model.py:313-321)
+ * fp32; runs in the policy workspace and uses step slot 0. */
+int m3pc_goal_step(m3pc_handle* h, int batch, const float* states, const float* actions, const float* rewards,
+                   const double* rtg, const unsigned char* const masks_pi[4], const unsigned char* const masks_fid[4],
+                   int idx, float* inferred, float* window_states, float* out_mu, float* out_std, void* stream);
+
 /* The two halves of m3pc_plan_step as calls of their own, for pipelined callers:
  *   m3pc_policy_pass     learner.py:278-284: returns tokens + return-conditioned policy (batch 1, rcbc
  *                        mask, fp32) -> loc / std of the slot (and the caller's copies, optional).  Policy

@@ -26,7 +26,7 @@ SLOTS = 4  # M3PC_SLOTS: plan steps in flight per handle
 
 EXPORTS = (
     "m3pc_last_error", "m3pc_abi_version", "m3pc_create", "m3pc_destroy", "m3pc_load_weights", "m3pc_load_stats",
-    "m3pc_set_tokenizer", "m3pc_set_critic", "m3pc_tokenize", "m3pc_detokenize", "m3pc_forward",
+    "m3pc_set_tokenizer", "m3pc_set_critic", "m3pc_tokenize", "m3pc_detokenize", "m3pc_forward", "m3pc_goal_step",
     "m3pc_policy_pass", "m3pc_candidate_pass", "m3pc_candidate_join",
     "m3pc_plan_step", "m3pc_plan_step_batch", "m3pc_score_actions", "m3pc_rescore", "m3pc_rescore_topk", "m3pc_topk_window",
     "m3pc_rescore_listed", "m3pc_rescore_merge", "m3pc_select",
@@ -86,6 +86,7 @@ def load_library(path: Optional[str] = None):
         "m3pc_tokenize": [vp, i, vp, i, vp, ll, vp],
         "m3pc_detokenize": [vp, i, vp, vp, ll, vp],
         "m3pc_forward": [vp, i, C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp, vp, i, vp],
+        "m3pc_goal_step": [vp, i, vp, vp, vp, C.POINTER(d), C.POINTER(vp), C.POINTER(vp), i, vp, vp, vp, vp, vp],
         "m3pc_policy_pass": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, vp],
         "m3pc_candidate_pass": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_candidate_join": [vp, i, vp],
@@ -271,6 +272,30 @@ class Handle:
         check(self.lib.m3pc_forward(self._h, B, tp, mp, _ptr(out.get("states")), _ptr(out.get("rewards")),
                                     _ptr(out.get("returns")), _ptr(mu), _ptr(sd), precision, _stream(dev)))
         return out
+
+    @staticmethod
+    def _mask_ptrs(masks):
+        mb = [bytes(bytearray(int(v != 0) for v in m)) for m in masks]
+        mbuf = [C.create_string_buffer(b, len(b)) for b in mb]
+        return (C.c_void_p * 4)(*[C.addressof(b) for b in mbuf]), mbuf
+
+    def goal_step(self, states, actions, rewards, rtg, masks_pi, masks_fid, idx: int):
+        """Both forwards of the zero-shot piid call on raw windows: states (E,T,S), actions (E,T,A), rewards (E,T,1) fp32 cuda,
+        rtg (E,) floats.  Returns (mu, std) (E,T,A) of the inverse-dynamics forward, the de-tokenised inferred states (E,T,S) and
+        the observation rows the second forward saw (E,T,S)."""
+        E = states.shape[0]
+        f32 = dict(dtype=torch.float32, device=self.device)
+        ins = [self._f32(t) for t in (states, actions, rewards)]
+        inferred = torch.empty((E, self.T, self.S), **f32)
+        window = torch.empty((E, self.T, self.S), **f32)
+        mu = torch.empty((E, self.T, self.A), **f32)
+        sd = torch.empty_like(mu)
+        rt = (C.c_double * E)(*[float(v) for v in rtg])
+        pi, keep1 = self._mask_ptrs(masks_pi)
+        fid, keep2 = self._mask_ptrs(masks_fid)
+        check(self.lib.m3pc_goal_step(self._h, E, _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), rt, pi, fid, int(idx), _ptr(inferred),
+                                      _ptr(window), _ptr(mu), _ptr(sd), _stream(self.device)))
+        return mu, sd, inferred, window
 
     # -- plan step ---------------------------------------------------------------------------------
     @staticmethod

@@ -743,6 +743,25 @@ void launch_detokenize(const float* in, float* out, long long rows, int D, const
     hipLaunchKernelGGL(detokenize_kernel, dim3(grid_for(n)), dim3(256), 0, st, in, out, n, D, mean, stdv, normalize);
 }
 
+// zero-shot path inference -> inverse dynamics hand-over (zeroshot_omtm/learner.py:240-246): the states head's raw output is
+// de-tokenised in place (`pred`, (B,T,S)) and written over the window's observation rows [0, idx] and [idx+2, T-2]
+__global__ __launch_bounds__(256) void goal_overlay_kernel(float* pred, const float* states_in, float* states_out, long long n, int T,
+                                                           int D, int idx, const float* mean, const float* stdv, int normalize) {
+    for (long long x = blockIdx.x * (long long)blockDim.x + threadIdx.x; x < n; x += (long long)gridDim.x * blockDim.x) {
+        const int f = (int)(x % D), t = (int)((x / D) % T);
+        float v = pred[x];
+        if (normalize) v = __fadd_rn(__fmul_rn(v, stdv[f]), mean[f]);
+        pred[x] = v;
+        states_out[x] = (t <= idx || (t >= idx + 2 && t < T - 1)) ? v : states_in[x];
+    }
+}
+void launch_goal_overlay(float* pred, const float* states_in, float* states_out, long long rows, int T, int D, int idx,
+                         const float* mean, const float* stdv, int normalize, hipStream_t st) {
+    const long long n = rows * D;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(goal_overlay_kernel, dim3(grid_for(n)), dim3(256), 0, st, pred, states_in, states_out, n, T, D, idx, mean, stdv, normalize);
+}
+
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* in, bf16_t* out, long long n) {
     for (long long x = blockIdx.x * (long long)blockDim.x + threadIdx.x; x < n; x += (long long)gridDim.x * blockDim.x)
         out[x] = (bf16_t)in[x];

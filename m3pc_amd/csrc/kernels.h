@@ -356,6 +356,8 @@ void launch_tokenize(const void* in, int in_f64, float* out, long long rows, int
                      const float* stdv, int normalize, hipStream_t st);
 void launch_detokenize(const float* in, float* out, long long rows, int D, const float* mean, const float* stdv,
                        int normalize, hipStream_t st);
+void launch_goal_overlay(float* pred, const float* states_in, float* states_out, long long rows, int T, int D, int idx,
+                         const float* mean, const float* stdv, int normalize, hipStream_t st);
 void launch_f32_to_bf16(const float* in, bf16_t* out, long long n, hipStream_t st);
 void launch_fill(float* out, float value, long long n, hipStream_t st);
 void launch_transpose_f32(const float* in, float* out, int rows, int cols, hipStream_t st);  // out (cols, rows) = in (rows, cols)^T

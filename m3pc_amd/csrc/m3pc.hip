@@ -161,6 +161,7 @@ struct m3pc_handle {
     Base* cur = nullptr;
     bool two_stream = true;       // candidate halves on two streams (M3PC_TWO_STREAM=0: one stream); measured -2.5 % step time on C2
     bool allow_splitk = true;     // see gemm(): off while sharded candidates are scored
+    double pass_scale = 1.0;      // candidates of the whole plan step / candidates of the launch being enqueued (>= 1; FUSED_MIN_ROWS)
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     const int* score_scatter_index = nullptr;  // set around a pass whose scores also go to scatter_out[index[i]] (score_kernel)
@@ -524,6 +525,13 @@ void invalidate_tables(m3pc_handle* h) {
 // x_dead: nothing reads X after this block except through next_ln (lets the fused tail skip the fp32 store).
 // Xnext / res_nshared (fused tail only): the block output goes to Xnext instead of X, and the first res_nshared rows of
 // every sequence of X are read from sequence 0 (the embedding kernel stored the history rows once, EmbedP::x_first_only).
+// The fused layer tail (block_fused.hip) works in 128-row tiles, one per CU, and a tile takes its ~130-170 us whatever the row
+// count: below ~96 tiles most of the chip idles for that long and the GEMM chain, whose tiles spread over all CUs, is faster
+// (the reference's shipped N=625 / T=8 config, 64 + 40 tiles: 1.13 -> 1.00 ms per closed-loop call).
+// The choice goes by the size of the WHOLE step (m3pc_handle::pass_scale = n_total / candidates of this launch), not by the
+// rows of a shard or a candidate part: a candidate's score must not depend on how the candidates were cut.
+constexpr long long FUSED_MIN_ROWS = 96 * 128;
+
 // qkv_done: the previous layer's fused tail already wrote this layer's Q|K|V rows; next_qkv: prefix of the layer whose Q|K|V
 // projection this layer's fused tail may compute (-> *next_qkv_done)
 int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L, int dt, hipStream_t st, bool ln1_done = false,
@@ -639,7 +647,7 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
     }
     // many-row bf16 passes: everything after the attention is one launch (block_fused.hip)
     static const bool no_fused = M3PC_ENV("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
-    if (dt == DT_BF16 && !no_fused && rows >= 512 && h->wstream.count(pfx)) {
+    if (dt == DT_BF16 && !no_fused && (double)rows * h->pass_scale >= (double)FUSED_MIN_ROWS && h->wstream.count(pfx)) {
         BlockP b;
         memset(&b, 0, sizeof(b));
         b.O = (const bf16_t*)h->O;
@@ -1142,6 +1150,11 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
                    hipStream_t st, const int* widx = nullptr, int stage_from = 0, int stage_to = 1 << 30, PieceState* ln_state = nullptr) {
     const int T = h->T, d = h->d, hh = a->horizon, idx = T - hh;
     const size_t es = dtype_size(dt);
+    struct ScaleScope {
+        m3pc_handle* h;
+        ~ScaleScope() { h->pass_scale = 1.0; }
+    } scale_scope{h};
+    h->pass_scale = !widx && a->n_total > n ? (double)a->n_total / (double)n : 1.0;
     Plan* pl = nullptr;
     CHK(get_mask_plan(h, 1, idx, &pl));  // fd mask (finetune_omtm/masks.py:30-44)
     const int qi = a->mode == M3PC_MODE_RTG ? 0 : 1;
@@ -1187,7 +1200,7 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         ln.Yf = (float*)h->Hn;
     bool kv_done = false;
     static const bool no_kv_fused = M3PC_ENV("M3PC_NO_KV_FUSED") != nullptr || M3PC_ENV("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
-    if (dt == DT_BF16 && !no_kv_fused && q.all_masked && (long long)n * Le >= 512 && h->kvstream[0] && (pl->kept[0] || pl->kept[1])) {
+    if (dt == DT_BF16 && !no_kv_fused && q.all_masked && (double)n * Le * h->pass_scale >= 512.0 && h->kvstream[0] && (pl->kept[0] || pl->kept[1])) {
         // embedding, norm1 and the K|V projection in one launch (kv_fused_kernel): the fp32 rows Y are consumed by nothing
         // else when every scored token is masked
         KvFusedP kp;
@@ -1307,7 +1320,7 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     float* Y1 = h->EncOut;  // (n*nq, d) decoder residual of the scored tokens (EncOut is dead: Z/Y hold its uses)
     static const bool no_fused = M3PC_ENV("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
     bool tail_done = false;
-    if (dt == DT_BF16 && !no_fused && (long long)n * nq >= 512 && h->wstream.count(pfx)) {
+    if (dt == DT_BF16 && !no_fused && (double)n * nq * h->pass_scale >= (double)FUSED_MIN_ROWS && h->wstream.count(pfx)) {
         // out-proj, norm2, FFN, decoder.norm and the two heads' LayerNorms in one launch (block_fused.hip): the rows of
         // head s land in the s-th block of n*h rows of Hn
         BlockP b;
@@ -1460,6 +1473,8 @@ int find_tensor(const m3pc_named_tensor* list, int n, const std::string& name) {
 }  // namespace
 
 // =====================================================================================================
+static int fill_rtok(m3pc_handle* h, const double* rtg, int n_windows, hipStream_t st);
+
 extern "C" {
 
 const char* m3pc_last_error(void) { return g_err; }
@@ -1836,6 +1851,46 @@ int m3pc_forward(m3pc_handle* h, int batch, const float* const tokens[4], const 
     CHK(ws_sync(h, (hipStream_t)stream));
     return forward_impl(h, pl, in, batch, out_states, out_rewards, out_returns, out_mu, out_std,
                         precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32, (hipStream_t)stream);
+}
+
+// Zero-shot goal reaching, both forwards of action_piid_sample (zeroshot_omtm/learner.py:151-261) in one call on RAW windows:
+// path inference under the pi mask -> the inferred observations over the window rows [0, idx] and [idx+2, T-2] (240-246) ->
+// inverse dynamics under the fid mask -> the action distribution.  fp32, in the policy workspace.
+int m3pc_goal_step(m3pc_handle* h, int batch, const float* states, const float* actions, const float* rewards, const double* rtg,
+                   const unsigned char* const masks_pi[4], const unsigned char* const masks_fid[4], int idx, float* inferred,
+                   float* window_states, float* out_mu, float* out_std, void* stream) {
+    if (!h || !states || !actions || !rewards || !rtg || !masks_pi || !masks_fid || !inferred || !window_states || !out_mu || !out_std)
+        return fail(M3PC_EINVAL, "null argument");
+    if (!h->weights_loaded) return fail(M3PC_ESTATE, "weights not loaded");
+    for (int k = 0; k < 4; ++k)
+        if (!h->tok_set[k]) return fail(M3PC_ESTATE, "tokenizer '%s' not set", KEYN[k]);
+    if (batch < 1 || batch > h->dm.max_batch) return fail(M3PC_EINVAL, "batch %d outside [1, max_batch=%d]", batch, h->dm.max_batch);
+    const int T = h->T;
+    if (idx < 0 || idx >= T) return fail(M3PC_EINVAL, "idx %d outside [0, T=%d)", idx, T);
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->device));
+    Plan *pi = nullptr, *fid = nullptr;
+    CHK(get_plan(h, masks_pi, &pi));
+    CHK(get_plan(h, masks_fid, &fid));
+    bind_slot(h, 0);
+    h->slot[0].policy_valid = false;
+    CHK(fill_rtok(h, rtg, batch, st));
+    TokIn in;
+    memset(&in, 0, sizeof(in));
+    const float* src[4] = {states, actions, rewards, h->rtok};
+    for (int k = 0; k < 4; ++k) {
+        in.ptr[k] = src[k];
+        in.bstride[k] = (long long)T * h->feat[k];
+        in.normalize[k] = k == M3PC_RETURNS ? 0 : h->tok_norm[k];
+    }
+    h->allow_splitk = true;
+    WsScope ws(h, true, true);
+    CHK(forward_impl(h, pi, in, batch, inferred, nullptr, nullptr, nullptr, nullptr, DT_F32, st));
+    launch_goal_overlay(inferred, states, window_states, (long long)batch * T, T, h->S, idx, h->tok_mean[M3PC_STATES],
+                        h->tok_std[M3PC_STATES], h->tok_norm[M3PC_STATES], st);
+    in.ptr[M3PC_STATES] = window_states;
+    CHK(forward_impl(h, fid, in, batch, nullptr, nullptr, nullptr, out_mu, out_std, DT_F32, st));
+    return check_launch("goal_step");
 }
 
 // common argument checks of the plan-step entry points; binds the step's slot

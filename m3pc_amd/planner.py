@@ -195,6 +195,7 @@ class HipPlanner:
         self.action_list = []       # zero-shot "piid_allout" (action_piid_list_sample)
         self._force_collective = False  # test hook: run the all-gather even in a world of one
         self._bf16_offset = 0.0     # test hook: a constant added to the bf16 scores before the re-score
+        self._predrawn = None       # (mode, h, eps, expo) drawn by action_sample ahead of the window copy
 
     # ---------------------------------------------------------------------------------------- weights
     def load_state_dict(self, state_dict):
@@ -277,6 +278,16 @@ class HipPlanner:
     def _eps(self, shape):
         return torch.randn(shape, device=self.device, dtype=torch.float32, generator=self.generator)
 
+    def _draw_eps(self, mode, h):
+        """The candidate variates, in the shapes the reference draws: dist.sample((N,)) over loc (1,T,1,A) (learner.py:285) /
+        randn((N,h,A)) for the fixed-variance variant (learner.py:157-163); identical on every rank."""
+        N, T, A = int(self.cfg.action_samples), self.T, self.A
+        return self._eps((N, h, A)) if mode == capi.MODE_NOISE else self._eps((N, 1, T, 1, A))
+
+    def _draw_expo(self):
+        """The multinomial's exponentials (ATen's own algorithm: argmax(p / q), q ~ Exp(1))."""
+        return torch.empty((int(self.cfg.action_samples),), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
+
     def _chain_stream(self):
         if self._chain is None:
             self._chain = torch.cuda.Stream(device=self.device, priority=self._chain_priority)
@@ -338,12 +349,14 @@ class HipPlanner:
             # the variates of the step in the serial order of draws: eps, then the multinomial's exponentials.  (Pipelined:
             # drawn on the chain stream -- the generator's state advances on the host in issue order either way -- so that
             # nothing but the candidate pass sits on the current stream.)
+            expo = None
+            if eps is None and self._predrawn is not None and self._predrawn[:2] == (mode, h):
+                eps, expo = self._predrawn[2:]  # action_sample drew them before the window's H2D copy (same order of draws)
+            self._predrawn = None
             if eps is None:
-                # same shapes the reference draws: dist.sample((N,)) over loc (1,T,1,A) (learner.py:285) /
-                # randn((N,h,A)) for the fixed-variance variant (learner.py:157-163); identical on every rank
-                eps = self._eps((N, h, A)) if mode == capi.MODE_NOISE else self._eps((N, 1, T, 1, A))
+                eps = self._draw_eps(mode, h)
             tk.eps = eps = eps.reshape(N, -1, A)
-            tk.expo = torch.empty((N,), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
+            tk.expo = self._draw_expo() if expo is None else expo
             hd.policy_pass(mode, states, actions, rewards, h, tk.rtg, slot=sl.i, returns=returns)
             if chain is not None:
                 sl.ev_pol.record(chain)
@@ -677,15 +690,15 @@ class HipPlanner:
         T = self.T
         s, a, r, h, rtg_v = self.assemble_goal_window(sequence_history, rtg, percentage)
         idx = T - h
-        toks = self._goal_tokens(s, a, r, rtg_v)
-        raw = self.handle.forward(toks, mask_rows(create_pi_mask(T, "cpu", idx)), want=("states",))["states"]
-        inferred = self.handle.detokenize(capi.STATES, raw)  # (1,T,S)
-        s = s.clone()
-        s[idx + 2 : T - 1] = inferred[0, idx + 2 : T - 1]
-        s[: idx + 1] = inferred[0, : idx + 1]
-        toks[0] = self.handle.tokenize(capi.STATES, s[None])
-        self.last = dict(state_inference=inferred, window_states=s)
-        return self._policy_from(toks, create_fid_mask(T, "cpu", idx), h, eval)
+        self._drain()  # (m3pc_goal_step runs in the policy workspace: no pipelined plan step may still be using it)
+        # both forwards and the hand-over between them in one library call on the raw window (m3pc_goal_step)
+        mu, sd, inferred, window = self.handle.goal_step(s[None], a[None], r[None], [rtg_v], mask_rows(create_pi_mask(T, "cpu", idx)),
+                                                         mask_rows(create_fid_mask(T, "cpu", idx)), idx)
+        self.last = dict(state_inference=inferred, window_states=window[0])
+        dist_ = SquashedNormal(mu.unsqueeze(2), sd.unsqueeze(2))
+        if eval:
+            return dist_.mean[0, idx]
+        return dist_.sample(eps=self._eps(tuple(dist_.loc.shape)))[0, idx]
 
     @torch.no_grad()
     def action_piid_list_sample(self, sequence_history, percentage=1.0, horizon=4, plan=True, eval=False, rtg=None):
@@ -715,6 +728,7 @@ class HipPlanner:
         dev = torch.from_numpy(host).to(self.device)  # one packed H2D copy for all windows
         out = torch.empty((E, self.A), dtype=torch.float32, device=self.device)
         infer = [None] * E
+        self._drain()
         for h in sorted({m[0] for m in meta}):
             ids = [i for i, m in enumerate(meta) if m[0] == h]
             idx = T - h
@@ -722,16 +736,8 @@ class HipPlanner:
             s = sel[:, : T * S].reshape(-1, T, S).contiguous()
             a = sel[:, T * S : T * (S + A)].reshape(-1, T, A).contiguous()
             r = sel[:, T * (S + A) :].reshape(-1, T, 1).contiguous()
-            ret = torch.tensor([meta[i][1] for i in ids], dtype=torch.float64, device=self.device)[:, None, None].expand(-1, T, 1)
-            toks = [self.handle.tokenize(capi.STATES, s), a, self.handle.tokenize(capi.REWARDS, r),
-                    self.handle.tokenize(capi.RETURNS, ret.contiguous())]
-            raw = self.handle.forward(toks, mask_rows(create_pi_mask(T, "cpu", idx)), want=("states",))["states"]
-            inferred = self.handle.detokenize(capi.STATES, raw)  # (B,T,S)
-            s = s.clone()
-            s[:, idx + 2 : T - 1] = inferred[:, idx + 2 : T - 1]
-            s[:, : idx + 1] = inferred[:, : idx + 1]
-            toks[0] = self.handle.tokenize(capi.STATES, s)
-            mu, sd = self.handle.forward(toks, mask_rows(create_fid_mask(T, "cpu", idx)), want=("actions",))["actions"]
+            mu, sd, inferred, _ = self.handle.goal_step(s, a, r, [meta[i][1] for i in ids], mask_rows(create_pi_mask(T, "cpu", idx)),
+                                                        mask_rows(create_fid_mask(T, "cpu", idx)), idx)
             dist_ = SquashedNormal(mu.unsqueeze(2), sd.unsqueeze(2))
             act = dist_.mean if eval else dist_.sample(eps=self._eps(tuple(dist_.loc.shape)))
             out[torch.tensor(ids, device=self.device)] = act[:, idx, 0]
@@ -919,11 +925,18 @@ class HipPlanner:
         """learner.py:329-417 (the ``horizon`` argument is ignored there too: cfg.horizon rules)."""
         if eval:
             assert rtg is not None
-        states, actions, rewards, h, return_to_go = self.assemble_window(sequence_history, rtg, percentage)
-        traj = {"states": states[None], "actions": actions[None], "rewards": rewards[None], "_rtg": return_to_go}
+        self._predrawn = None
         if plan:
             guidance = self.cfg.plan_guidance
             assert guidance in _MODES, guidance
+            # the step's variates do not depend on the window: their kernels are enqueued first and run while the host copies
+            # the window (same draws in the same order as without this: eps, then the multinomial's exponentials)
+            h, _ = self._window_host(sequence_history, rtg, percentage, self._host)
+            self._drain()
+            self._predrawn = (_MODES[guidance], h, self._draw_eps(_MODES[guidance], h), self._draw_expo())
+        states, actions, rewards, h, return_to_go = self.assemble_window(sequence_history, rtg, percentage)
+        traj = {"states": states[None], "actions": actions[None], "rewards": rewards[None], "_rtg": return_to_go}
+        if plan:
             if guidance == "rtg_guiding":
                 sample_action, eval_action = self.rtg_guiding(traj, h)  # default lmbda=0.6, learner.py:405-407
             else:

@@ -9,6 +9,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 from m3pc_amd import capi  # noqa: E402
 from tests.test_block_fused_gpu import D, FF, _call, make_params  # noqa: E402
 
