@@ -574,7 +574,7 @@ def extras(args, dims, cfg, hist, planner, S, A):
                 hi = synth.make_history(dims, i)
                 hi["path_length"] = 500
                 hs.append(hi)
-            for _ in range(3):
+            for _ in range(8):  # (the certificate's bound settles within the first calls: every raise repeats a merge + select)
                 pb.action_sample_batch(hs, eval=True, rtg=3.0)
             torch.cuda.synchronize()
             t0 = time.perf_counter()

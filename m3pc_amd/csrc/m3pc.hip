@@ -1548,7 +1548,14 @@ int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out) {
     CHK(dmalloc(&h->sa_buf, (size_t)(D.max_candidates > h->chain.max_cand ? D.max_candidates : h->chain.max_cand) * T * h->A));
     bind_ws(h.get(), &h->base);
     bind_slot(h.get(), 0);
-    HIPCHK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+    // ONE extra stream per device for all handles of the process: a process has four hardware queues, and with more
+    // streams than that two of them share a queue and stop overlapping (a second planner must not cost the first its halves)
+    {
+        static std::map<int, hipStream_t> shared_aux;
+        hipStream_t& sa = shared_aux[device];
+        if (!sa) HIPCHK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+        h->aux = sa;
+    }
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     for (int s = 0; s < M3PC_SLOTS; ++s)
@@ -1625,7 +1632,7 @@ int m3pc_destroy(m3pc_handle* h) {
             if (h->slot_join[s][i]) hipEventDestroy(h->slot_join[s][i]);
     for (int i = 0; i < 3; ++i)
         if (h->aux_tail[i]) hipEventDestroy(h->aux_tail[i]);
-    if (h->aux) hipStreamDestroy(h->aux);
+    if (h->aux) hipStreamSynchronize(h->aux);  // (shared by the handles of the device: not destroyed)
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     for (void* b : bufs)

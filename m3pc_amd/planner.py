@@ -40,6 +40,9 @@ _MODES = {"rtg_guiding": capi.MODE_RTG, "critic_lambda_guiding": capi.MODE_CRITI
           "noise_adding_lambda": capi.MODE_NOISE}
 
 
+_CHAIN_STREAMS = {}  # (device, priority) -> (policy-pass stream, re-score + select stream), shared by all planners
+
+
 def _cfg_get(cfg, name, default=None):
     return getattr(cfg, name, default)
 
@@ -290,8 +293,15 @@ class HipPlanner:
 
     def _chain_stream(self):
         if self._chain is None:
-            self._chain = torch.cuda.Stream(device=self.device, priority=self._chain_priority)
-            self._tchain = torch.cuda.Stream(device=self.device, priority=self._chain_priority) if self._tail_stream else self._chain
+            # one pair of streams per (device, priority) for every planner of the process: the device gives a process four
+            # hardware queues (current stream, the library's stream for the second candidate half, these two) -- with more
+            # streams than queues two of them share a queue and no longer overlap
+            key = (str(self.device), self._chain_priority)
+            if key not in _CHAIN_STREAMS:
+                _CHAIN_STREAMS[key] = (torch.cuda.Stream(device=self.device, priority=self._chain_priority),
+                                       torch.cuda.Stream(device=self.device, priority=self._chain_priority))
+            self._chain, t = _CHAIN_STREAMS[key]
+            self._tchain = t if self._tail_stream else self._chain
         return self._chain
 
     def _acquire_slot(self):

@@ -37,7 +37,7 @@ def main():
         for w in range(4):
             dl = [int(s[w, k + 1] - s[w, k]) for k in range(6)]
             print(f"rows {M} wave {w} clocks: " + "  ".join(f"{n} {v}" for n, v in zip(names, dl)) + f"  total {int(s[w, 6] - s[w, 0])}")
-        for v in (3, 6, 1, 7, 2, 0):
+        for v in (3, 4, 0):
             stamps.zero_()
             _call(lib, O, R, None, 1, W, sb, 0, p, [None] * 4, 0, 0, X, H, v, stamps=stamps)
             s = stamps.cpu()

@@ -1,10 +1,10 @@
 #!/bin/bash
-# lab: candidate-part sizes x hardware queue count on the pipelined plan step (run on the GPU box)
+# lab: candidate-part sizes with the re-score tail on the policy stream (four streams in all) on the pipelined plan step
 set -uo pipefail
 export M3PC_LIB=$PWD/m3pc_amd/libm3pc_hip_lab.so
-for q in 4 8; do
-  for sp in "" "334,334" "256,256,256" "668" "334,334,334"; do
-    echo "== queues $q split '$sp'"
-    GPU_MAX_HW_QUEUES=$q M3PC_STREAM_SPLIT=$sp timeout -k 10 120 python tools/pipeline_probe.py 60 0,2,2 2>&1 | grep depth
+for sp in "" "334,334" "342,341" "256,256,256"; do
+  for kw in "dict(tail_stream=False)" "dict()"; do
+    echo "== split '$sp' $kw"
+    M3PC_STREAM_SPLIT=$sp timeout -k 10 120 python tools/pipeline_probe.py 60 2,2 "$kw" 2>&1 | grep depth
   done
 done
