@@ -107,6 +107,11 @@ def test_c2_bf16_with_fp32_rescore_keeps_reference_argmax():
     ref = g["expect_return_shifted"][top]
     assert np.abs(got - ref).max() <= 5e-5 * float(er.abs().max())
     assert np.abs(ev.cpu().numpy() - g["eval_action"]).max() < 5e-3
+    # the reference's multinomial draw (learner.py:324-325), replayed on the bf16 mode's p with the stored seed: the same index
+    # (VERDICT r2 item 4), and p itself within the bf16 deviation of the reference's
+    idx = torch.multinomial(p.last["p"].cpu(), 1, generator=torch.Generator().manual_seed(77))
+    assert int(idx) == int(g["sample_idx"].reshape(-1)[0])
+    assert np.abs(p.last["p"].cpu().numpy() - g["p"].reshape(-1)).max() < 5e-3
     p.handle.close()
 
 
