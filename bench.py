@@ -585,6 +585,22 @@ def extras(args, dims, cfg, hist, planner, S, A):
             dt_ = (time.perf_counter() - t0) / reps
             bat[f"E{E}"] = {"ms_per_call": round(1e3 * dt_, 4), "plan_steps_per_s": round(E / dt_, 2)}
             pb.handle.close()
+        # the environments stepping together: one policy pass at batch E, the windows' candidate passes back to back, one fp32
+        # re-score pass over all windows' sets (action_sample_batch(lockstep=True))
+        E = 8
+        pl_ = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None, precision="bf16",
+                         generator=torch.Generator(device="cuda").manual_seed(1), max_batch=E, max_windows=E)
+        hs = [dict(synth.make_history(dims, i), path_length=500) for i in range(E)]
+        for _ in range(4):
+            pl_.action_sample_batch(hs, eval=True, rtg=3.0, lockstep=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(12):
+            pl_.action_sample_batch(hs, eval=True, rtg=3.0, lockstep=True)
+        torch.cuda.synchronize()
+        dt_ = (time.perf_counter() - t0) / 12
+        bat["E8_lockstep"] = {"ms_per_call": round(1e3 * dt_, 4), "plan_steps_per_s": round(E / dt_, 2)}
+        pl_.handle.close()
         out["batched"] = {"what": "action_sample_batch: E env windows x N=%d candidates per call, one pipelined plan step per window "
                                   "(incl. host window assembly and H2D copies; the call returns when all E are resolved)" % cfg.action_samples,
                           **bat}

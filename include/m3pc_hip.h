@@ -111,7 +111,8 @@ typedef struct m3pc_plan_args {
     const void* returns; /* optional device (T,) raw returns row of the window (what
                           trajectory["returns"] holds, learner.py:272-293); NULL: `rtg` everywhere */
     int flags;         /* M3PC_PLAN_* bits (m3pc_candidate_pass); 0 = none                       */
-    int reserved;      /* 0                                                                      */
+    int window;        /* m3pc_candidate_pass behind m3pc_policy_pass_batch: which of the slot's windows
+                          this step plans (0 after a single-window m3pc_policy_pass)                */
 } m3pc_plan_args;
 
 /* m3pc_plan_args::flags.  M3PC_PLAN_DEFER_JOIN (m3pc_candidate_pass only): a large bf16 pass runs its candidate
@@ -194,6 +195,15 @@ int m3pc_policy_pass(m3pc_handle* h, const m3pc_plan_args* args, const float* st
 int m3pc_candidate_pass(m3pc_handle* h, const m3pc_plan_args* args, const float* states, const float* actions,
                         const float* rewards, const float* eps, float* loc, float* std, float* sample_actions,
                         float* expect_return, float* pred_rewards, float* pred_boot, void* stream);
+/* The policy passes of E independent windows as ONE pass at batch E (learner.py:278-284 per window; several
+ * environments step together: replay_buffer.py:204-232 per environment): states (E,T,S), actions (E,T,A), rewards (E,T,1)
+ * device, rtg host (E,).  The slot then holds E policy heads; m3pc_candidate_pass plans window w of them with
+ * m3pc_plan_args::window = w and that window's rows of states / actions / rewards.  loc / std: optional (E,T,A) out.
+ * args: mode, horizon, slot are read.  E <= max_batch.  The few-row fp32 kernels choose their tiling by the row count, so
+ * a window's policy head agrees with the single-window pass to fp32 rounding, not bit for bit. */
+int m3pc_policy_pass_batch(m3pc_handle* h, const m3pc_plan_args* args, int n_windows, const float* states,
+                           const float* actions, const float* rewards, const double* rtg, float* loc, float* std,
+                           void* stream);
 /* Orders `stream` behind every part of the last m3pc_candidate_pass(M3PC_PLAN_DEFER_JOIN) of step slot `slot`
  * (no-op when that pass joined by itself or ran in one part).  The consumer of a step's scores -- the re-score +
  * select of learner.py:318-325 -- calls it on its own stream. */

@@ -27,7 +27,7 @@ SLOTS = 4  # M3PC_SLOTS: plan steps in flight per handle
 EXPORTS = (
     "m3pc_last_error", "m3pc_abi_version", "m3pc_create", "m3pc_destroy", "m3pc_load_weights", "m3pc_load_stats",
     "m3pc_set_tokenizer", "m3pc_set_critic", "m3pc_tokenize", "m3pc_detokenize", "m3pc_forward", "m3pc_goal_step",
-    "m3pc_policy_pass", "m3pc_candidate_pass", "m3pc_candidate_join",
+    "m3pc_policy_pass", "m3pc_candidate_pass", "m3pc_candidate_join", "m3pc_policy_pass_batch",
     "m3pc_plan_step", "m3pc_plan_step_batch", "m3pc_score_actions", "m3pc_rescore", "m3pc_rescore_topk", "m3pc_topk_window",
     "m3pc_rescore_listed", "m3pc_rescore_merge", "m3pc_select",
     "m3pc_profile_enable",
@@ -49,7 +49,7 @@ class PlanArgs(C.Structure):
     _fields_ = [("mode", C.c_int), ("precision", C.c_int), ("horizon", C.c_int), ("n_total", C.c_int),
                 ("n_begin", C.c_int), ("n_count", C.c_int), ("lmbda", C.c_double), ("discount", C.c_double),
                 ("rtg", C.c_double), ("slot", C.c_int), ("returns_f64", C.c_int), ("returns", C.c_void_p),
-                ("flags", C.c_int), ("reserved", C.c_int)]
+                ("flags", C.c_int), ("window", C.c_int)]
 
 
 PLAN_DEFER_JOIN = 1
@@ -90,6 +90,7 @@ def load_library(path: Optional[str] = None):
         "m3pc_policy_pass": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, vp],
         "m3pc_candidate_pass": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_candidate_join": [vp, i, vp],
+        "m3pc_policy_pass_batch": [vp, C.POINTER(PlanArgs), i, vp, vp, vp, C.POINTER(d), vp, vp, vp],
         "m3pc_plan_step": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_plan_step_batch": [vp, C.POINTER(PlanArgs), i, vp, vp, vp, C.POINTER(d), vp, vp, vp, vp, vp, vp, vp],
         "m3pc_score_actions": [vp, C.POINTER(PlanArgs), i, vp, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -321,7 +322,7 @@ class Handle:
 
     def candidate_pass(self, mode: int, states, actions, rewards, eps, horizon: int, lmbda: float, discount: float,
                        n_total: int, n_begin: int = 0, n_count: Optional[int] = None, precision: int = PREC_FP32, slot: int = 0,
-                       want_debug: bool = False, out=None, defer_join: bool = False):
+                       want_debug: bool = False, out=None, defer_join: bool = False, window: int = 0):
         """Candidates + PASS 2 + scores of a plan step on the current stream (candidate workspace) from ``slot``'s policy
         head.  ``out``: optional dict of preallocated loc / std / sample_actions / expect_return.  ``defer_join``: the
         current stream does not wait for the parts of the pass that run on the handle's own streams; the consumer of the
@@ -345,6 +346,7 @@ class Handle:
         pb = torch.empty((n_count, horizon), **f32) if want_debug else None
         args = self._args(mode, precision, horizon, n_total, n_begin, n_count, lmbda, discount, 0.0, slot)
         args.flags = PLAN_DEFER_JOIN if defer_join else 0
+        args.window = int(window)  # which of the slot's policy heads (policy_pass_batch)
         ins = [self._f32(t) for t in (states, actions, rewards, eps)]
         check(self.lib.m3pc_candidate_pass(self._h, C.byref(args), _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), _ptr(ins[3]),
                                            _ptr(loc), _ptr(std), _ptr(acts), _ptr(er), _ptr(pr), _ptr(pb), _stream(dev)))
@@ -352,6 +354,15 @@ class Handle:
         if want_debug:
             res["pred_rewards"], res["pred_boot"] = pr, pb
         return res
+
+    def policy_pass_batch(self, mode: int, states, actions, rewards, horizon: int, rtg, slot: int = 0, loc=None, std=None):
+        """PASS 1 of E windows as one pass at batch E (policy workspace): states (E,T,S), actions (E,T,A), rewards (E,T,1),
+        rtg (E,) floats.  Leaves E policy heads in ``slot``: ``candidate_pass(..., slot=slot, window=w)`` plans window w."""
+        E = states.shape[0]
+        args = self._args(mode, PREC_FP32, horizon, 1, 0, 1, 0.0, 0.0, 0.0, slot)
+        rt = (C.c_double * E)(*[float(v) for v in rtg])
+        check(self.lib.m3pc_policy_pass_batch(self._h, C.byref(args), E, _ptr(self._f32(states)), _ptr(self._f32(actions)),
+                                              _ptr(self._f32(rewards)), rt, _ptr(loc), _ptr(std), _stream(self.device)))
 
     def candidate_join(self, slot: int):
         """Order the current stream behind every part of ``slot``'s last candidate pass enqueued with ``defer_join``."""

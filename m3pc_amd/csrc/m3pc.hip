@@ -143,6 +143,7 @@ struct m3pc_handle {
     struct Slot {
         float *loc = nullptr, *sd = nullptr, *rtok = nullptr;
         bool policy_valid = false;  // loc / sd / rtok hold a single-window policy pass (what m3pc_rescore needs)
+        int n_windows = 0;          // policy heads the slot holds (m3pc_policy_pass: 1, m3pc_policy_pass_batch: E)
     } slot[M3PC_SLOTS];
     int cur_slot = 0;
     // Workspaces.  The pointers above (X ... splitk_ws) are VIEWS of the workspace bound last (bind_ws), re-based per candidate
@@ -1749,7 +1750,10 @@ int m3pc_load_weights(m3pc_handle* h, const m3pc_named_tensor* tensors, int n, v
         invalidate_tables(h);
         ls[3] = 1;
     }
-    for (int sl = 0; sl < M3PC_SLOTS; ++sl) h->slot[sl].policy_valid = false;
+    for (int sl = 0; sl < M3PC_SLOTS; ++sl) {
+        h->slot[sl].policy_valid = false;
+        h->slot[sl].n_windows = 0;
+    }
     HIPCHK(hipStreamSynchronize(st));  // the caller's tensors may go away when the call returns
     h->weights_loaded = true;
     return check_launch("load_weights");
@@ -1881,6 +1885,7 @@ int m3pc_goal_step(m3pc_handle* h, int batch, const float* states, const float* 
     CHK(get_plan(h, masks_fid, &fid));
     bind_slot(h, 0);
     h->slot[0].policy_valid = false;
+    h->slot[0].n_windows = 0;
     CHK(fill_rtok(h, rtg, batch, st));
     TokIn in;
     memset(&in, 0, sizeof(in));
@@ -1956,6 +1961,7 @@ int m3pc_policy_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* state
     h->allow_splitk = false;
     if (rc) return rc;
     h->slot[a->slot].policy_valid = true;
+    h->slot[a->slot].n_windows = 1;
     if (loc) HIPCHK(hipMemcpyAsync(loc, h->loc, (size_t)T * h->A * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (std_) HIPCHK(hipMemcpyAsync(std_, h->sd, (size_t)T * h->A * sizeof(float), hipMemcpyDeviceToDevice, st));
     return check_launch("policy_pass");
@@ -1968,7 +1974,9 @@ int m3pc_candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* st
     if (!h || !a || !states || !actions || !rewards || !eps || !sample_actions || !expect_return)
         return fail(M3PC_EINVAL, "null argument");
     CHK(plan_check(h, a, true));
-    if (!h->slot[a->slot].policy_valid) return fail(M3PC_ESTATE, "m3pc_candidate_pass needs m3pc_policy_pass on slot %d first", a->slot);
+    if (a->window < 0 || a->window >= h->slot[a->slot].n_windows)
+        return fail(M3PC_ESTATE, "m3pc_candidate_pass: slot %d holds %d policy pass(es), window %d asked for (m3pc_policy_pass[_batch] first)",
+                    a->slot, h->slot[a->slot].n_windows, a->window);
     const int T = h->T;
     if (a->n_count < 1 || a->n_begin < 0 || a->n_begin + a->n_count > a->n_total)
         return fail(M3PC_EINVAL, "candidate range [%d,+%d) outside n_total=%d", a->n_begin, a->n_count, a->n_total);
@@ -1983,8 +1991,8 @@ int m3pc_candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* st
         SampleP sp;
         memset(&sp, 0, sizeof(sp));
         sp.hist_actions = actions;
-        sp.loc = h->loc;
-        sp.sd = h->sd;
+        sp.loc = h->loc + (size_t)a->window * T * h->A;
+        sp.sd = h->sd + (size_t)a->window * T * h->A;
         sp.eps = eps;
         sp.mode = a->mode == M3PC_MODE_NOISE ? 1 : 0;
         sp.T = T;
@@ -2149,29 +2157,24 @@ int m3pc_score_actions(m3pc_handle* h, const m3pc_plan_args* a, int n_windows, c
     return rc;
 }
 
-int m3pc_plan_step_batch(m3pc_handle* h, const m3pc_plan_args* a, int n_windows, const float* states, const float* actions,
-                         const float* rewards, const double* rtg, const float* eps, const int* window_index, float* loc,
-                         float* std_, float* sample_actions, float* expect_return, void* stream) {
-    if (!h || !a || !states || !actions || !rewards || !rtg || !eps || !window_index || !sample_actions || !expect_return)
-        return fail(M3PC_EINVAL, "null argument");
+// PASS 1 of E windows at once (learner.py:278-284 per window): return-conditioned policy, batch E, rcbc mask, fp32, in the
+// policy workspace; the slot then holds E policy heads (loc / sd rows [w T, (w+1) T)) and E rows of returns tokens.
+int m3pc_policy_pass_batch(m3pc_handle* h, const m3pc_plan_args* a, int n_windows, const float* states, const float* actions,
+                           const float* rewards, const double* rtg, float* loc, float* std_, void* stream) {
+    if (!h || !a || !states || !actions || !rewards || !rtg) return fail(M3PC_EINVAL, "null argument");
     if (!h->weights_loaded) return fail(M3PC_ESTATE, "weights not loaded");
     for (int k = 0; k < 4; ++k)
         if (!h->tok_set[k]) return fail(M3PC_ESTATE, "tokenizer '%s' not set", KEYN[k]);
-    const int T = h->T, E = n_windows, N = a->n_total;
+    const int T = h->T, E = n_windows;
     if (E < 1 || E > h->dm.max_batch) return fail(M3PC_ENOMEM, "n_windows %d outside [1, max_batch=%d]", E, h->dm.max_batch);
     if (a->horizon < 1 || a->horizon > T) return fail(M3PC_EINVAL, "horizon %d outside [1, T=%d]", a->horizon, T);
     if (a->mode < 0 || a->mode > 2) return fail(M3PC_EINVAL, "bad mode %d", a->mode);
-    if (a->precision != M3PC_PREC_FP32 && a->precision != M3PC_PREC_BF16) return fail(M3PC_EINVAL, "bad precision");
-    if (N < 1 || (long long)E * N > h->dm.max_candidates)
-        return fail(M3PC_ENOMEM, "n_windows * n_total = %lld > max_candidates %d", (long long)E * N, h->dm.max_candidates);
-    if (a->mode != M3PC_MODE_RTG && !h->critic_set) return fail(M3PC_ESTATE, "critic weights not set");
+    if (a->slot < 0 || a->slot >= M3PC_SLOTS) return fail(M3PC_EINVAL, "slot %d outside [0, %d)", a->slot, M3PC_SLOTS);
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->device));
-    const int hh = a->horizon, idx = T - hh, A = h->A;
-    if (a->slot < 0 || a->slot >= M3PC_SLOTS) return fail(M3PC_EINVAL, "slot %d outside [0, %d)", a->slot, M3PC_SLOTS);
+    const int idx = T - a->horizon, A = h->A;
     bind_slot(h, a->slot);
     CHK(fill_rtok(h, rtg, E, st));
-    // PASS 1 for all windows at once: return-conditioned policy, batch E, rcbc mask, fp32
     Plan* pl = nullptr;
     CHK(get_mask_plan(h, 0, idx, &pl));
     TokIn in;
@@ -2191,10 +2194,30 @@ int m3pc_plan_step_batch(m3pc_handle* h, const m3pc_plan_args* a, int n_windows,
     {
         WsScope ws(h, true, true);
         const int rc = forward_impl(h, pl, in, E, nullptr, nullptr, nullptr, h->loc, h->sd, DT_F32, st);
+        h->allow_splitk = false;
         if (rc) return rc;
     }
-    h->allow_splitk = false;
-    h->slot[a->slot].policy_valid = false;  // (m3pc_rescore works on a single-window slot; batched callers re-score with m3pc_score_actions)
+    h->slot[a->slot].policy_valid = E == 1;  // (m3pc_rescore works on a single-window slot; batched callers re-score with m3pc_score_actions)
+    h->slot[a->slot].n_windows = E;
+    if (loc) HIPCHK(hipMemcpyAsync(loc, h->loc, (size_t)E * T * A * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (std_) HIPCHK(hipMemcpyAsync(std_, h->sd, (size_t)E * T * A * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return check_launch("policy_pass_batch");
+}
+
+int m3pc_plan_step_batch(m3pc_handle* h, const m3pc_plan_args* a, int n_windows, const float* states, const float* actions,
+                         const float* rewards, const double* rtg, const float* eps, const int* window_index, float* loc,
+                         float* std_, float* sample_actions, float* expect_return, void* stream) {
+    if (!h || !a || !states || !actions || !rewards || !rtg || !eps || !window_index || !sample_actions || !expect_return)
+        return fail(M3PC_EINVAL, "null argument");
+    const int T = h->T, E = n_windows, N = a->n_total;
+    if (a->precision != M3PC_PREC_FP32 && a->precision != M3PC_PREC_BF16) return fail(M3PC_EINVAL, "bad precision");
+    if (E >= 1 && (N < 1 || (long long)E * N > h->dm.max_candidates))
+        return fail(M3PC_ENOMEM, "n_windows * n_total = %lld > max_candidates %d", (long long)E * N, h->dm.max_candidates);
+    if (a->mode >= 0 && a->mode <= 2 && a->mode != M3PC_MODE_RTG && !h->critic_set) return fail(M3PC_ESTATE, "critic weights not set");
+    CHK(m3pc_policy_pass_batch(h, a, n_windows, states, actions, rewards, rtg, nullptr, nullptr, stream));
+    hipStream_t st = (hipStream_t)stream;
+    const int hh = a->horizon, idx = T - hh, A = h->A;
+    h->slot[a->slot].policy_valid = false;
     CHK(ws_sync(h, st));
     // candidates of window w: rows [w N, (w+1) N) of cand / sample_actions, drawn from window w's policy head and eps block
     for (int w = 0; w < E; ++w) {

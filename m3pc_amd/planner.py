@@ -151,8 +151,9 @@ class HipPlanner:
         # chain workspace: the fp32 re-score sets (all windows of a lock-step batch together), the calibration subset
         self._n_cal = min(64, N)
         max_rescore = max(int(rescore_max) * nw, int(rescore_topk), self._n_cal, 1) if precision == "bf16" else 1
+        self._max_batch = max(int(max_batch), nw, 1)
         self.handle = capi.Handle(S, A, T, n_embd, n_head, n_enc_layer, n_dec_layer,
-                                  max_candidates=max(n_local * nw, 1), max_batch=max(int(max_batch), nw, 1),
+                                  max_candidates=max(n_local * nw, 1), max_batch=self._max_batch,
                                   critic_hidden=hidden, device=device, max_rescore=max_rescore)
         self.device = self.handle.device
         self.S, self.A, self.T = S, A, T
@@ -796,12 +797,15 @@ class HipPlanner:
         flight, staggered: window i+1's policy pass and window i-1's re-score + select run on the chain stream under window
         i's candidate pass.  Per window the result is bit-identical to the single-window call (same kernels, same rows, same
         draws in window order), first-layer history sharing included.
-        ``lockstep=True``: the round-2 form -- one policy pass at batch E, ONE candidate pass over E x N rows, one fp32
-        re-score pass over all windows' sets (needs ``HipPlanner(..., max_batch=E, max_windows=E)``; windows grouped by
-        effective horizon; no history sharing between windows).
+        ``lockstep=True``: the environments step together -- ONE policy pass at batch E (m3pc_policy_pass_batch), every window's own
+        candidate pass back to back, ONE fp32 re-score pass over all windows' sets: the ~75 short launches of the fp32 chains are
+        paid once per call instead of once per window (needs ``HipPlanner(..., max_batch=E, max_windows=E)``; windows grouped by
+        effective horizon; the few-row fp32 kernels choose their tiling by the row count, so a window's result agrees with the
+        single-window call to fp32 rounding, not bit for bit).  ``lockstep="onepass"``: the round-2 form, one candidate pass
+        over E x N rows with a per-candidate window index (no history sharing between windows).
         ``rtg``: None, a float, or one value per window.  Returns (E, A)."""
         if lockstep:
-            return self._action_sample_lockstep(sequence_histories, percentage, eval, rtg)
+            return self._action_sample_lockstep(sequence_histories, percentage, eval, rtg, onepass=lockstep == "onepass")
         E, A = len(sequence_histories), self.A
         rtgs = [rtg] * E if (rtg is None or np.isscalar(rtg)) else list(rtg)
         out = torch.empty((E, A), dtype=torch.float32, device=self.device)
@@ -823,7 +827,7 @@ class HipPlanner:
         self.last = dict(windows=info, delta=self._delta)
         return out
 
-    def _action_sample_lockstep(self, sequence_histories, percentage=1.0, eval=False, rtg=None):
+    def _action_sample_lockstep(self, sequence_histories, percentage=1.0, eval=False, rtg=None, onepass: bool = False):
         self._drain()
         cfg = self.cfg
         guidance = cfg.plan_guidance
@@ -841,16 +845,32 @@ class HipPlanner:
         dev = torch.from_numpy(host).to(self.device)  # one packed H2D copy for all windows
         out = torch.empty((E, A), dtype=torch.float32, device=self.device)
         info = [None] * E
-        for h in sorted({m[0] for m in meta}):
-            ids = [i for i, m in enumerate(meta) if m[0] == h]
+        groups = []
+        for h in sorted({m[0] for m in meta}):  # windows of one effective horizon, at most max_batch of them per group
+            same = [i for i, m in enumerate(meta) if m[0] == h]
+            groups += [(h, same[c0 : c0 + self._max_batch]) for c0 in range(0, len(same), self._max_batch)]
+        for h, ids in groups:
             sel = dev if len(ids) == E else dev[torch.tensor(ids, device=self.device)]
             s = sel[:, : T * S].reshape(-1, T, S).contiguous()
             a = sel[:, T * S : T * (S + A)].reshape(-1, T, A).contiguous()
             r = sel[:, T * (S + A) :].reshape(-1, T, 1).contiguous()
             Eg = len(ids)
             eps = self._eps((Eg, N, h, A)) if mode == capi.MODE_NOISE else self._eps((Eg, N, T, A))
-            res = self.handle.plan_step_batch(mode, s, a, r, [meta[i][1] for i in ids], eps, h, lmbda, float(cfg.discount), N,
-                                              precision=self.precision)
+            if onepass:
+                res = self.handle.plan_step_batch(mode, s, a, r, [meta[i][1] for i in ids], eps, h, lmbda, float(cfg.discount), N,
+                                                  precision=self.precision)
+            else:
+                # ONE policy pass at batch Eg, then every window's own candidate pass (first-layer history sharing and the two
+                # candidate halves as in the single-window step), back to back: the caller's stream joins the halves once, at the end
+                f32 = dict(dtype=torch.float32, device=self.device)
+                res = dict(expect_return=torch.empty((Eg, N), **f32), sample_actions=torch.empty((Eg, N, h, A), **f32),
+                           loc=torch.empty((Eg, T, A), **f32), std=torch.empty((Eg, T, A), **f32))
+                self.handle.policy_pass_batch(mode, s, a, r, h, [meta[i][1] for i in ids], slot=0)
+                for w in range(Eg):
+                    self.handle.candidate_pass(mode, s[w], a[w], r[w], eps[w], h, lmbda, float(cfg.discount), N, precision=self.precision,
+                                               slot=0, window=w, defer_join=True,
+                                               out={k: v[w] for k, v in res.items()})
+                self.handle.candidate_join(0)
             er, acts = res["expect_return"], res["sample_actions"]
             stats_h = None
             merged = [er[w] for w in range(Eg)]

@@ -39,7 +39,7 @@ def test_abi_version_and_error_string(lib):
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(capi.Dims) == 11 * 4
     assert ctypes.sizeof(capi.PlanArgs) == 6 * 4 + 3 * 8 + 2 * 4 + 8 + 2 * 4
-    assert capi.PlanArgs.flags.offset == 64 and capi.PlanArgs.reserved.offset == 68
+    assert capi.PlanArgs.flags.offset == 64 and capi.PlanArgs.window.offset == 68
     assert capi.PlanArgs.lmbda.offset == 24 and capi.PlanArgs.rtg.offset == 40
     assert capi.PlanArgs.slot.offset == 48 and capi.PlanArgs.returns_f64.offset == 52 and capi.PlanArgs.returns.offset == 56
     assert ctypes.sizeof(capi.NamedTensor) == 32

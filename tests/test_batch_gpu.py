@@ -30,7 +30,7 @@ def _tiny(N=16, guidance="rtg_guiding", temp=0.01, **kw):
 
 
 # ------------------------------------------------------------------------------------------------ batched planning (f1)
-@pytest.mark.parametrize("lockstep", [False, True])
+@pytest.mark.parametrize("lockstep", [False, True, "onepass"])
 @pytest.mark.parametrize("guidance,mode,temp", [("rtg_guiding", "rtg", 0.01), ("critic_lambda_guiding", "critic", 1.0)])
 def test_batched_planning_equals_single_window_calls_and_the_reference(guidance, mode, temp, lockstep):
     """E = 4 windows with mixed horizons (path_length 0 and 3 plan with horizon T - end_idx) on the tiny config, fp32: every
@@ -67,7 +67,7 @@ def test_batched_planning_equals_single_window_calls_and_the_reference(guidance,
     ps.handle.close()
 
 
-@pytest.mark.parametrize("lockstep", [False, True])
+@pytest.mark.parametrize("lockstep", [False, True, "onepass"])
 def test_batched_bf16_planning_keeps_the_reference_argmax(lockstep):
     """Full-size model, bf16 candidate pass + bound-driven fp32 re-score, E = 4 windows x N = 256: the four hopper / weight
     seed 0 cases of g5_argmax.npz (captured from the reference) in one batch."""
