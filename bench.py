@@ -163,6 +163,9 @@ def main():
                     help="fp32 re-score set: certified (every candidate that can still hold the arg-max; default) or a fixed top-k")
     ap.add_argument("--rescore-topk", type=int, default=16)
     ap.add_argument("--rescore-min", type=int, default=None, help="smallest first re-score pass (default: the planner's)")
+    ap.add_argument("--settle", type=int, default=24,
+                    help="untimed plan steps right after the weights are loaded, before the W warm-up steps: the bf16 error bound of "
+                         "the certified re-score is calibrated per weight load and rises over the first steps it sees (setup)")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / closed-loop / shipped-config / parity side measurements")
     ap.add_argument("--shard", default="env", choices=["env", "candidates"], help="what the ranks of a multi-GPU run divide")
     ap.add_argument("--strong", action="store_true", help="--shard candidates: keep the global candidate count fixed")
@@ -271,6 +274,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    run(args.settle)  # per-weight-load setup: lets the re-score's error bound settle (a raise repeats that step's merge + select)
     run(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -384,7 +388,7 @@ def main():
                                       + (f"certified set, {sum(n_re) / max(len(n_re), 1):.1f} candidates on average" if args.rescore == "bound"
                                          else f"top-{args.rescore_topk}") + f"); {flight_txt}; window resident in HBM",
                           "candidates_per_gpu": n_local, "global_candidates": n_global, "horizon": H, "traj_length": T,
-                          "steps_in_flight": depth, "parallelism": par},
+                          "steps_in_flight": depth, "settle_steps": args.settle, "parallelism": par},
                "latency_ms": latency, "roofline": roofline,
                "rescore": {"mode": args.rescore, "n_mean": round(sum(n_re) / max(len(n_re), 1), 2), "n_max": max(n_re) if n_re else None,
                            "delta": planner.last.get("delta"), "delta_grown": planner.delta_grown,
