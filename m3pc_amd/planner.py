@@ -200,6 +200,7 @@ class HipPlanner:
         self._force_collective = False  # test hook: run the all-gather even in a world of one
         self._bf16_offset = 0.0     # test hook: a constant added to the bf16 scores before the re-score
         self._predrawn = None       # (mode, h, eps, expo) drawn by action_sample ahead of the window copy
+        self._stage, self._stage_i = None, 0  # two pinned window staging buffers (+ the event of the copy that read each last)
 
     # ---------------------------------------------------------------------------------------- weights
     def load_state_dict(self, state_dict):
@@ -271,11 +272,24 @@ class HipPlanner:
         st = self.tokenizer_manager.tokenizers["returns"].stats
         return float(np.asarray(st.min + (st.max - st.min) * percentage).reshape(-1)[0])
 
+    def _stage_copy(self, fill):
+        """One packed H2D copy of a window through one of two pinned staging buffers (asynchronous: the host goes on enqueuing
+        while the copy runs; a buffer is re-used only after the copy that read it last has completed).  fill(flat) -> meta."""
+        if self._stage is None:
+            n = self.T * (self.S + self.A + 1)
+            self._stage = [(torch.zeros((n,), dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+        pin, ev = self._stage[self._stage_i]
+        self._stage_i ^= 1
+        ev.synchronize()
+        meta = fill(pin.numpy())
+        dev = pin.to(self.device, non_blocking=True)
+        ev.record()
+        return dev, meta
+
     def assemble_window(self, sequence_history, rtg=None, percentage=1.0):
         """learner.py:342-385.  Returns (states (T,S), actions (T,A), rewards (T,1) on device, horizon, rtg)."""
-        horizon, return_to_go = self._window_host(sequence_history, rtg, percentage, self._host)
-        dev = torch.from_numpy(self._host).to(self.device)  # one packed H2D copy; the three blocks are contiguous views
-        states, actions, rewards = self._blocks(dev)
+        dev, (horizon, return_to_go) = self._stage_copy(lambda flat: self._window_host(sequence_history, rtg, percentage, flat))
+        states, actions, rewards = self._blocks(dev)  # one packed H2D copy; the three blocks are contiguous views
         return states, actions, rewards, horizon, return_to_go
 
     # ---------------------------------------------------------------------------------------- guidance
@@ -642,8 +656,7 @@ class HipPlanner:
     def assemble_goal_window(self, sequence_history, rtg=None, percentage=1.0):
         """research/zeroshot_omtm/learner.py:164-223: the history window, with the observation rows of the
         WHOLE window taken from the buffer (future rows are way-points), shortened near the 1000-step end."""
-        horizon, return_to_go = self._goal_window_host(sequence_history, rtg, percentage, self._host)
-        dev = torch.from_numpy(self._host).to(self.device)
+        dev, (horizon, return_to_go) = self._stage_copy(lambda flat: self._goal_window_host(sequence_history, rtg, percentage, flat))
         states, actions, rewards = self._blocks(dev)
         return states, actions, rewards, horizon, return_to_go
 
@@ -961,7 +974,9 @@ class HipPlanner:
             assert guidance in _MODES, guidance
             # the step's variates do not depend on the window: their kernels are enqueued first and run while the host copies
             # the window (same draws in the same order as without this: eps, then the multinomial's exponentials)
-            h, _ = self._window_host(sequence_history, rtg, percentage, self._host)
+            h, end_idx = int(self.cfg.horizon), int(sequence_history["path_length"])
+            if end_idx + h < self.T:
+                h = self.T - end_idx  # (learner.py:342-345, as _window_host)
             self._drain()
             self._predrawn = (_MODES[guidance], h, self._draw_eps(_MODES[guidance], h), self._draw_expo())
         states, actions, rewards, h, return_to_go = self.assemble_window(sequence_history, rtg, percentage)
