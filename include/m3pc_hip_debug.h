@@ -33,6 +33,13 @@ int m3pc_debug_block_fused_qkv(const void* O, int M, const float* res, const voi
                                void* stream_buf, const float* bo, const float* b1, const float* b2, const float* ln2_g,
                                const float* ln2_b, const float* lnA_g, const float* lnA_b, const float* bqkv, float* Xout, void* QKV,
                                void* stream, long long* stamps);
+/* the decoder form with the two scalar output heads inside the tail (see csrc/m3pc.hip for the argument layout) */
+int m3pc_debug_block_fused_heads(const void* O, int M, const float* rowtab, int rt_mod, const void* Wo, const void* W1, const void* W2,
+                                 const void* Wh, void* stream_buf, const float* bo, const float* b1, const float* b2, const float* ln2_g,
+                                 const float* ln2_b, const float* lnA_g, const float* lnA_b, const float* lnB_g0, const float* lnB_b0,
+                                 const float* lnB_g1, const float* lnB_b1, int out_mod, int out_grp, const float* hb1, const float* hw2,
+                                 const float* hb2, const float* hmean, const float* hstd, float* out0, float* out1, void* stream,
+                                 long long* stamps);
 /* the fused decoder input (kv_fused_kernel) on caller tensors */
 long long m3pc_debug_kv_stream_bytes(void);
 int m3pc_debug_kv_fused(const void* Z, int n, int Le, int kept0, int off0, int kept1, int off1, const void* We0, const void* We1,

@@ -7,6 +7,9 @@
 //     X''= X' + b2 + H W2^T               FFN2 + residual
 //     Hout = bf16(LN_A(X''))  [LN_B on top]  the LayerNorm(s) that consume the block output, or -- an encoder layer followed by
 //     QKV  = bf16(LN_A(X'') Wqkv^T + bqkv)    another -- the next layer's whole Q|K|V projection (Hout then never exists)
+//     or -- the decoder layer of a plan step whose two scored keys have scalar heads (rewards, returns: mtm_model.py:428-433) --
+//     y = Linear(512,1)(gelu(Linear(512,512)(LN_head(LN_A(X''))))) de-tokenised: the whole output head (TAIL == 2; a
+//     workgroup then owns 128 rows of ONE of the two keys, so that its four waves stream one head's weights)
 //
 // d = 512, ff = 2048.  A workgroup owns 128 token rows, each of its four waves (one per SIMD, the whole 512-entry
 // register file) a strip of 32 of them -- through the whole chain, so nothing but O, the residual rows and the
@@ -69,6 +72,8 @@ constexpr int FR_TOTAL = FR_OUT + NCH * 128;     // 4608
 constexpr int RS_FR = 32, RS_B = RS_FR * 1024, NRS = FR_TOTAL / RS_FR;  // 144 ring stages (= phases) of 32 KiB
 constexpr int QKV_FR = 3 * FR_OUT;                // the next layer's Q|K|V projection behind the layer's own fragments: 1536
 constexpr int NRS_QKV = NRS + QKV_FR / RS_FR;     // 192 stages
+constexpr int HEAD_FR = FR_OUT;                   // one output head's Linear(512,512): 16 hidden tiles x 32 k-steps
+constexpr int NRS_HEAD = NRS + HEAD_FR / RS_FR;   // 160 stages (the stream holds both heads: 144 .. 175)
 constexpr int NSLOT = 3;
 constexpr int ACT_LDS = 8;                       // LayerNorm-2 fragments of k-steps 24..31 live in LDS: 8 KiB per wave
 constexpr int ACT_OFF = NSLOT * RS_B;
@@ -126,11 +131,29 @@ __global__ __launch_bounds__(256) void pack_block_qkv_kernel(const bf16_t* __res
     for (int j = 0; j < 8; ++j) o[j] = Wqkv[row + 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3)];
 }
 
+// fragments FR_TOTAL.. of the decoder layer's stream: the first Linear of the two scalar output heads, head s at
+// FR_TOTAL + 512 s: hidden tile t (32 units), MFMA i in the k order of an FFN1 phase (the other operand is a LayerNorm'd accumulator)
+__global__ __launch_bounds__(256) void pack_block_heads_kernel(const bf16_t* __restrict__ Wh0, const bf16_t* __restrict__ Wh1,
+                                                               bf16_t* __restrict__ out) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= 2 * HEAD_FR * 64) return;
+    const int f = gid >> 6, lane = gid & 63, r = lane & 31, h = lane >> 5;
+    const int hs = f / HEAD_FR, w = f % HEAD_FR, t = w / KS, ks = a_kstep(w % KS);
+    const bf16_t* W = hs ? Wh1 : Wh0;
+    const size_t row = (size_t)(32 * t + r) * BD;
+    bf16_t* o = out + (size_t)(FR_TOTAL * 64 + gid) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = W[row + 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3)];
+}
+
 size_t block_stream_bytes() { return (size_t)(FR_TOTAL + QKV_FR) * 1024; }
 bool block_fused_supported(int d, int ff) { return d == BD && ff == BFF; }
 
 void launch_pack_block_stream(const bf16_t* Wo, const bf16_t* W1, const bf16_t* W2, bf16_t* out, hipStream_t st) {
     hipLaunchKernelGGL(pack_block_stream_kernel, dim3(FR_TOTAL * 64 / 256), dim3(256), 0, st, Wo, W1, W2, out);
+}
+void launch_pack_block_heads(const bf16_t* Wh0, const bf16_t* Wh1, bf16_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(pack_block_heads_kernel, dim3(2 * HEAD_FR * 64 / 256), dim3(256), 0, st, Wh0, Wh1, out);
 }
 void launch_pack_block_qkv(const bf16_t* Wqkv_next, bf16_t* out, hipStream_t st) {
     hipLaunchKernelGGL(pack_block_qkv_kernel, dim3(QKV_FR * 64 / 256), dim3(256), 0, st, Wqkv_next, out);
@@ -154,6 +177,9 @@ __device__ __forceinline__ void mfma_a(f32x16& c, u32x4 a, u32x4 b) {
 __device__ __forceinline__ void mfma_v(f32x16& c, u32x4 a, u32x4 b) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
+__device__ __forceinline__ void mfma_v0(f32x16& c, u32x4 a, u32x4 b) {  // c = a b (no accumulator input)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
+}
 // after the last MFMA into c, before anything but an MFMA reads it (8-pass MFMA: 12 wait states; 18 given)
 __device__ __forceinline__ void mfma_done_v(f32x16& c) { asm volatile("s_nop 15\n\ts_nop 1" : "+v"(c)); }
 __device__ __forceinline__ void mfma_done_a(f32x16 (&c)[16]) {
@@ -173,17 +199,24 @@ __device__ __forceinline__ void acc_touch(f32x16 (&c)[16]) {
 // DBG (timing experiments): 1 = no DMA pieces, 2 = no gelu, 3 = clocks per FFN phase kind into p.stamps[8..11],
 // 4 = VALU slice in a region of its own behind its MFMA, 5 = gelu of every second value only, 6 = no s_barrier in the
 // per-stage sync, 7 = weight fragments read once (no LDS reads in the loops).  2, 5, 6, 7 compute wrong results.  p.stamps: phase stamps (shader clocks) of one workgroup
-// QKV: the stream goes on behind the FFN with the next layer's in_proj rows (p.QKVout)
-template <int DBG, bool QKV>
+// TAIL: what follows the FFN in the stream -- 1: the next layer's in_proj rows (p.QKVout), 2: the two scalar output heads (p.head_out)
+template <int DBG, int TAIL>
 __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
-    constexpr int NST = QKV ? NRS_QKV : NRS;  // ring stages of this stream
+    constexpr bool QKV = TAIL == 1, HEADS = TAIL == 2;
+    constexpr int NST = QKV ? NRS_QKV : HEADS ? NRS_HEAD : NRS;  // ring stages a workgroup consumes
     __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int row0 = blockIdx.x * 128;
-    const int rtok = row0 + 32 * wu + l31;          // this lane's token row
-    const bool valid = rtok < p.M;
+    // HEADS: workgroup b owns rows 128 (b >> 1) .. of row group hs = b & 1 -- the rows (r % out_mod) / out_grp == hs in their
+    // order; gi = this lane's index among them (= its index in that head's output)
+    const int hs = HEADS ? (int)(blockIdx.x & 1) : 0;
+    const int gi = HEADS ? (int)(blockIdx.x >> 1) * 128 + 32 * wu + l31 : 0;
+    const int gi_ld = HEADS ? (gi < p.M / 2 ? gi : p.M / 2 - 1) : 0;
+    const int rtok = HEADS ? (gi_ld / p.out_grp) * p.out_mod + hs * p.out_grp + gi_ld % p.out_grp
+                           : row0 + 32 * wu + l31;  // this lane's token row
+    const bool valid = HEADS ? gi < p.M / 2 : rtok < p.M;
     const int rld = valid ? rtok : p.M - 1;         // (loads of the padding rows read the last row)
     const int lane16 = lane * 16;
     long long stamps[7];  // (scalar registers; stored at the very end, and only when p.stamps is set)
@@ -191,13 +224,14 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     (void)pt;
     stamps[0] = __builtin_readcyclecounter();
 
-    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream, 0, (unsigned)(NST * RS_B), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream, 0, (unsigned)((HEADS ? NRS + 2 * HEAD_FR / RS_FR : NST) * RS_B), 0x00020000);
     (void)w_rs;
     // piece pc (0..7) of stage st: fragment wu + 4 pc of that stage -> the same position of ring slot `slot` = st % 3
     auto piece = [&](int st, int slot, int pc) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc does not know this builtin)
         if (DBG == 1) return;
-        const int sw = st >= NST ? st - NST : st;  // past the end: the head of the stream again (never read)
+        int sw = st >= NST ? st - NST : st;  // past the end: the head of the stream again (never read)
+        if (HEADS && sw >= NRS) sw += hs * (HEAD_FR / RS_FR);  // (this workgroup's head)
         const int fo = (wu + 4 * pc) * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lptr_t)(smem + slot * RS_B + fo), 16, lane16, sw * RS_B + fo, 0, 0);
 #endif
@@ -229,11 +263,11 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
             *(f32x4*)(tab + T_B2 + i) = *(const f32x4*)(p.b2 + i);
             *(f32x4*)(tab + T_G2 + i) = *(const f32x4*)(p.ln2_g + i);
             *(f32x4*)(tab + T_BE2 + i) = *(const f32x4*)(p.ln2_b + i);
-            if (p.Hout || QKV) {
+            if (p.Hout || QKV || HEADS) {
                 *(f32x4*)(tab + T_GA + i) = *(const f32x4*)(p.lnA_g + i);
                 *(f32x4*)(tab + T_BA + i) = *(const f32x4*)(p.lnA_b + i);
             }
-            if (!QKV && p.Hout && p.lnB_g[0]) {
+            if (!QKV && (p.Hout || HEADS) && p.lnB_g[0]) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     *(f32x4*)(tab + T_GB + k * BD + i) = *(const f32x4*)(p.lnB_g[k] + i);
@@ -628,6 +662,118 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the pieces issued past the end of the stream
         mfma_done_a(acc);
         store_third(2);
+    } else if constexpr (HEADS) {
+        // ---- the output head of this workgroup's key: y = w2 . gelu(W1 LN_head(LN_A(X'')) + b1) + b2, de-tokenised.
+        // W1 runs like an FFN1: 16 phases of one hidden tile (32 units over the 32 k-steps), accumulators h0 / h1 in turn;
+        // gelu of tile j-1 and its share of the dot product with w2 run on the VALU beside the MFMAs of tile j.
+        constexpr int T_HB1 = T_B1, T_HW2 = T_B1 + BD;  // this head's b1 | w2 in the (now dead) linear1-bias table
+        if (tid < BD / 4) *(f32x4*)(tab + T_HB1 + 4 * tid) = *(const f32x4*)(p.hb1[hs] + 4 * tid);
+        else *(f32x4*)(tab + T_HW2 + 4 * (tid - BD / 4)) = *(const f32x4*)(p.hw2[hs] + 4 * (tid - BD / 4));
+        float rstd, nmr;
+        row_stats(rstd, nmr);
+        acc_touch(acc);
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn)  // acc := LN_A(acc) (decoder.norm)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q == 0) asm volatile("" : "+v"(rstd), "+v"(nmr) : : "memory");  // (see LayerNorm-2)
+                const int n = 32 * jn + 8 * q;
+                const f32x4 g = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_GA + n);
+                const f32x4 b = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_BA + n);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[jn][4 * q + i] = fmaf(fmaf(acc[jn][4 * q + i], rstd, nmr), g[i], b[i]);
+                if (q == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        acc_touch(acc);
+        row_stats(rstd, nmr);
+        acc_touch(acc);
+        {   // the head's own LayerNorm -> bf16 B-operand fragments: k-steps 0..23 in act[], 24..31 in this wave's LDS region
+            lds_cf32_t const gtab = tabl + T_GB + hs * BD;
+            lds_cf32_t const btab = tabl + T_BB + hs * BD;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                asm volatile("" : "+v"(rstd), "+v"(nmr) : : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                const int jn = s >> 1;
+                float y[8];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int q = 2 * (s & 1) + k, n = 32 * jn + 8 * q;
+                    const f32x4 g = *(const f32x4 __attribute__((address_space(3)))*)(gtab + n);
+                    const f32x4 b = *(const f32x4 __attribute__((address_space(3)))*)(btab + n);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[4 * k + i] = fmaf(fmaf(acc[jn][4 * q + i], rstd, nmr), g[i], b[i]);
+                }
+                bf16x8 w;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[j] = (bf16_t)y[j];
+                if (s < KS - ACT_LDS) {
+                    act[s] = __builtin_bit_cast(u32x4, w);
+                    asm volatile("" : "+v"(act[s]));
+                } else {
+                    *(u32x4*)(abase + (s - (KS - ACT_LDS)) * 1024) = __builtin_bit_cast(u32x4, w);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the head tables are in place for every wave
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // fragment groups 0, 1 of stage 144 (slot 0): it landed before the FFN ended
+            R[0][k] = frag(0, k);
+            R[1][k] = frag(0, 4 + k);
+        }
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 hbb[2], hww[2];  // b1 / w2 of the two hidden units a group's gelu slice works on, by group parity
+        float dot = 0.f;
+        // units of tile tv, group g: registers e = 2 g, 2 g + 1 <-> features 32 tv + 8 (g >> 1) + 4 lh + 2 (g & 1) (+ 1)
+        auto hload = [&](int tv, int g) {
+            const int o = 32 * tv + 8 * (g >> 1) + 2 * (g & 1);
+            hbb[g & 1] = *(const f32x2 __attribute__((address_space(3)))*)(tabl + T_HB1 + o);
+            hww[g & 1] = *(const f32x2 __attribute__((address_space(3)))*)(tabl + T_HW2 + o);
+        };
+        auto gelu_dot = [&](const f32x16& hh, int g, int k) {
+            constexpr float C0 = -2.3011212f, C1 = -0.10677572f, C2 = 0.001014263f;  // (gelu_slice)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (k == 0) {
+                    const float x = hh[2 * g + j] + hbb[g & 1][j];
+                    gx[j] = x;
+                    gs[j] = fminf(x * x, 50.0f);
+                    gq[j] = fmaf(gs[j], C2, C1);
+                } else if (k == 1) {
+                    gq[j] = fmaf(gs[j], gq[j], C0);
+                    gq[j] = __builtin_amdgcn_exp2f(gx[j] * gq[j]);
+                } else if (k == 2) {
+                    gq[j] = __builtin_amdgcn_rcpf(gq[j] + 1.0f);
+                } else {
+                    dot = fmaf(gx[j] * gq[j], hww[g & 1][j], dot);
+                }
+            }
+        };
+        act_reads(0);
+        // phase of hidden tile j (static): ring stage 144 + j, slot j % 3, accumulator h0 / h1 by parity
+#define HEAD_PH(j, SL, HC, HP)                                                                                          \
+        phase(144 + (j), SL{},                                                                                          \
+              [&](int gn) { act_reads(gn); if (gn < 8) { if ((j) > 0) hload((j) - 1, gn); } else hload((j), 0); },       \
+              [&](int i, u32x4 a, int g) { if (i == 0) mfma_v0(HC, a, a_operand(i, g)); else mfma_v(HC, a, a_operand(i, g)); }, \
+              [&](int g, int k) { if ((j) > 0) gelu_dot(HP, g, k); });                                                  \
+        mfma_done_v(HC);
+        HEAD_PH(0, S0, h0, h1) HEAD_PH(1, S1, h1, h0) HEAD_PH(2, S2, h0, h1) HEAD_PH(3, S0, h1, h0)
+        HEAD_PH(4, S1, h0, h1) HEAD_PH(5, S2, h1, h0) HEAD_PH(6, S0, h0, h1) HEAD_PH(7, S1, h1, h0)
+        HEAD_PH(8, S2, h0, h1) HEAD_PH(9, S0, h1, h0) HEAD_PH(10, S1, h0, h1) HEAD_PH(11, S2, h1, h0)
+        HEAD_PH(12, S0, h0, h1) HEAD_PH(13, S1, h1, h0) HEAD_PH(14, S2, h0, h1) HEAD_PH(15, S0, h1, h0)
+#undef HEAD_PH
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the pieces issued past the end of the stream
+        // gelu + dot of the last tile (15, in h1): group 0's operands were fetched by the last phase
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g < 7) hload(15, g + 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gelu_dot(h1, g, k);
+        }
+        dot = half_swap_sum(dot);
+        float yv = dot + p.hb2[hs][0];
+        if (p.hmean[hs]) yv = __fadd_rn(__fmul_rn(yv, p.hstd[hs][0]), p.hmean[hs][0]);  // de-tokenise (continuous.py:86-94)
+        if (valid && lh == 0) p.head_out[hs][gi] = yv;
     } else if (p.Hout) {
         int orow_h = rtok, sel = 0;
         if (p.out_mod > 0) {  // two row groups per out_mod rows: group s rows go to the s-th compact block, LN_B[s] applies
@@ -978,19 +1124,25 @@ bool launch_block_fused(const BlockP& p, hipStream_t st) {
         if (p.Hout || p.lnB_g[0] || !p.lnA_g || !p.bqkv || ((uintptr_t)p.QKVout & 3) || p.ldq < 3 * BD) return false;
         if (p.qkv_bytes == 0 || p.qkv_bytes >= 0x80000000u || (unsigned long long)p.M * p.ldq * 2 > p.qkv_bytes) return false;
     }
+    if (p.head_out[0]) {  // the two scalar output heads instead of their LayerNorm rows
+        if (p.Hout || p.QKVout || p.Xout || !p.head_out[1] || !p.lnA_g || !p.lnB_g[0] || !p.lnB_g[1] || p.out_mod <= 0 || (p.M & 1)) return false;
+        for (int s = 0; s < 2; ++s)
+            if (!p.hb1[s] || !p.hw2[s] || !p.hb2[s] || ((uintptr_t)p.hb1[s] & 15) || ((uintptr_t)p.hw2[s] & 15) || (p.hmean[s] && !p.hstd[s])) return false;
+    }
     const dim3 grid((p.M + 127) / 128), block(256);
 #ifdef M3PC_LAB  // timing experiments (tools/block_bench.py): the lab build only
-    if (p.variant == 1) hipLaunchKernelGGL((block_fused_kernel<1, false>), grid, block, 0, st, p);
-    else if (p.variant == 2) hipLaunchKernelGGL((block_fused_kernel<2, false>), grid, block, 0, st, p);
-    else if (p.variant == 3) hipLaunchKernelGGL((block_fused_kernel<3, false>), grid, block, 0, st, p);
-    else if (p.variant == 4) hipLaunchKernelGGL((block_fused_kernel<4, false>), grid, block, 0, st, p);
-    else if (p.variant == 5) hipLaunchKernelGGL((block_fused_kernel<5, false>), grid, block, 0, st, p);
-    else if (p.variant == 6) hipLaunchKernelGGL((block_fused_kernel<6, false>), grid, block, 0, st, p);
-    else if (p.variant == 7) hipLaunchKernelGGL((block_fused_kernel<7, false>), grid, block, 0, st, p);
+    if (p.variant == 1) hipLaunchKernelGGL((block_fused_kernel<1, 0>), grid, block, 0, st, p);
+    else if (p.variant == 2) hipLaunchKernelGGL((block_fused_kernel<2, 0>), grid, block, 0, st, p);
+    else if (p.variant == 3) hipLaunchKernelGGL((block_fused_kernel<3, 0>), grid, block, 0, st, p);
+    else if (p.variant == 4) hipLaunchKernelGGL((block_fused_kernel<4, 0>), grid, block, 0, st, p);
+    else if (p.variant == 5) hipLaunchKernelGGL((block_fused_kernel<5, 0>), grid, block, 0, st, p);
+    else if (p.variant == 6) hipLaunchKernelGGL((block_fused_kernel<6, 0>), grid, block, 0, st, p);
+    else if (p.variant == 7) hipLaunchKernelGGL((block_fused_kernel<7, 0>), grid, block, 0, st, p);
     else
 #endif
-    if (p.QKVout) hipLaunchKernelGGL((block_fused_kernel<0, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((block_fused_kernel<0, false>), grid, block, 0, st, p);
+    if (p.QKVout) hipLaunchKernelGGL((block_fused_kernel<0, 1>), grid, block, 0, st, p);
+    else if (p.head_out[0]) hipLaunchKernelGGL((block_fused_kernel<0, 2>), dim3(2 * ((p.M / 2 + 127) / 128)), block, 0, st, p);
+    else hipLaunchKernelGGL((block_fused_kernel<0, 0>), grid, block, 0, st, p);
     return true;
 }
 

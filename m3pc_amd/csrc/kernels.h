@@ -113,6 +113,15 @@ struct BlockP {
     int ldq;                // stream then carries that layer's in_proj fragments behind the layer's own (launch_pack_block_qkv)
     unsigned qkv_bytes;     // size of the QKVout buffer from its base (< 2 GiB: stores go through a buffer resource)
     const float* bqkv;      // in_proj_bias of the next layer (3 d)
+    // optional, instead of Hout (out_mod / out_grp and lnB as for Hout): the two row groups' scalar output heads,
+    //     head_out[s][i] = detok(w2_s . gelu(W1_s LN_B[s](LN_A(X'')) + b1_s) + b2_s)   for the i-th row of group s;
+    // W1_s rides in the stream behind the layer's own fragments (launch_pack_block_heads)
+    float* head_out[2];
+    const float* hb1[2];    // Linear(512,512) bias (d)
+    const float* hw2[2];    // Linear(512,1) weight row (d)
+    const float* hb2[2];    // its bias (1)
+    const float* hmean[2];  // tokenizer mean / std of the key (1 each), or null: no de-tokenisation
+    const float* hstd[2];
     int variant;            // 0 = product kernel; 1, 2: timing experiments (tools/block_bench.py)
     long long* stamps;      // optional (4 waves, 16) shader-clock phase stamps of workgroup stamp_block
     int stamp_block;
@@ -120,7 +129,8 @@ struct BlockP {
 bool block_fused_supported(int d, int ff);
 size_t block_stream_bytes();
 void launch_pack_block_stream(const bf16_t* Wo, const bf16_t* W1, const bf16_t* W2, bf16_t* out, hipStream_t st);
-void launch_pack_block_qkv(const bf16_t* Wqkv_next, bf16_t* out, hipStream_t st);  // behind them: the next layer's in_proj
+void launch_pack_block_qkv(const bf16_t* Wqkv_next, bf16_t* out, hipStream_t st);
+void launch_pack_block_heads(const bf16_t* Wh0, const bf16_t* Wh1, bf16_t* out, hipStream_t st);  // or: the two scalar heads' Linear(512,512)  // behind them: the next layer's in_proj
 bool launch_block_fused(const BlockP& p, hipStream_t st);  // false: arguments not covered (caller takes the unfused path)
 
 // Decoder input of the un-masked tokens as one launch (block_fused.hip: kv_fused_kernel; d = 512, bf16 operands):

@@ -1350,19 +1350,38 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         }
         b.out_mod = nq;
         b.out_grp = hh;
-        b.Hout = (bf16_t*)h->Hn;
-        b.ldh = d;
+        // both scored keys have scalar heads (rtg_guiding: rewards, returns): the heads run inside the tail, on workgroups
+        // that each own rows of one key; else the heads' LayerNorm rows go to Hn and the heads are launches of their own
+        static const bool no_head_fused = M3PC_ENV("M3PC_NO_HEAD_FUSED") != nullptr;  // A/B switch
+        const bool fuse_heads = !no_head_fused && q.qkeys[0] == M3PC_REWARDS && q.qkeys[1] == M3PC_RETURNS &&
+                                h->feat[M3PC_REWARDS] == 1 && h->feat[M3PC_RETURNS] == 1;
+        if (fuse_heads) {
+            for (int s = 0; s < 2; ++s) {
+                const std::string hp = std::string("output_head_dict.") + KEYN[q.qkeys[s]];
+                b.head_out[s] = h->pred[s];
+                b.hb1[s] = W(h, hp + ".1.bias").f;
+                b.hw2[s] = W(h, hp + ".3.weight").f;
+                b.hb2[s] = W(h, hp + ".3.bias").f;
+                if (h->tok_norm[q.qkeys[s]]) {
+                    b.hmean[s] = h->tok_mean[q.qkeys[s]];
+                    b.hstd[s] = h->tok_std[q.qkeys[s]];
+                }
+            }
+        } else {
+            b.Hout = (bf16_t*)h->Hn;
+            b.ldh = d;
+        }
         bool ok;
         {
-            GemmTimer t(h, st, 2.0 * n * nq * ((double)d * d + 2.0 * d * h->ff), dt, 1);
+            GemmTimer t(h, st, 2.0 * n * nq * ((double)d * d + 2.0 * d * h->ff + (fuse_heads ? (double)d * d : 0.0)), dt, 1);
             ok = launch_block_fused(b, st);
         }
-        if (ok) {
+        if (ok && !fuse_heads) {
             for (int s = 0; s < 2; ++s)
                 CHK(run_head_tail(h, q.qkeys[s], (const char*)h->Hn + (size_t)s * n * hh * d * es, n * hh, h->pred[s],
                                   h->feat[q.qkeys[s]], true, dt, st));
-            tail_done = true;
         }
+        tail_done = ok;
     }
     if (!tail_done) {
     {
@@ -1715,6 +1734,16 @@ int m3pc_load_weights(m3pc_handle* h, const m3pc_named_tensor* tensors, int n, v
         for (int i = 0; i < h->dm.n_enc_layer; ++i)
             CHK(pack("encoder.layers." + std::to_string(i), i + 1 < h->dm.n_enc_layer ? "encoder.layers." + std::to_string(i + 1) : ""));
         for (int i = 0; i < h->dm.n_dec_layer; ++i) CHK(pack("decoder.layers." + std::to_string(i), ""));
+        // behind the decoder layer's own fragments: the first Linear of the two scalar output heads rtg_guiding scores
+        // (rewards, returns: learner.py:294-305), consumed by the fused tail's head phases
+        if (h->dm.n_dec_layer >= 1 && h->wstream.count("decoder.layers.0")) {
+            const std::string w0 = std::string("output_head_dict.") + KEYN[M3PC_REWARDS] + ".1.weight";
+            const std::string w1 = std::string("output_head_dict.") + KEYN[M3PC_RETURNS] + ".1.weight";
+            if (is_dirty(w0) || is_dirty(w1)) {
+                launch_pack_block_heads(W(h, w0).b, W(h, w1).b, h->wstream["decoder.layers.0"], st);
+                ++ls[1];
+            }
+        }
         if (h->dm.n_dec_layer >= 1)
             for (int k = 0; k < 4; ++k) {
                 const std::string we = std::string("decoder_embed_dict.") + KEYN[k] + ".weight";
@@ -2478,6 +2507,52 @@ int m3pc_debug_block_fused_qkv(const void* O, int M, const float* res, const voi
     b.stamps = stamps;
     if (!launch_block_fused(b, st)) return fail(M3PC_EINVAL, "block_fused (qkv): arguments not covered");
     return check_launch("debug_block_fused_qkv");
+}
+
+// the decoder form of the fused tail with the two scalar output heads inside: rows of group s = (r % out_mod) / out_grp;
+// out0 / out1 (M / 2) floats; Wh (2, 512, 512) bf16, hb1 / hw2 (2, 512), hb2 / hmean / hstd (2) floats (hmean null: no detok)
+int m3pc_debug_block_fused_heads(const void* O, int M, const float* rowtab, int rt_mod, const void* Wo, const void* W1, const void* W2,
+                                 const void* Wh, void* stream_buf, const float* bo, const float* b1, const float* b2, const float* ln2_g,
+                                 const float* ln2_b, const float* lnA_g, const float* lnA_b, const float* lnB_g0, const float* lnB_b0,
+                                 const float* lnB_g1, const float* lnB_b1, int out_mod, int out_grp, const float* hb1, const float* hw2,
+                                 const float* hb2, const float* hmean, const float* hstd, float* out0, float* out1, void* stream,
+                                 long long* stamps) {
+    hipStream_t st = (hipStream_t)stream;
+    launch_pack_block_stream((const bf16_t*)Wo, (const bf16_t*)W1, (const bf16_t*)W2, (bf16_t*)stream_buf, st);
+    launch_pack_block_heads((const bf16_t*)Wh, (const bf16_t*)Wh + 512 * 512, (bf16_t*)stream_buf, st);
+    BlockP b;
+    memset(&b, 0, sizeof(b));
+    b.O = (const bf16_t*)O;
+    b.ldo = 512;
+    b.M = M;
+    b.rowtab = rowtab;
+    b.rt_mod = rt_mod;
+    b.wstream = (const bf16_t*)stream_buf;
+    b.bo = bo;
+    b.b1 = b1;
+    b.b2 = b2;
+    b.ln2_g = ln2_g;
+    b.ln2_b = ln2_b;
+    b.lnA_g = lnA_g;
+    b.lnA_b = lnA_b;
+    b.lnB_g[0] = lnB_g0;
+    b.lnB_b[0] = lnB_b0;
+    b.lnB_g[1] = lnB_g1;
+    b.lnB_b[1] = lnB_b1;
+    b.out_mod = out_mod;
+    b.out_grp = out_grp;
+    b.head_out[0] = out0;
+    b.head_out[1] = out1;
+    for (int s = 0; s < 2; ++s) {
+        b.hb1[s] = hb1 + 512 * s;
+        b.hw2[s] = hw2 + 512 * s;
+        b.hb2[s] = hb2 + s;
+        b.hmean[s] = hmean ? hmean + s : nullptr;
+        b.hstd[s] = hstd ? hstd + s : nullptr;
+    }
+    b.stamps = stamps;
+    if (!launch_block_fused(b, st)) return fail(M3PC_EINVAL, "block_fused (heads): arguments not covered");
+    return check_launch("debug_block_fused_heads");
 }
 
 // kv_fused_kernel alone (tests/test_block_fused_gpu.py): n candidates of Le rows each in Z (n*Le, 512) bf16; group g holds

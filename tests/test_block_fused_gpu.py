@@ -172,6 +172,54 @@ def test_block_fused_with_next_qkv(M):
         assert torch.equal(X3, Xout[lo:lo + n]) and torch.equal(Q3, QKV[lo:lo + n])
 
 
+@pytest.mark.parametrize("n,hh,detok", [(512, 16, True), (333, 5, False), (64, 32, True)])
+def test_block_fused_with_scalar_output_heads(n, hh, detok):
+    """decoder form with the two scalar output heads inside the tail (rtg_guiding's rewards / returns heads, mtm_model.py:428-433):
+    head_s(row) = w2_s . gelu(W1_s LN_s(decoder.norm(X'')) + b1_s) + b2_s, de-tokenised; rows of group s = (r % 2h) // h"""
+    lib = lab_library()
+    dev = torch.device("cuda")
+    nq = 2 * hh
+    M = n * nq
+    W, p, lnB, g = make_params(4000 + n)
+    rn = lambda *sh: torch.randn(*sh, device=dev, generator=g)
+    Wh = (rn(2, D, D) / D ** 0.5).to(torch.bfloat16)
+    hb1, hw2, hb2 = 0.1 * rn(2, D), rn(2, D) / D ** 0.5, 0.1 * rn(2)
+    hmean, hstd = rn(2), rn(2).abs() + 0.5
+    O = rn(M, D).to(torch.bfloat16)
+    tab = rn(nq, D)
+    nbytes = lib.m3pc_debug_block_stream_bytes
+    nbytes.restype = C.c_longlong
+    sb = torch.empty(int(nbytes()), dtype=torch.uint8, device=dev)
+    out = [torch.full((M // 2 + 1,), float("nan"), device=dev) for _ in range(2)]  # (one guard element behind the end)
+    fn = lib.m3pc_debug_block_fused_heads
+    fn.restype = C.c_int
+    vp, i = C.c_void_p, C.c_int
+    fn.argtypes = [vp, i, vp, i] + [vp] * 16 + [i, i] + [vp] * 9
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    rc = fn(O.data_ptr(), M, tab.data_ptr(), nq, W["o"].data_ptr(), W["1"].data_ptr(), W["2"].data_ptr(), Wh.data_ptr(), sb.data_ptr(),
+            p["bo"].data_ptr(), p["b1"].data_ptr(), p["b2"].data_ptr(), p["g2"].data_ptr(), p["be2"].data_ptr(), p["gA"].data_ptr(),
+            p["bA"].data_ptr(), lnB[0].data_ptr(), lnB[1].data_ptr(), lnB[2].data_ptr(), lnB[3].data_ptr(), nq, hh, hb1.data_ptr(),
+            hw2.data_ptr(), hb2.data_ptr(), ptr(hmean if detok else None), ptr(hstd if detok else None), out[0].data_ptr(),
+            out[1].data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream), None)
+    assert rc == 0, lib.m3pc_last_error()
+    torch.cuda.synchronize()
+    r = torch.arange(M, device=dev)
+    sel = (r % nq) // hh
+    _, y = reference(O, tab[r % nq], W, p, lnB, sel)  # LN_head(decoder.norm(X'')) per row, fp32
+    yb = y.to(torch.bfloat16).float()
+    for s_ in range(2):
+        rows = r[sel == s_]  # in order: the i-th row of group s
+        hid = F.gelu(yb[rows] @ Wh[s_].float().T + hb1[s_])
+        want = hid @ hw2[s_] + hb2[s_]
+        if detok:
+            want = want * hstd[s_] + hmean[s_]
+        got = out[s_][: M // 2]
+        assert torch.isnan(out[s_][M // 2]), "element past the end written"
+        assert torch.isfinite(got).all()
+        err = float((got - want).abs().max())
+        assert err <= 3e-2 * max(1.0, float(want.abs().max())), (s_, err)
+
+
 # ------------------------------------------------------------------------------------------------ decoder input (kv_fused_kernel)
 def _kv_call(lib, Z, n, Le, kept, off, We, Wkv, rowtab, g, b, bkv, stamps=None):
     fn = lib.m3pc_debug_kv_fused
