@@ -334,8 +334,9 @@ def main():
     if t_launches:   # the dominant kernel: the fused layer tail (block_fused.hip)
         achieved, dom_l, dom_ms, dom_fl = t_flops / (t_ms * 1e-3) / 1e12, t_launches, t_ms, t_flops
         al_l, al_ms, al_fl = at_launches, at_ms, at_flops
-        kname = ("m3pc::block_fused_kernel (layer tail: out-proj + residual + LayerNorm + Linear/GELU/Linear + residual + LayerNorm, "
-                 "one launch per layer and candidate half)")
+        kname = ("m3pc::block_fused_kernel (layer tail: out-proj + residual + LayerNorm + Linear/GELU/Linear + residual + LayerNorm "
+                 "[+ the next encoder layer's Q|K|V projection | + the two scalar output heads], one launch per layer and "
+                 "candidate half)")
     else:            # fp32 mode / shapes the fused kernel does not cover: the GEMM class
         achieved, dom_l, dom_ms, dom_fl = cls, launches, gemm_ms, gemm_flops
         al_l, al_ms, al_fl = a_launches, a_ms, a_flops
