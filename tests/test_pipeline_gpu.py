@@ -144,3 +144,34 @@ def test_weight_update_between_pipelined_steps_is_ordered():
     c = pr.action_sample(wins[2], plan=True, eval=True, rtg=3.0)
     assert torch.equal(b, c) and a.shape == b.shape
     pr.handle.close()
+
+
+def test_deferred_join_orders_other_users_of_the_candidate_workspace():
+    """C-ABI contract of M3PC_PLAN_DEFER_JOIN: the second candidate half stays un-joined on the library's stream until
+    m3pc_candidate_join -- but every other call into the candidate workspace (here: m3pc_forward right behind the pass, on the same
+    stream, nothing joined) is ordered behind it by the library, and the joined scores equal those of an ordinary pass."""
+    dims = synth.Dims(11, 3, 32)
+    N, H = 1024, 16
+    p = _planner(dims, N, H, "rtg_guiding", "bf16", max_batch=4)
+    hd = p.handle
+    hist = synth.make_history(dims, 0)
+    hist["path_length"] = 500
+    s, a, r, h, rtg = p.assemble_window(hist, rtg=3.0)
+    eps = synth.make_eps(N, dims, 1).cuda().reshape(N, -1, 3)
+    from m3pc_amd.masks import create_rcbc_mask, mask_rows
+    toks = [hd.tokenize(capi.STATES, torch.stack([s] * 4)), torch.stack([a] * 4), hd.tokenize(capi.REWARDS, torch.stack([r] * 4)),
+            hd.tokenize(capi.RETURNS, torch.full((4, 32, 1), 3.0, dtype=torch.float64, device="cuda"))]
+    masks = mask_rows(create_rcbc_mask(32, "cpu", 16))
+    want_fwd = [t.clone() for t in hd.forward(toks, masks, want=("actions",), precision=capi.PREC_BF16)["actions"]]
+    hd.policy_pass(capi.MODE_RTG, s, a, r, h, rtg, slot=1)
+    ref = hd.candidate_pass(capi.MODE_RTG, s, a, r, eps, h, 0.6, 0.99, N, precision=capi.PREC_BF16, slot=1)
+    want_er = ref["expect_return"].clone()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        res = hd.candidate_pass(capi.MODE_RTG, s, a, r, eps, h, 0.6, 0.99, N, precision=capi.PREC_BF16, slot=1, defer_join=True)
+        got_fwd = hd.forward(toks, masks, want=("actions",), precision=capi.PREC_BF16)["actions"]  # (same workspace, no join)
+        hd.candidate_join(1)
+        torch.cuda.synchronize()
+        assert torch.equal(res["expect_return"], want_er)
+        assert torch.equal(got_fwd[0], want_fwd[0]) and torch.equal(got_fwd[1], want_fwd[1])
+    hd.close()
