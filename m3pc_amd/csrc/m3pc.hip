@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>
@@ -1572,6 +1573,8 @@ int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out) {
     // streams than that two of them share a queue and stop overlapping (a second planner must not cost the first its halves)
     {
         static std::map<int, hipStream_t> shared_aux;
+        static std::mutex shared_aux_mutex;  // (handles of different threads may be created at the same time)
+        std::lock_guard<std::mutex> lock(shared_aux_mutex);
         hipStream_t& sa = shared_aux[device];
         if (!sa) HIPCHK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
         h->aux = sa;

@@ -896,30 +896,76 @@ class HipPlanner:
                         f32 = self.handle.score_actions(smode, s[0], a[0], r[0], acts[0, cid], None, h, lmbda, float(cfg.discount))
                         d = er[0, cid] - f32
                         self._delta = max(1.5 * float((d - d.median()).abs().max()), 1e-6 * float(f32.abs().max()), 1e-30)
-                    kmax, kmin = max(min(self.rescore_max, N - 1), 1), max(min(self.rescore_min, N), 1)
-                    tops, stats = zip(*[self.handle.topk_window(er[w], kmax, min(kmin, kmax), 2.0 * self._delta) for w in range(Eg)])
-                    stats_h = torch.stack(stats).cpu()  # the one host read of the group
-                    counts = [int(stats_h[w, 0]) for w in range(Eg)]
+                    # The certified re-score of HipPlanner.__init__'s docstring, for all windows of the group at once: the kmin best
+                    # candidates of every window in ONE fp32 pass, merge + select enqueued for every window, THEN one host read
+                    # of the certificates; windows that ask for more candidates get a second pass of their own.
+                    kmax = max(min(self.rescore_max, N - 1 if N > 1 else 1), 1)
+                    kmin = max(min(self.rescore_min, N, kmax), 1)
+                    tops, btops = [], []
+                    for w in range(Eg):
+                        bt = torch.empty((kmax + 1,), dtype=torch.float32, device=self.device)
+                        tops.append(self.handle.topk_window(er[w], kmax, kmin, 0.0, top_scores=bt)[0])
+                        btops.append(bt)
+                    counts = [kmin] * Eg
                 else:
                     k = min(self.rescore_topk, N)
                     tops = [torch.topk(er[w], k).indices.to(torch.int32) for w in range(Eg)]
+                    btops = [er[w][tops[w].long()].contiguous() for w in range(Eg)]
                     counts = [k] * Eg
+                delta = float(self._delta) if self.rescore == "bound" else 0.0
                 pick = torch.cat([tops[w][: counts[w]].long() for w in range(Eg)])
-                wsel = torch.cat([torch.full((counts[w],), w, dtype=torch.int32, device=self.device) for w in range(Eg)])
+                wsel = torch.arange(Eg, dtype=torch.int32, device=self.device).repeat_interleave(counts[0])
                 f32 = self.handle.score_actions(smode, s, a, r, acts[wsel.long(), pick], wsel, h, lmbda, float(cfg.discount))
-                off = 0
+                ftops, mstats = [], []
                 for w in range(Eg):  # fp32 scores for the set, shift-corrected bf16 scores for the rest (m3pc_rescore_merge)
-                    ix = tops[w][: counts[w]].contiguous()
-                    merged[w], _ = self.handle.rescore_merge(er[w], ix, counts[w], er[w][ix.long()].contiguous(),
-                                                             f32[off : off + counts[w]].contiguous())
-                    off += counts[w]
+                    ftops.append(f32[w * counts[w] : (w + 1) * counts[w]].contiguous())
+                    merged[w], st_w = self.handle.rescore_merge(er[w], tops[w], counts[w], btops[w], ftops[w], delta=delta)
+                    mstats.append(st_w)
+            expos = [torch.empty((N,), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
+                     for _ in range(Eg)]
+            sels = [self.handle.select(merged[j], acts[j, :, 0], float(cfg.temperature), expos[j]) for j in range(Eg)]
+            if self.rescore == "bound":
+                stats_h = torch.stack(mstats).cpu()  # the one host read of the group: [shift, deviation, need, margin] per window
+                for w in range(Eg):
+                    n_done = counts[w]
+                    while True:
+                        dev_w, need = float(stats_h[w, 1]), int(stats_h[w, 2])
+                        grown = self._delta_fixed is None and 1.5 * dev_w > delta
+                        if grown:  # this window saw a larger deviation than the bound: raise it (for everybody from here on)
+                            delta = self._delta = 1.5 * dev_w
+                            self.delta_grown += 1
+                        if need <= n_done and not grown:
+                            break
+                        if need > n_done:
+                            cnt = min(need, N, 1024)
+                            if cnt > kmax:  # beyond the list: the `need` best candidates by bf16 score, re-scored in chunks
+                                if not self._warned_saturated:
+                                    self._warned_saturated = True
+                                    warnings.warn(f"m3pc_amd: {need} candidates may still hold the fp32 arg-max (delta={delta:.3g}); "
+                                                  "re-scoring the whole window set in fp32 (slow path)")
+                                vals, idx = torch.topk(er[w], cnt)
+                                tops[w], btops[w] = idx.to(torch.int32).contiguous(), vals.contiguous()
+                                ftops[w], n_done = torch.empty((0,), dtype=torch.float32, device=self.device), 0
+                            cap = max(self.handle.max_rescore, 1)
+                            parts = [ftops[w]]
+                            for c0 in range(n_done, cnt, cap):
+                                ix = tops[w][c0 : min(cnt, c0 + cap)].long()
+                                parts.append(self.handle.score_actions(smode, s[w], a[w], r[w], acts[w, ix], None, h, lmbda,
+                                                                       float(cfg.discount)))
+                            ftops[w], n_done = torch.cat(parts).contiguous(), cnt
+                        merged[w], st_w = self.handle.rescore_merge(er[w], tops[w], n_done, btops[w], ftops[w], delta=delta)
+                        sels[w] = self.handle.select(merged[w], acts[w, :, 0], float(cfg.temperature), expos[w])
+                        stats_h[w] = st_w.cpu()
+                        if n_done >= min(N, 1024):
+                            break
+                    counts[w] = n_done
             for j, i in enumerate(ids):
-                expo = torch.empty((N,), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
-                p, ev, am, si, sa = self.handle.select(merged[j], acts[j, :, 0], float(cfg.temperature), expo)
+                p, ev, am, si, sa = sels[j]
                 out[i] = ev if eval else sa[0]
                 info[i] = dict(expect_return=merged[j], argmax=am, sample_idx=si, eval_action=ev, sample_action=sa, horizon=h,
-                               n_rescored=None if stats_h is None else int(stats_h[j, 0]),
-                               min_margin_outside=None if stats_h is None else float(stats_h[j, 1]))
+                               n_rescored=None if stats_h is None else counts[j],
+                               min_margin_outside=None if stats_h is None else float(stats_h[j, 3]),
+                               delta=self._delta)
         self.last = dict(windows=info, delta=self._delta)
         return out
 
