@@ -27,8 +27,8 @@ Multi-GPU (`--shard`):
                   `--strong` (N = 1024 in total; `replicated_ms` tells what every rank repeats).
   `--config c4`   BASELINE configs[3]: halfcheetah shapes, rtg_guiding, N=16384, H=32, T=64, candidate-sharded over the
                   ranks (strong scaling: 16384 candidates in total), value = plan steps of 16384 candidates per second.
-With --shard env at N > 1 GPUs the line also carries `c4` (the candidate-sharded config 4 through RCCL on the same ranks,
-a few steps), so that the collective path is measured whenever more than one GPU is.
+With --shard env at N > 1 GPUs and `--with-c4` the line also carries `c4` (the candidate-sharded config 4 through RCCL on the
+same ranks, a few steps).
 
 Prints ONE JSON line on rank 0.
 """
@@ -170,6 +170,9 @@ def main():
     ap.add_argument("--shard", default="env", choices=["env", "candidates"], help="what the ranks of a multi-GPU run divide")
     ap.add_argument("--strong", action="store_true", help="--shard candidates: keep the global candidate count fixed")
     ap.add_argument("--config", default="c2", choices=["c2", "c4"], help="c4: BASELINE configs[3] (halfcheetah N=16384 H=32 T=64, candidate-sharded)")
+    ap.add_argument("--with-c4", action="store_true",
+                    help="--shard env at N > 1 GPUs: also run BASELINE configs[3] candidate-sharded through RCCL on the same ranks (a "
+                         "few steps; off by default: the collective path has run on one GPU only, a hang there must not cost the run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alone-pass", action="store_true",
                     help="skip the extra instrumented pass with the candidate halves serialised (roofline.alone); "
@@ -365,7 +368,7 @@ def main():
                 "step_hbm_frac_alg": round(alg_bytes(n_local, T, S, A) / step_s / 1e9 / HBM_PEAK_GBS, 5)}
 
     c4 = None
-    if world > 1 and not shard_cand and args.config == "c2" and not args.no_extras:
+    if world > 1 and not shard_cand and args.config == "c2" and args.with_c4:
         c4 = c4_sharded(rank, local_rank, world)
 
     if rank == 0:
