@@ -74,6 +74,7 @@ constexpr int QKV_FR = 3 * FR_OUT;                // the next layer's Q|K|V proj
 constexpr int NRS_QKV = NRS + QKV_FR / RS_FR;     // 192 stages
 constexpr int HEAD_FR = FR_OUT;                   // one output head's Linear(512,512): 16 hidden tiles x 32 k-steps
 constexpr int NRS_HEAD = NRS + HEAD_FR / RS_FR;   // 160 stages (the stream holds both heads: 144 .. 175)
+constexpr int SPLIT_N = 4;                        // TAIL == 3: workgroups per 128-row tile
 constexpr int NSLOT = 3;
 constexpr int ACT_LDS = 8;                       // LayerNorm-2 fragments of k-steps 24..31 live in LDS: 8 KiB per wave
 constexpr int ACT_OFF = NSLOT * RS_B;
@@ -202,8 +203,14 @@ __device__ __forceinline__ void acc_touch(f32x16 (&c)[16]) {
 // TAIL: what follows the FFN in the stream -- 1: the next layer's in_proj rows (p.QKVout), 2: the two scalar output heads (p.head_out)
 template <int DBG, int TAIL>
 __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
-    constexpr bool QKV = TAIL == 1, HEADS = TAIL == 2;
-    constexpr int NST = QKV ? NRS_QKV : HEADS ? NRS_HEAD : NRS;  // ring stages a workgroup consumes
+    constexpr bool QKV = TAIL == 1, HEADS = TAIL == 2, SPLIT = TAIL == 3;
+    // SPLIT (few tiles: a launch would leave most CUs idle for a whole tile): blockIdx.y = which quarter of the FFN's hidden
+    // chunks this workgroup takes; every quarter repeats the out-proj and LayerNorm-2 (11 % of a tile), adds its share of
+    // FFN2 to zero (quarter 0: to X' + b2) and stores the fp32 partial to its slab; block_split_reduce sums the slabs in order
+    constexpr int NCHL = SPLIT ? NCH / SPLIT_N : NCH;  // hidden chunks of this workgroup
+    static_assert((NCHL - 2) % 3 == 0, "the chunk loop runs in rounds of three behind the first two");
+    constexpr int NST = QKV ? NRS_QKV : HEADS ? NRS_HEAD : SPLIT ? FR_OUT / RS_FR + 4 * NCHL : NRS;  // ring stages a workgroup consumes
+    const int cbase = SPLIT ? (int)blockIdx.y * NCHL : 0;  // first hidden chunk
     __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     (void)pt;
     stamps[0] = __builtin_readcyclecounter();
 
-    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream, 0, (unsigned)((HEADS ? NRS + 2 * HEAD_FR / RS_FR : NST) * RS_B), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wstream, 0, (unsigned)((HEADS ? NRS + 2 * HEAD_FR / RS_FR : SPLIT ? NRS : NST) * RS_B), 0x00020000);
     (void)w_rs;
     // piece pc (0..7) of stage st: fragment wu + 4 pc of that stage -> the same position of ring slot `slot` = st % 3
     auto piece = [&](int st, int slot, int pc) {
@@ -232,6 +239,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
         if (DBG == 1) return;
         int sw = st >= NST ? st - NST : st;  // past the end: the head of the stream again (never read)
         if (HEADS && sw >= NRS) sw += hs * (HEAD_FR / RS_FR);  // (this workgroup's head)
+        if (SPLIT && sw >= FR_OUT / RS_FR) sw += 4 * cbase;    // (this workgroup's hidden chunks)
         const int fo = (wu + 4 * pc) * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lptr_t)(smem + slot * RS_B + fo), 16, lane16, sw * RS_B + fo, 0, 0);
 #endif
@@ -478,8 +486,16 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     u32x4 R2[2];  // the LDS-resident LayerNorm-2 fragment of an FFN1 group, by group parity
     auto a_operand = [&](int i, int g) -> u32x4 { return i % 4 < 3 ? act[a_kstep(i)] : R2[g & 1]; };
     auto act_reads = [&](int gn) { R2[gn & 1] = afrag(gn & 7); };  // (gn = 8: group 0 of the next FFN1 phase)
-    bias_init(h0, 0, 0);
-    bias_init(h1, 0, 1);
+    if (SPLIT && blockIdx.y != 0) {  // the other quarters add their share of FFN2 to zero (X' stays with quarter 0)
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[jn][e] = 0.f;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    bias_init(h0, cbase, 0);
+    bias_init(h1, cbase, 1);
     act_reads(0);
     // one chunk = four phases A0 A1 B1 B2 starting in ring slot SL0 (the slot pattern repeats every three chunks)
     auto chunk = [&](int c, auto s0_c) {
@@ -488,7 +504,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
         using P1 = std::integral_constant<int, (SL0 + 1) % 3>;
         using P2 = std::integral_constant<int, (SL0 + 2) % 3>;
         const int ph = 16 + 4 * c;
-        const int cn = c + 1 < NCH ? c + 1 : c;
+        const int cn = (c + 1 < NCHL ? c + 1 : c) + cbase;
         if (DBG == 3) pt = __builtin_readcyclecounter();
         // A0: hidden tile 0
         phase(ph, P0{}, act_reads, [&](int i, u32x4 a, int g) { mfma_v(h0, a, a_operand(i, g)); }, no_valu);
@@ -516,7 +532,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     // phase 16 = slot 1; a chunk advances the slot by 4 = 1 (mod 3)
     chunk(0, S1{});
     chunk(1, S2{});
-    for (int c = 2; c < NCH; c += 3) {  // chunks 2..31 = ten rounds of three
+    for (int c = 2; c < NCHL; c += 3) {  // chunks 2..31 = ten rounds of three
         chunk(c, S0{});
         chunk(c + 1, S1{});
         chunk(c + 2, S2{});
@@ -526,19 +542,21 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     stamps[4] = __builtin_readcyclecounter();
 
     // ---- epilogue: X'' = acc + b2 (fp32, optional) and the LayerNorm(s) of it (bf16)
+    if (!SPLIT || blockIdx.y == 0) {
 #pragma unroll
-    for (int jn = 0; jn < NT; ++jn) {
+        for (int jn = 0; jn < NT; ++jn) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_B2 + 32 * jn + 8 * q);
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_B2 + 32 * jn + 8 * q);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[jn][4 * q + i] += b[i];
+                for (int i = 0; i < 4; ++i) acc[jn][4 * q + i] += b[i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
     acc_touch(acc);
-    if (p.Xout && valid) {
-        float* xrow = p.Xout + (size_t)rtok * p.ldx;
+    if (p.Xout && valid) {  // (SPLIT: this quarter's slab of M rows)
+        float* xrow = p.Xout + ((SPLIT ? (size_t)blockIdx.y * p.M : 0) + (size_t)rtok) * p.ldx;
 #pragma unroll
         for (int jn = 0; jn < NT; ++jn)
 #pragma unroll
@@ -1096,6 +1114,70 @@ __global__ __launch_bounds__(256, 1) void kv_fused_kernel(KvFusedP p) {
 
 }  // namespace
 
+// Sum of the SPLIT_N partial slabs of block_fused_kernel<0, 3> in slab order, and the LayerNorm(s) that consume the block output:
+//   x = slab_0 + slab_1 + slab_2 + slab_3 -> Xout (fp32, optional);  y = LN_B?(LN_A(x)) -> Hout (bf16, optional; row groups as BlockP)
+// One wave per row (d = 512: 8 values per lane).
+__global__ __launch_bounds__(256) void block_split_reduce_kernel(SplitReduceP p) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.M) return;
+    f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
+#pragma unroll
+    for (int s = 0; s < SPLIT_N; ++s) {
+        const float* row = p.slabs + ((size_t)s * p.M + r) * BD + 8 * lane;
+        const f32x4 a = *(const f32x4*)row, b = *(const f32x4*)(row + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x0[i] += a[i];
+            x1[i] += b[i];
+        }
+    }
+    if (p.Xout) {
+        float* xr = p.Xout + (size_t)r * p.ldx + 8 * lane;
+        *(f32x4*)xr = x0;
+        *(f32x4*)(xr + 4) = x1;
+    }
+    if (!p.Hout) return;
+    float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    auto wave_sum = [](float t) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        return t;
+    };
+    auto ln = [&](const float* g, const float* b) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s1 += v[i];
+        const float mean = wave_sum(s1) * (1.0f / BD);
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s2 = fmaf(v[i] - mean, v[i] - mean, s2);
+        const float rstd = rsqrtf(wave_sum(s2) * (1.0f / BD) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaf((v[i] - mean) * rstd, g[8 * lane + i], b[8 * lane + i]);
+    };
+    ln(p.lnA_g, p.lnA_b);
+    int orow = r;
+    if (p.lnB_g[0]) {
+        int sel = 0;
+        if (p.out_mod > 0) {
+            const int w = r % p.out_mod;
+            sel = w / p.out_grp;
+            orow = sel * (p.M / p.out_mod) * p.out_grp + (r / p.out_mod) * p.out_grp + w % p.out_grp;
+        }
+        ln(p.lnB_g[sel], p.lnB_b[sel]);
+    }
+    bf16x8 w;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = (bf16_t)v[i];
+    *(bf16x8*)(p.Hout + (size_t)orow * p.ldh + 8 * lane) = w;
+}
+void launch_block_split_reduce(const SplitReduceP& p, hipStream_t st) {
+    if (p.M <= 0) return;
+    hipLaunchKernelGGL(block_split_reduce_kernel, dim3((p.M + 3) / 4), dim3(256), 0, st, p);
+}
+int block_split_n() { return SPLIT_N; }
+
 bool launch_kv_fused(const KvFusedP& p, hipStream_t st) {
     if (((uintptr_t)p.Z & 15) || (p.ldz % 8) || ((uintptr_t)p.KV & 7) || (p.ldkv % 4)) return false;
     if (p.kv_bytes == 0 || p.kv_bytes >= 0x80000000u) return false;
@@ -1129,6 +1211,9 @@ bool launch_block_fused(const BlockP& p, hipStream_t st) {
         for (int s = 0; s < 2; ++s)
             if (!p.hb1[s] || !p.hw2[s] || !p.hb2[s] || ((uintptr_t)p.hb1[s] & 15) || ((uintptr_t)p.hw2[s] & 15) || (p.hmean[s] && !p.hstd[s])) return false;
     }
+    if (p.split) {  // four workgroups per tile, fp32 partials to four slabs of M rows behind Xout (block_split_reduce sums them)
+        if (p.Hout || p.QKVout || p.head_out[0] || !p.Xout || p.Xout == p.res || p.res_L > 0) return false;
+    }
     const dim3 grid((p.M + 127) / 128), block(256);
 #ifdef M3PC_LAB  // timing experiments (tools/block_bench.py): the lab build only
     if (p.variant == 1) hipLaunchKernelGGL((block_fused_kernel<1, 0>), grid, block, 0, st, p);
@@ -1140,7 +1225,8 @@ bool launch_block_fused(const BlockP& p, hipStream_t st) {
     else if (p.variant == 7) hipLaunchKernelGGL((block_fused_kernel<7, 0>), grid, block, 0, st, p);
     else
 #endif
-    if (p.QKVout) hipLaunchKernelGGL((block_fused_kernel<0, 1>), grid, block, 0, st, p);
+    if (p.split) hipLaunchKernelGGL((block_fused_kernel<0, 3>), dim3((p.M + 127) / 128, SPLIT_N), block, 0, st, p);
+    else if (p.QKVout) hipLaunchKernelGGL((block_fused_kernel<0, 1>), grid, block, 0, st, p);
     else if (p.head_out[0]) hipLaunchKernelGGL((block_fused_kernel<0, 2>), dim3(2 * ((p.M / 2 + 127) / 128)), block, 0, st, p);
     else hipLaunchKernelGGL((block_fused_kernel<0, 0>), grid, block, 0, st, p);
     return true;

@@ -122,6 +122,8 @@ struct BlockP {
     const float* hb2[2];    // its bias (1)
     const float* hmean[2];  // tokenizer mean / std of the key (1 each), or null: no de-tokenisation
     const float* hstd[2];
+    int split;              // 1: four workgroups per 128-row tile, each a quarter of the FFN's hidden units; fp32 partials go to the
+                            // four slabs of M rows behind Xout (M * 512 floats each), LayerNorms / Hout are launch_block_split_reduce's
     int variant;            // 0 = product kernel; 1, 2: timing experiments (tools/block_bench.py)
     long long* stamps;      // optional (4 waves, 16) shader-clock phase stamps of workgroup stamp_block
     int stamp_block;
@@ -132,6 +134,21 @@ void launch_pack_block_stream(const bf16_t* Wo, const bf16_t* W1, const bf16_t* 
 void launch_pack_block_qkv(const bf16_t* Wqkv_next, bf16_t* out, hipStream_t st);
 void launch_pack_block_heads(const bf16_t* Wh0, const bf16_t* Wh1, bf16_t* out, hipStream_t st);  // or: the two scalar heads' Linear(512,512)  // behind them: the next layer's in_proj
 bool launch_block_fused(const BlockP& p, hipStream_t st);  // false: arguments not covered (caller takes the unfused path)
+struct SplitReduceP {       // behind launch_block_fused(split = 1): x = sum of the slabs -> Xout; LN_B?(LN_A(x)) -> Hout
+    const float* slabs;     // (block_split_n(), M, 512) fp32
+    int M;
+    float* Xout;            // optional
+    int ldx;
+    const float* lnA_g;
+    const float* lnA_b;
+    const float* lnB_g[2];  // optional, per row group (out_mod / out_grp as BlockP)
+    const float* lnB_b[2];
+    int out_mod, out_grp;
+    bf16_t* Hout;           // optional
+    int ldh;
+};
+void launch_block_split_reduce(const SplitReduceP& p, hipStream_t st);
+int block_split_n();
 
 // Decoder input of the un-masked tokens as one launch (block_fused.hip: kv_fused_kernel; d = 512, bf16 operands):
 //     y = Z W_k^T + rowtab_k[r % rt_mod]      decoder embedding of key k (mtm_model.py:665-676)

@@ -533,6 +533,9 @@ void invalidate_tables(m3pc_handle* h) {
 // The choice goes by the size of the WHOLE step (m3pc_handle::pass_scale = n_total / candidates of this launch), not by the
 // rows of a shard or a candidate part: a candidate's score must not depend on how the candidates were cut.
 constexpr long long FUSED_MIN_ROWS = 96 * 128;
+// Between 16 and 96 tiles the tail still runs fused, four workgroups per tile (each a quarter of the FFN's hidden units, fp32
+// partials to four slabs in the F buffer) with a row-wise reduce + LayerNorm launch behind it (block_fused_kernel<0, 3>).
+constexpr long long SPLIT_MIN_ROWS = 16 * 128;
 
 // qkv_done: the previous layer's fused tail already wrote this layer's Q|K|V rows; next_qkv: prefix of the layer whose Q|K|V
 // projection this layer's fused tail may compute (-> *next_qkv_done)
@@ -649,7 +652,54 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
     }
     // many-row bf16 passes: everything after the attention is one launch (block_fused.hip)
     static const bool no_fused = M3PC_ENV("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
-    if (dt == DT_BF16 && !no_fused && (double)rows * h->pass_scale >= (double)FUSED_MIN_ROWS && h->wstream.count(pfx)) {
+    static const bool no_split = M3PC_ENV("M3PC_NO_BLOCK_SPLIT") != nullptr;  // A/B switch
+    const double step_rows = (double)rows * h->pass_scale;
+    if (dt == DT_BF16 && !no_fused && !no_split && step_rows < (double)FUSED_MIN_ROWS && step_rows >= (double)SPLIT_MIN_ROWS &&
+        h->wstream.count(pfx) && !Xnext && !res_nshared && (long long)rows * block_split_n() * d <= h->R * 4LL * d) {
+        // few tiles: four workgroups per tile + the reduce (which also applies the LayerNorm that consumes the block output)
+        BlockP b;
+        memset(&b, 0, sizeof(b));
+        b.O = (const bf16_t*)h->O;
+        b.ldo = d;
+        b.M = rows;
+        b.res = X;
+        b.ldr = d;
+        b.wstream = h->wstream[pfx];
+        b.bo = W(h, pfx + ".self_attn.out_proj.bias").f;
+        b.b1 = W(h, pfx + ".linear1.bias").f;
+        b.b2 = W(h, pfx + ".linear2.bias").f;
+        b.ln2_g = W(h, pfx + ".norm2.weight").f;
+        b.ln2_b = W(h, pfx + ".norm2.bias").f;
+        b.split = 1;
+        b.Xout = (float*)h->F;
+        b.ldx = d;
+        const bool fuse_ln = next_ln && next_ln->Yb && !next_ln->Yf && !next_ln->g2 && next_ln->X == X && next_ln->xmap.rpg == 0 &&
+                             next_ln->rows == rows;
+        bool ok;
+        {
+            GemmTimer t(h, st, 2.0 * rows * ((double)d * d * block_split_n() + 2.0 * d * ff), dt, 1);
+            ok = launch_block_fused(b, st);
+        }
+        if (ok) {
+            SplitReduceP r;
+            memset(&r, 0, sizeof(r));
+            r.slabs = (const float*)h->F;
+            r.M = rows;
+            r.ldx = d;
+            if (!(fuse_ln && x_dead)) r.Xout = X;
+            if (fuse_ln) {
+                r.lnA_g = next_ln->g1;
+                r.lnA_b = next_ln->b1;
+                r.Hout = next_ln->Yb;
+                r.ldh = d;
+            }
+            launch_block_split_reduce(r, st);
+            if (next_ln_done) *next_ln_done = fuse_ln;
+            if (next_qkv_done) *next_qkv_done = false;
+            return check_launch(pfx.c_str());
+        }
+    }
+    if (dt == DT_BF16 && !no_fused && step_rows >= (double)FUSED_MIN_ROWS && h->wstream.count(pfx)) {
         BlockP b;
         memset(&b, 0, sizeof(b));
         b.O = (const bf16_t*)h->O;
@@ -1322,7 +1372,10 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
     float* Y1 = h->EncOut;  // (n*nq, d) decoder residual of the scored tokens (EncOut is dead: Z/Y hold its uses)
     static const bool no_fused = M3PC_ENV("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
     bool tail_done = false;
-    if (dt == DT_BF16 && !no_fused && (double)n * nq * h->pass_scale >= (double)FUSED_MIN_ROWS && h->wstream.count(pfx)) {
+    static const bool no_split = M3PC_ENV("M3PC_NO_BLOCK_SPLIT") != nullptr;  // A/B switch
+    const double step_rows = (double)n * nq * h->pass_scale;
+    const bool tail_split = !no_split && step_rows < (double)FUSED_MIN_ROWS && step_rows >= (double)SPLIT_MIN_ROWS;  // (run_block)
+    if (dt == DT_BF16 && !no_fused && (step_rows >= (double)FUSED_MIN_ROWS || tail_split) && h->wstream.count(pfx)) {
         // out-proj, norm2, FFN, decoder.norm and the two heads' LayerNorms in one launch (block_fused.hip): the rows of
         // head s land in the s-th block of n*h rows of Hn
         BlockP b;
@@ -1354,9 +1407,13 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         // both scored keys have scalar heads (rtg_guiding: rewards, returns): the heads run inside the tail, on workgroups
         // that each own rows of one key; else the heads' LayerNorm rows go to Hn and the heads are launches of their own
         static const bool no_head_fused = M3PC_ENV("M3PC_NO_HEAD_FUSED") != nullptr;  // A/B switch
-        const bool fuse_heads = !no_head_fused && q.qkeys[0] == M3PC_REWARDS && q.qkeys[1] == M3PC_RETURNS &&
+        const bool fuse_heads = !tail_split && !no_head_fused && q.qkeys[0] == M3PC_REWARDS && q.qkeys[1] == M3PC_RETURNS &&
                                 h->feat[M3PC_REWARDS] == 1 && h->feat[M3PC_RETURNS] == 1;
-        if (fuse_heads) {
+        if (tail_split) {  // few tiles: four workgroups per tile, the LayerNorms on the reduce of their partials
+            b.split = 1;
+            b.Xout = (float*)h->F;
+            b.ldx = d;
+        } else if (fuse_heads) {
             for (int s = 0; s < 2; ++s) {
                 const std::string hp = std::string("output_head_dict.") + KEYN[q.qkeys[s]];
                 b.head_out[s] = h->pred[s];
@@ -1374,8 +1431,25 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         }
         bool ok;
         {
-            GemmTimer t(h, st, 2.0 * n * nq * ((double)d * d + 2.0 * d * h->ff + (fuse_heads ? (double)d * d : 0.0)), dt, 1);
+            GemmTimer t(h, st, 2.0 * n * nq * ((double)d * d * (tail_split ? block_split_n() : 1) + 2.0 * d * h->ff + (fuse_heads ? (double)d * d : 0.0)), dt, 1);
             ok = launch_block_fused(b, st);
+        }
+        if (ok && tail_split) {
+            SplitReduceP r;
+            memset(&r, 0, sizeof(r));
+            r.slabs = (const float*)h->F;
+            r.M = n * nq;
+            r.lnA_g = b.lnA_g;
+            r.lnA_b = b.lnA_b;
+            for (int s = 0; s < 2; ++s) {
+                r.lnB_g[s] = b.lnB_g[s];
+                r.lnB_b[s] = b.lnB_b[s];
+            }
+            r.out_mod = nq;
+            r.out_grp = hh;
+            r.Hout = (bf16_t*)h->Hn;
+            r.ldh = d;
+            launch_block_split_reduce(r, st);
         }
         if (ok && !fuse_heads) {
             for (int s = 0; s < 2; ++s)
