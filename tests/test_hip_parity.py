@@ -303,6 +303,31 @@ def test_odd_shapes_match_oracle(T, H, N, mode):
     h.close()
 
 
+@pytest.mark.parametrize("T,H,N,mode", [(8, 4, 625, "rtg"), (8, 4, 625, "critic"), (16, 8, 300, "rtg")])
+def test_few_tile_bf16_passes_match_oracle(T, H, N, mode):
+    """bf16 candidate passes of 16..96 fused-tail tiles (the reference's shipped N=625 / H=4 / T=8 config among them) take the
+    four-workgroups-per-tile form of the fused layer tail + its reduce launch (DESIGN.md section 4 "Small problems"): scores
+    within the bf16 tolerance of the oracle, shards of the candidates bit-identical to the whole."""
+    dims = synth.Dims(11, 3, T)
+    h, sd, stats, critic = make_handle(dims, max_candidates=N, max_batch=1)
+    cfg = O.PlanCfg(T, H, N, 0.99, 1.0 if mode != "rtg" else 0.01, 0.6)
+    win, hh = O.assemble_window(cfg, synth.make_history(dims, 3), 300, 2.0)
+    eps = synth.make_eps(N, dims, 9)
+    dev_eps = eps[:, 0, :, 0, :].cuda()
+    ref = O.guiding(sd, stats, cfg, win, H, 0.6, eps, mode, critic=critic)
+    s, a, r = window_dev(win)
+    res = h.plan_step(MODES[mode], s, a, r, dev_eps, H, 2.0, 0.6, 0.99, N, precision=capi.PREC_BF16)
+    scale = max(float(ref["expect_return"].abs().max()), 1.0)
+    d = res["expect_return"].cpu() - ref["expect_return"]
+    assert float((d - d.median()).abs().max()) <= 3e-2 * scale, float((d - d.median()).abs().max()) / scale
+    # two shards: the same bits (the kernel choice goes by n_total, not by the shard)
+    n0 = N // 2
+    parts = [h.plan_step(MODES[mode], s, a, r, dev_eps, H, 2.0, 0.6, 0.99, N, b0, cnt, precision=capi.PREC_BF16)["expect_return"]
+             for b0, cnt in ((0, n0), (n0, N - n0))]
+    assert torch.equal(torch.cat(parts), res["expect_return"])
+    h.close()
+
+
 # ------------------------------------------------------------------------------------ properties at full size
 def test_sharding_is_exact():
     """Scoring candidates in shards gives bit-identical scores to one call (candidates are independent)."""
