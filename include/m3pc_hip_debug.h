@@ -45,6 +45,9 @@ long long m3pc_debug_kv_stream_bytes(void);
 int m3pc_debug_kv_fused(const void* Z, int n, int Le, int kept0, int off0, int kept1, int off1, const void* We0, const void* We1,
                         const void* Wkv, void* stream_buf, const float* rowtab0, const float* rowtab1, const float* ln_g,
                         const float* ln_b, const float* bkv, void* KV, void* stream, long long* stamps);
+/* in-kernel phase stamps of workgroup 37 of every fused-tail launch as the step runs: cap > 0 starts a ring of cap entries
+ * (64 int64 each), cap == 0 copies it to `out` (host), reports the number of launches logged and stops */
+int m3pc_debug_stamp_log(m3pc_handle* h, int cap, long long* out, int* n_logged);
 /* XCD / CU of every workgroup of a launch on `stream`: out[2 i] = XCC_ID, out[2 i + 1] = HW_ID */
 int m3pc_debug_xcc_probe(int* out, int n_blocks, void* stream);
 

@@ -187,6 +187,9 @@ struct m3pc_handle {
     std::map<std::string, bf16_t*> wstream;
     // packed streams of the fused decoder input (kv_fused_kernel), by key: embedding of key k + K|V rows of decoder layer 0
     bf16_t* kvstream[4] = {nullptr, nullptr, nullptr, nullptr};
+    // lab: in-kernel phase stamps of one workgroup of every fused-tail launch, as the step runs (m3pc_debug_stamp_log)
+    long long* stamp_log = nullptr;
+    int stamp_cap = 0, stamp_i = 0;
     // profiling
     bool prof = false;
     bool prof_serial = false;     // m3pc_profile_enable(h, 2): the candidate halves run one after the other on the caller's stream
@@ -739,6 +742,10 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
         if (!(fuse_ln && x_dead)) {
             b.Xout = Xnext ? Xnext : X;
             b.ldx = d;
+        }
+        if (h->stamp_log) {
+            b.stamps = h->stamp_log + 64 * (h->stamp_i++ % h->stamp_cap);
+            b.stamp_block = 37;
         }
         GemmTimer t(h, st, 2.0 * rows * ((double)d * d + 2.0 * d * ff + (fuse_qkv ? 3.0 * d * d : 0.0)), dt, 1);
         if (launch_block_fused(b, st)) {
@@ -1428,6 +1435,10 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         } else {
             b.Hout = (bf16_t*)h->Hn;
             b.ldh = d;
+        }
+        if (h->stamp_log) {
+            b.stamps = h->stamp_log + 64 * (h->stamp_i++ % h->stamp_cap);
+            b.stamp_block = 37;
         }
         bool ok;
         {
@@ -2495,6 +2506,29 @@ int m3pc_debug_gemm(int dtype, const void* A, const void* Wt, const float* bias,
 }
 
 // Not part of the public header (tools/gemm_bench.py): clock counters of the last probed GEMM workgroup.
+// cap > 0: from now on every fused-tail launch of the handle logs the phase stamps of its workgroup 37 into a ring of `cap`
+// entries (64 int64 each: wave w at [16 w ..]); cap == 0: copy the ring to out (host, cap_prev * 64 int64), return how many
+// launches were logged through *n_logged, and stop logging
+int m3pc_debug_stamp_log(m3pc_handle* h, int cap, long long* out, int* n_logged) {
+    if (!h) return fail(M3PC_EINVAL, "null handle");
+    if (cap > 0) {
+        if (h->stamp_log) hipFree(h->stamp_log);
+        CHK(dmalloc(&h->stamp_log, (size_t)cap * 64));
+        HIPCHK(hipMemset(h->stamp_log, 0, (size_t)cap * 64 * sizeof(long long)));
+        h->stamp_cap = cap;
+        h->stamp_i = 0;
+        return 0;
+    }
+    if (!h->stamp_log) return fail(M3PC_ESTATE, "stamp log not enabled");
+    HIPCHK(hipDeviceSynchronize());
+    if (out) HIPCHK(hipMemcpy(out, h->stamp_log, (size_t)h->stamp_cap * 64 * sizeof(long long), hipMemcpyDeviceToHost));
+    if (n_logged) *n_logged = h->stamp_i;
+    hipFree(h->stamp_log);
+    h->stamp_log = nullptr;
+    h->stamp_cap = 0;
+    return 0;
+}
+
 int m3pc_debug_clock(long long* out2) {
     HIPCHK(hipDeviceSynchronize());
     read_clock_probe(out2);
