@@ -41,13 +41,18 @@ class _Episode:
 
 def evaluate_plan(planner, envs: Sequence, episode_rtg_ref: np.ndarray, ratio: float = 1.0, max_steps: int = 1000,
                   in_flight: Optional[int] = None, on_step: Optional[Callable] = None, eval: bool = True,
-                  percentage: float = 1.0) -> Dict[str, Any]:
+                  percentage: float = 1.0, lockstep: bool = False) -> Dict[str, Any]:
     """One evaluation episode in each of ``envs`` (learner.py:645-741 with num_episodes = len(envs)), planned through the
     pipelined planner.  ``episode_rtg_ref[t] * ratio`` is the return-to-go handed to the planner at timestep t (learner.py:
     688); with ``eval=False`` the planner explores as ``online_rollout`` does (sampled action, return-to-go from the
     ``percentage`` of the returns range, replay_buffer.py:206-212).
     in_flight: how many environments have a plan step on the device at the same time (default: planner.pipeline_depth + 1,
-    at most the number of slots - 1).  Returns {"return_mean", "return_std", "length_mean", "length_std", "returns",
+    at most the number of slots - 1).
+    lockstep: the environments step TOGETHER instead -- per round one ``action_sample_batch(lockstep=True)`` over the windows
+    of all live environments (one policy pass at batch E, the candidate passes back to back, one batched fp32 re-score: the
+    short launches of the fp32 chains are paid once per round, not once per environment; needs a planner built with
+    ``max_batch >= len(envs)``; per environment the actions agree with the pipelined loop to fp32 rounding of the policy
+    head, not bit for bit, and the draws are taken per round).  Returns {"return_mean", "return_std", "length_mean", "length_std", "returns",
     "lengths", "trajectories", "plan_steps"} -- the statistics evaluate_plan logs (learner.py:715-731)."""
     from . import capi
 
@@ -67,10 +72,12 @@ def evaluate_plan(planner, envs: Sequence, episode_rtg_ref: np.ndarray, ratio: f
         ep.ticket = planner.plan_async(ep.traj, percentage=percentage, eval=eval, rtg=rtg)
         flying.append(ep)
 
-    def land(ep: _Episode):
+    def land(ep: _Episode, action=None):
         nonlocal steps
-        action = np.clip(ep.ticket.result().cpu().numpy(), -1, 1)  # learner.py:690 / replay_buffer.py:213-215
-        ep.ticket = None
+        if action is None:
+            action = ep.ticket.result().cpu().numpy()
+            ep.ticket = None
+        action = np.clip(action, -1, 1)  # learner.py:690 / replay_buffer.py:213-215
         obs, reward, done, info = ep.env.step(action)
         ep.traj["actions"][ep.timestep] = action
         ep.traj["rewards"][ep.timestep] = reward
@@ -85,6 +92,14 @@ def evaluate_plan(planner, envs: Sequence, episode_rtg_ref: np.ndarray, ratio: f
         if not ep.done and ep.timestep < max_steps:
             waiting.append(ep)
 
+    while lockstep and waiting:
+        live, waiting = waiting, []
+        for ep in live:
+            ep.traj["observations"][ep.timestep] = ep.observation
+        rtgs = [float(episode_rtg_ref[ep.timestep] * ratio) for ep in live] if eval else None
+        acts = planner.action_sample_batch([ep.traj for ep in live], percentage=percentage, eval=eval, rtg=rtgs, lockstep=True)
+        for ep, action in zip(live, acts.cpu().numpy()):  # one read-back per round
+            land(ep, action)
     while waiting or flying:
         while waiting and len(flying) < cap:
             issue(waiting.pop(0))

