@@ -22,6 +22,7 @@ Every step owns a slot (policy head, returns tokens, re-score scratch); its resu
 """
 from __future__ import annotations
 
+import os
 import types
 from typing import Dict, Optional
 
@@ -57,7 +58,7 @@ class _Slot:
         self.device = device
         self.b_top = self.f_top = self.stats = self.mstats = None
         self.hs_win = self.hs_mrg = None
-        self.win = self.win_np = None
+        self.win = self.win_np = self.win_dev = self.eps_buf = self.expo_buf = None
         self.ev_in = self.ev_pol = self.ev_cand = self.ev_done = None
 
     def ready(self, planner):
@@ -70,6 +71,15 @@ class _Slot:
             self.hs_win, self.hs_mrg = capi.HostStats(), capi.HostStats()
             self.win = torch.zeros((planner.T * (planner.S + planner.A + 1),), dtype=torch.float32).pin_memory()
             self.win_np = self.win.numpy()
+            # Device buffers a pipelined step fills on the policy stream and reads on the other streams (window, variates): owned
+            # by the SLOT, not allocated per step -- the caching allocator recycles a block within the stream it was allocated on
+            # without knowing about the other streams' readers, so a per-step tensor freed when its ticket goes could be
+            # overwritten by the next step's draw while this step's select still reads it.  A slot's buffers are re-filled only
+            # behind ev_done of the slot's previous owner.
+            n = int(planner.cfg.action_samples)
+            self.win_dev = torch.empty((planner.T * (planner.S + planner.A + 1),), dtype=torch.float32, device=dev)
+            self.eps_buf = torch.empty((n * planner.T * planner.A,), dtype=torch.float32, device=dev)
+            self.expo_buf = torch.empty((n,), dtype=torch.float32, device=dev)
             self.ev_in, self.ev_pol, self.ev_cand, self.ev_done = (torch.cuda.Event() for _ in range(4))
         return self
 
@@ -296,11 +306,15 @@ class HipPlanner:
     def _eps(self, shape):
         return torch.randn(shape, device=self.device, dtype=torch.float32, generator=self.generator)
 
-    def _draw_eps(self, mode, h):
+    def _draw_eps(self, mode, h, buf=None):
         """The candidate variates, in the shapes the reference draws: dist.sample((N,)) over loc (1,T,1,A) (learner.py:285) /
-        randn((N,h,A)) for the fixed-variance variant (learner.py:157-163); identical on every rank."""
+        randn((N,h,A)) for the fixed-variance variant (learner.py:157-163); identical on every rank.  buf: a flat device
+        buffer to draw into (same variates as a fresh tensor of the shape)."""
         N, T, A = int(self.cfg.action_samples), self.T, self.A
-        return self._eps((N, h, A)) if mode == capi.MODE_NOISE else self._eps((N, 1, T, 1, A))
+        shape = (N, h, A) if mode == capi.MODE_NOISE else (N, 1, T, 1, A)
+        if buf is None or type(self)._eps is not HipPlanner._eps or "_eps" in self.__dict__:  # (tests substitute _eps)
+            return self._eps(shape)
+        return buf[: int(np.prod(shape))].view(shape).normal_(generator=self.generator)
 
     def _draw_expo(self):
         """The multinomial's exponentials (ATen's own algorithm: argmax(p / q), q ~ Exp(1))."""
@@ -378,10 +392,14 @@ class HipPlanner:
             if eps is None and self._predrawn is not None and self._predrawn[:2] == (mode, h):
                 eps, expo = self._predrawn[2:]  # action_sample drew them before the window's H2D copy (same order of draws)
             self._predrawn = None
+            if chain is not None:
+                chain.wait_event(sl.ev_done)  # (see _Slot.ready: the slot's buffers are free once its previous owner is done)
             if eps is None:
-                eps = self._draw_eps(mode, h)
+                eps = self._draw_eps(mode, h, sl.eps_buf if chain is not None else None)
             tk.eps = eps = eps.reshape(N, -1, A)
-            tk.expo = self._draw_expo() if expo is None else expo
+            if expo is None:
+                expo = sl.expo_buf.exponential_(1, generator=self.generator) if chain is not None else self._draw_expo()
+            tk.expo = expo
             hd.policy_pass(mode, states, actions, rewards, h, tk.rtg, slot=sl.i, returns=returns)
             if chain is not None:
                 sl.ev_pol.record(chain)
@@ -787,8 +805,9 @@ class HipPlanner:
         h, return_to_go = self._window_host(sequence_history, rtg, percentage, sl.win_np)
         # pinned per-slot staging (the slot is free, so its last copy is done), copied on the CHAIN stream: the current
         # stream is in order behind the previous step's candidate pass, the chain stream is not
-        with torch.cuda.stream(self._chain_stream()):
-            dev = sl.win.to(self.device, non_blocking=True)
+        with torch.cuda.stream(self._chain_stream()) as _:
+            self._chain.wait_event(sl.ev_done)  # (the slot's previous owner has finished with the slot's device buffers)
+            dev = sl.win_dev.copy_(sl.win, non_blocking=True)
         states, actions, rewards = self._blocks(dev)
         tk = self._issue(_MODES[guidance], states, actions, rewards, return_to_go, h, lmbda, pipelined=True, slot=sl,
                          inputs_ready=True)
