@@ -71,3 +71,8 @@ def test_every_python_block_of_integration_md_runs(tmp_path, monkeypatch):
         except Exception as e:
             raise AssertionError(f"INTEGRATION.md python block {i} failed: {e!r}\n{block[:400]}") from e
     torch.cuda.synchronize()
+    # the stub's structures are the library's (a shorter m3pc_plan_args would let the library read past it)
+    import ctypes
+    from m3pc_amd import capi
+    assert ctypes.sizeof(ns["PlanArgs"]) == ctypes.sizeof(capi.PlanArgs) and ctypes.sizeof(ns["Dims"]) == ctypes.sizeof(capi.Dims)
+    assert ctypes.sizeof(ns["NamedTensor"]) == ctypes.sizeof(capi.NamedTensor)
