@@ -2032,6 +2032,8 @@ static int plan_check(m3pc_handle* h, const m3pc_plan_args* a, bool need_critic)
     if (a->mode < 0 || a->mode > 2) return fail(M3PC_EINVAL, "bad mode %d", a->mode);
     if (a->precision != M3PC_PREC_FP32 && a->precision != M3PC_PREC_BF16) return fail(M3PC_EINVAL, "bad precision");
     if (a->slot < 0 || a->slot >= M3PC_SLOTS) return fail(M3PC_EINVAL, "slot %d outside [0, %d)", a->slot, M3PC_SLOTS);
+    if (a->flags & ~M3PC_PLAN_DEFER_JOIN)  // (also what a caller built against the shorter ABI v2 structure would hand over)
+        return fail(M3PC_EINVAL, "unknown m3pc_plan_args::flags 0x%x (is the caller's structure the ABI v%d one?)", a->flags, M3PC_ABI_VERSION);
     if (need_critic && a->mode != M3PC_MODE_RTG && !h->critic_set) return fail(M3PC_ESTATE, "critic weights not set");
     HIPCHK(hipSetDevice(h->device));
     bind_slot(h, a->slot);
