@@ -153,6 +153,14 @@ def test_c2_candidate_halves_on_two_streams_are_bit_identical_to_one_stream(monk
     er2, sa2 = scores({})
     er1, sa1 = scores({"M3PC_TWO_STREAM": "0"})
     assert torch.equal(er1, er2) and torch.equal(sa1, sa2)
+    # the round-3 fusions against the launches they replaced (the next layer's Q|K|V inside the layer tail, the output heads
+    # inside the decoder tail): the same candidates, scores within a fraction of the bf16 deviation of the fp32 scores
+    scale = float(er2.abs().max())
+    for env in ({"M3PC_NO_QKV_FUSED": "1"}, {"M3PC_NO_HEAD_FUSED": "1"}, {"M3PC_NO_QKV_FUSED": "1", "M3PC_NO_HEAD_FUSED": "1"}):
+        er_, sa_ = scores(env)
+        assert torch.equal(sa_, sa2)
+        d = er_ - er2
+        assert float((d - d.median()).abs().max()) <= 1e-2 * scale, (env, float((d - d.median()).abs().max()), scale)
 
 
 @pytest.mark.parametrize("pl", [0, 2, 37, 997])
