@@ -22,7 +22,6 @@ Every step owns a slot (policy head, returns tokens, re-score scratch); its resu
 """
 from __future__ import annotations
 
-import os
 import types
 from typing import Dict, Optional
 
