@@ -680,7 +680,7 @@ int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L
                              next_ln->rows == rows;
         bool ok;
         {
-            GemmTimer t(h, st, 2.0 * rows * ((double)d * d * block_split_n() + 2.0 * d * ff), dt, 1);
+            GemmTimer t(h, st, 2.0 * rows * ((double)d * d + 2.0 * d * ff), dt, 1);  // (algorithmic: the repeated out-proj is not counted)
             ok = launch_block_fused(b, st);
         }
         if (ok) {
@@ -1442,7 +1442,7 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         }
         bool ok;
         {
-            GemmTimer t(h, st, 2.0 * n * nq * ((double)d * d * (tail_split ? block_split_n() : 1) + 2.0 * d * h->ff + (fuse_heads ? (double)d * d : 0.0)), dt, 1);
+            GemmTimer t(h, st, 2.0 * n * nq * ((double)d * d + 2.0 * d * h->ff + (fuse_heads ? (double)d * d : 0.0)), dt, 1);
             ok = launch_block_fused(b, st);
         }
         if (ok && tail_split) {
