@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define M3PC_ABI_VERSION 3
+#define M3PC_ABI_VERSION 4
 
 #define M3PC_OK 0
 #define M3PC_EINVAL (-1)   /* bad argument / shape mismatch            */
@@ -83,6 +83,7 @@ typedef struct m3pc_dims {
     int critic_hidden;  /* TwinQ hidden width (256), 0 = no critic */
     int max_rescore;    /* largest n of m3pc_rescore* / fp32 m3pc_score_actions that runs in the re-score
                            workspace (beside a candidate pass); 0 = 64 */
+    int max_goal_batch; /* largest batch of m3pc_goal_step_batch (zero-shot windows per call); 0 = none.  ABI v4 */
 } m3pc_dims;
 
 /* step slots of a handle (see "Pipelined plan steps") */
@@ -182,6 +183,29 @@ int m3pc_forward(m3pc_handle* h, int batch, const float* const tokens[4], const 
 int m3pc_goal_step(m3pc_handle* h, int batch, const float* states, const float* actions, const float* rewards,
                    const double* rtg, const unsigned char* const masks_pi[4], const unsigned char* const masks_fid[4],
                    int idx, float* inferred, float* window_states, float* out_mu, float* out_std, void* stream);
+
+/* m3pc_goal_step for MANY windows per call (BASELINE config 5: 64 environments x 1024 = 8192 windows per GPU), exactly
+ * pruned to what the reference reads of the two forwards and run in the arithmetic of the candidate pass:
+ *   path inference (pi mask, zeroshot_omtm/masks.py:72-91): the states head is read at the window rows t <= idx and
+ *   idx+2 <= t <= T-2 only (zeroshot_omtm/learner.py:240-246) -- those decoder tokens are the queries of the decoder layer;
+ *   inverse dynamics (fid mask, masks.py:30-47): the action distribution is read at token idx only (learner.py:250-256) --
+ *   ONE query per window.  Un-read decoder rows are never computed; read rows are computed as in m3pc_goal_step.
+ *   Neither mask keeps a rewards or returns token, so those rows of the window (and the return-to-go) never enter the
+ *   arithmetic: the call takes states and actions only.
+ *   batch      E independent windows (<= max_goal_batch): states (E,T,S), actions (E,T,A) device, RAW (un-normalised)
+ *   idx        T - h; the masks are built inside (plan tables cached per idx)
+ *   goal_mode  M3PC_GOAL_PIID: action_piid_sample (learner.py:151-261), both forwards;
+ *              M3PC_GOAL_ID:   action_id_sample (learner.py:60-149), one forward under the gid mask (masks.py:50-69)
+ *   precision  M3PC_PREC_BF16: bf16 MFMA kernels of the candidate pass (fused layer tails); M3PC_PREC_FP32: fp32 MFMA.
+ *              Either way a window's result does not depend on which other windows share the call, as long as the
+ *              batch sizes fall in the same kernel regime (environment sharding: no collective).
+ *   window_states  device out (E,T,S), optional: the observation rows the inverse-dynamics forward saw
+ *   out_mu/out_std device out (E,A): DiagGaussianActor loc / std at token idx (mtm_model.py:313-321)
+ * Runs in the candidate workspace. */
+#define M3PC_GOAL_PIID 0
+#define M3PC_GOAL_ID 1
+int m3pc_goal_step_batch(m3pc_handle* h, int batch, const float* states, const float* actions, int idx, int goal_mode,
+                         int precision, float* window_states, float* out_mu, float* out_std, void* stream);
 
 /* The two halves of m3pc_plan_step as calls of their own, for pipelined callers:
  *   m3pc_policy_pass     learner.py:278-284: returns tokens + return-conditioned policy (batch 1, rcbc

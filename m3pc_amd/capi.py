@@ -21,12 +21,14 @@ KEYS = ("states", "actions", "rewards", "returns")
 MODE_RTG, MODE_CRITIC, MODE_NOISE = 0, 1, 2
 PREC_FP32, PREC_BF16 = 0, 1
 PROF_LAYER_TAIL = 16  # m3pc_profile_read: the fused layer-tail launches only
-ABI_VERSION = 3
+ABI_VERSION = 4
+GOAL_PIID, GOAL_ID = 0, 1  # m3pc_goal_step_batch goal_mode
 SLOTS = 4  # M3PC_SLOTS: plan steps in flight per handle
 
 EXPORTS = (
     "m3pc_last_error", "m3pc_abi_version", "m3pc_create", "m3pc_destroy", "m3pc_load_weights", "m3pc_load_stats",
     "m3pc_set_tokenizer", "m3pc_set_critic", "m3pc_tokenize", "m3pc_detokenize", "m3pc_forward", "m3pc_goal_step",
+    "m3pc_goal_step_batch",
     "m3pc_policy_pass", "m3pc_candidate_pass", "m3pc_candidate_join", "m3pc_policy_pass_batch",
     "m3pc_plan_step", "m3pc_plan_step_batch", "m3pc_score_actions", "m3pc_rescore", "m3pc_rescore_topk", "m3pc_topk_window",
     "m3pc_rescore_listed", "m3pc_rescore_merge", "m3pc_select",
@@ -38,7 +40,7 @@ EXPORTS = (
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "state_dim", "action_dim", "traj_length", "n_embd", "n_head", "n_enc_layer", "n_dec_layer",
-        "max_candidates", "max_batch", "critic_hidden", "max_rescore")]
+        "max_candidates", "max_batch", "critic_hidden", "max_rescore", "max_goal_batch")]
 
 
 class NamedTensor(C.Structure):
@@ -87,6 +89,7 @@ def load_library(path: Optional[str] = None):
         "m3pc_detokenize": [vp, i, vp, vp, ll, vp],
         "m3pc_forward": [vp, i, C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp, vp, i, vp],
         "m3pc_goal_step": [vp, i, vp, vp, vp, C.POINTER(d), C.POINTER(vp), C.POINTER(vp), i, vp, vp, vp, vp, vp],
+        "m3pc_goal_step_batch": [vp, i, vp, vp, i, i, i, vp, vp, vp, vp],
         "m3pc_policy_pass": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, vp],
         "m3pc_candidate_pass": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_candidate_join": [vp, i, vp],
@@ -178,14 +181,16 @@ class Handle:
     """RAII wrapper of one m3pc_handle (one per process and GPU)."""
 
     def __init__(self, state_dim, action_dim, traj_length, n_embd=512, n_head=4, n_enc_layer=2, n_dec_layer=1,
-                 max_candidates=1024, max_batch=1, critic_hidden=256, device: int = 0, max_rescore: int = 64):
+                 max_candidates=1024, max_batch=1, critic_hidden=256, device: int = 0, max_rescore: int = 64,
+                 max_goal_batch: int = 0):
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise M3pcError("no HIP device visible: m3pc_amd runs only on a GPU (there is no CPU path)")
         self.device = torch.device("cuda", device)
         self.dims = Dims(state_dim, action_dim, traj_length, n_embd, n_head, n_enc_layer, n_dec_layer,
-                         max_candidates, max_batch, critic_hidden, max(int(max_rescore), 1))
+                         max_candidates, max_batch, critic_hidden, max(int(max_rescore), 1), max(int(max_goal_batch), 0))
         self.max_rescore = max(int(max_rescore), 1)
+        self.max_goal_batch = max(int(max_goal_batch), 0)
         self._h = C.c_void_p()
         torch.cuda.init()
         with torch.cuda.device(self.device):
@@ -297,6 +302,21 @@ class Handle:
         check(self.lib.m3pc_goal_step(self._h, E, _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), rt, pi, fid, int(idx), _ptr(inferred),
                                       _ptr(window), _ptr(mu), _ptr(sd), _stream(self.device)))
         return mu, sd, inferred, window
+
+    def goal_step_batch(self, states, actions, idx: int, goal_mode: int = GOAL_PIID, precision: int = PREC_BF16,
+                        want_window: bool = False, out=None):
+        """The zero-shot call for many windows, exactly pruned (m3pc_goal_step_batch): states (E,T,S), actions (E,T,A) raw fp32
+        cuda.  Returns (mu, std) (E,A) of the action token at ``idx`` [and the observation rows (E,T,S) the inverse-dynamics
+        forward saw].  ``out``: optional preallocated (mu, std)."""
+        E = states.shape[0]
+        f32 = dict(dtype=torch.float32, device=self.device)
+        s, a = self._f32(states), self._f32(actions)
+        assert s.shape == (E, self.T, self.S) and a.shape == (E, self.T, self.A)
+        mu, sd = out if out is not None else (torch.empty((E, self.A), **f32), torch.empty((E, self.A), **f32))
+        window = torch.empty((E, self.T, self.S), **f32) if want_window else None
+        check(self.lib.m3pc_goal_step_batch(self._h, E, _ptr(s), _ptr(a), int(idx), int(goal_mode), int(precision), _ptr(window),
+                                            _ptr(mu), _ptr(sd), _stream(self.device)))
+        return (mu, sd, window) if want_window else (mu, sd)
 
     # -- plan step ---------------------------------------------------------------------------------
     @staticmethod

@@ -762,6 +762,27 @@ void launch_goal_overlay(float* pred, const float* states_in, float* states_out,
     hipLaunchKernelGGL(goal_overlay_kernel, dim3(grid_for(n)), dim3(256), 0, st, pred, states_in, states_out, n, T, D, idx, mean, stdv, normalize);
 }
 
+// The same hand-over for the pruned path inference (m3pc_goal_step_batch): the states head ran on the window rows the
+// overlay reads only -- rows t <= idx, then idx + 2 <= t <= T - 2, in that order, nq per window -- and `pred` (E * nq, D)
+// is already de-tokenised (head_out_kernel).  states_out = states_in with those rows replaced.
+__global__ __launch_bounds__(256) void goal_overlay_rows_kernel(const float* pred, const float* states_in, float* states_out, long long n,
+                                                                int T, int D, int idx, int nq) {
+    for (long long x = blockIdx.x * (long long)blockDim.x + threadIdx.x; x < n; x += (long long)gridDim.x * blockDim.x) {
+        const int f = (int)(x % D), t = (int)((x / D) % T);
+        const long long e = x / ((long long)D * T);
+        int q = -1;
+        if (t <= idx) q = t;
+        else if (t >= idx + 2 && t < T - 1) q = idx + 1 + (t - (idx + 2));
+        states_out[x] = q >= 0 ? pred[(e * nq + q) * D + f] : states_in[x];
+    }
+}
+void launch_goal_overlay_rows(const float* pred, const float* states_in, float* states_out, long long windows, int T, int D, int idx,
+                              int nq, hipStream_t st) {
+    const long long n = windows * T * D;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(goal_overlay_rows_kernel, dim3(grid_for(n)), dim3(256), 0, st, pred, states_in, states_out, n, T, D, idx, nq);
+}
+
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* in, bf16_t* out, long long n) {
     for (long long x = blockIdx.x * (long long)blockDim.x + threadIdx.x; x < n; x += (long long)gridDim.x * blockDim.x)
         out[x] = (bf16_t)in[x];

@@ -385,6 +385,9 @@ void launch_detokenize(const float* in, float* out, long long rows, int D, const
                        int normalize, hipStream_t st);
 void launch_goal_overlay(float* pred, const float* states_in, float* states_out, long long rows, int T, int D, int idx,
                          const float* mean, const float* stdv, int normalize, hipStream_t st);
+// pruned hand-over (m3pc_goal_step_batch): pred (windows * nq, D) de-tokenised rows of the window rows t <= idx, idx+2 .. T-2
+void launch_goal_overlay_rows(const float* pred, const float* states_in, float* states_out, long long windows, int T, int D, int idx,
+                              int nq, hipStream_t st);
 void launch_f32_to_bf16(const float* in, bf16_t* out, long long n, hipStream_t st);
 void launch_fill(float* out, float value, long long n, hipStream_t st);
 void launch_transpose_f32(const float* in, float* out, int rows, int cols, hipStream_t st);  // out (cols, rows) = in (rows, cols)^T

@@ -72,6 +72,7 @@ struct SharedTables {  // candidate-independent decoder quantities of one plan, 
     float *pre_m = nullptr, *pre_l = nullptr, *pre_O = nullptr;
 };
 
+constexpr int N_QUERY = 4;
 struct Plan {
     std::string key;
     int T = 0, Le = 0, Lm = 0;
@@ -82,16 +83,24 @@ struct Plan {
     int2* d_tokmap = nullptr;    // (Le)
     int* d_dec_rowsrc = nullptr; // (4T): enc row, or -(key)-1 -> mask token table
     int* d_masked_rowsrc = nullptr;  // (Lm): -(i)-1 rows of a (4T, *) table
-    // scoring variants (mode-dependent query sets)
+    // decoder position tables of the kept tokens of key k, (kept[k], d): h->Edec[k] itself when the kept set is the prefix
+    // 0..kept-1 (every finetune mask), else the kept rows gathered (the zero-shot pi mask keeps states 0..idx and T-1)
+    const float* edec_kept[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* edec_own[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool edec_valid = false;
+    // query sets of the pruned decoder: the decoder tokens whose outputs the caller reads, n_groups groups of grp tokens
+    // per batch element, group s = tokens of key qkeys[s]
     struct Query {
         bool built = false;
         int nq = 0, h = 0;
+        int n_groups = 2, grp = 0;
         int qkeys[2] = {0, 0};
         bool all_masked = true;
         int* d_q_rowsrc_tab = nullptr;  // (nq): -(i)-1 rows of (4T,*) tables
         int* d_q_rowsrc_mix = nullptr;  // (nq): enc row or -(i)-1 rows of Yall
         SharedTables tab[2];
-    } query[2];  // index: 0 rtg (rewards, returns), 1 critic (states, rewards)
+    } query[N_QUERY];  // index: 0 rtg (rewards, returns), 1 critic (states, rewards), 2 goal path inference (the state rows the
+                       // overlay reads), 3 goal inverse dynamics (the action token at idx)
 };
 
 struct EventPair {
@@ -132,6 +141,7 @@ struct m3pc_handle {
     void *Hn = nullptr, *QKV = nullptr, *O = nullptr, *F = nullptr, *Z = nullptr;
     float *cand = nullptr, *loc = nullptr, *sd = nullptr, *rtok = nullptr, *pred[2] = {nullptr, nullptr}, *qv = nullptr;
     float* sel_scratch = nullptr;
+    float* goal_ws = nullptr;     // (max_goal_batch, T, S) the window rows the second forward of m3pc_goal_step_batch sees
     int* d_topk = nullptr;        // (1024,) candidate ids of the last top-k
     float* er_top = nullptr;      // (1024,) their fp32 re-scores
     float* sa_buf = nullptr;      // (max(max_candidates, max_rescore), h, A) scratch for m3pc_rescore
@@ -182,7 +192,7 @@ struct m3pc_handle {
     bool aux_unjoined[3] = {false, false, false};
     std::vector<int> defer_parts;
     std::map<std::string, std::unique_ptr<Plan>> plans;
-    Plan* mask_plan[2][65] = {};  // get_mask_plan cache: [rcbc | fd][idx]
+    Plan* mask_plan[4][65] = {};  // get_mask_plan cache: [rcbc | fd | pi = gid | fid][idx]
     // packed MFMA-fragment weight streams of the fused layer tails (block_fused.hip), by block prefix
     std::map<std::string, bf16_t*> wstream;
     // packed streams of the fused decoder input (kv_fused_kernel), by key: embedding of key k + K|V rows of decoder layer 0
@@ -486,23 +496,54 @@ int get_plan(m3pc_handle* h, const unsigned char* const masks[4], Plan** out) {
     return 0;
 }
 
-// The two deterministic test-time masks of a plan step, cached per (kind, idx): kind 0 = rcbc (finetune_omtm/masks.py:7-27:
-// states[:idx+1], actions[:idx], all returns), kind 1 = fd (masks.py:30-44: states[:idx+1], all actions).  No host-side mask
-// work after the first call with a given idx.
+// The deterministic test-time masks, cached per (kind, idx): kind 0 = rcbc (finetune_omtm/masks.py:7-27: states[:idx+1],
+// actions[:idx], all returns), kind 1 = fd (masks.py:30-44: states[:idx+1], all actions), kind 2 = pi = gid
+// (zeroshot_omtm/masks.py:72-91 / 50-69: all states but idx+1 .. T-2 when idx > 0, actions[:idx]), kind 3 = fid
+// (zeroshot_omtm/masks.py:30-47: all states, actions[:idx]).  No host-side mask work after the first call with a given idx.
 int get_mask_plan(m3pc_handle* h, int kind, int idx, Plan** out) {
     Plan*& slot = h->mask_plan[kind][idx];
     if (!slot) {
         const int T = h->T;
         std::vector<unsigned char> m[4];
         for (int k = 0; k < 4; ++k) m[k].assign(T, 0);
-        for (int t = 0; t <= idx && t < T; ++t) m[M3PC_STATES][t] = 1;
-        for (int t = 0; t < (kind == 0 ? idx : T); ++t) m[M3PC_ACTIONS][t] = 1;
-        if (kind == 0)
-            for (int t = 0; t < T; ++t) m[M3PC_RETURNS][t] = 1;
+        if (kind <= 1) {
+            for (int t = 0; t <= idx && t < T; ++t) m[M3PC_STATES][t] = 1;
+            for (int t = 0; t < (kind == 0 ? idx : T); ++t) m[M3PC_ACTIONS][t] = 1;
+            if (kind == 0)
+                for (int t = 0; t < T; ++t) m[M3PC_RETURNS][t] = 1;
+        } else {
+            for (int t = 0; t < T; ++t) m[M3PC_STATES][t] = 1;
+            if (kind == 2 && idx > 0)
+                for (int t = idx + 1; t < T - 1; ++t) m[M3PC_STATES][t] = 0;  // state_mask[idx + 1 : -1] = 0
+            for (int t = 0; t < idx; ++t) m[M3PC_ACTIONS][t] = 1;
+        }
         const unsigned char* mp[4] = {m[0].data(), m[1].data(), m[2].data(), m[3].data()};
         CHK(get_plan(h, mp, &slot));
     }
     *out = slot;
+    return 0;
+}
+
+// Plan::edec_kept: the decoder position table rows of the kept tokens of each key, in encoder order
+int ensure_edec(m3pc_handle* h, Plan* pl, hipStream_t st) {
+    if (pl->edec_valid) return 0;
+    const int T = h->T, d = h->d;
+    for (int k = 0; k < 4; ++k) {
+        if (pl->prefix[k] || pl->kept[k] == 0) {
+            pl->edec_kept[k] = h->Edec[k];
+            continue;
+        }
+        if (!pl->edec_own[k]) CHK(dmalloc(&pl->edec_own[k], (size_t)T * d));
+        int j = 0;
+        for (int t = 0; t < T; ++t)
+            if (pl->dec_src[k * T + t] >= 0) {
+                HIPCHK(hipMemcpyAsync(pl->edec_own[k] + (size_t)j * d, h->Edec[k] + (size_t)t * d, (size_t)d * sizeof(float),
+                                      hipMemcpyDeviceToDevice, st));
+                ++j;
+            }
+        pl->edec_kept[k] = pl->edec_own[k];
+    }
+    pl->edec_valid = true;
     return 0;
 }
 
@@ -519,8 +560,11 @@ void free_tables(SharedTables& t) {
 
 void invalidate_tables(m3pc_handle* h) {
     for (auto& kv : h->plans)
-        for (int q = 0; q < 2; ++q)
+    {
+        for (int q = 0; q < N_QUERY; ++q)
             for (int pr = 0; pr < 2; ++pr) kv.second->query[q].tab[pr].valid = false;
+        kv.second->edec_valid = false;
+    }
 }
 
 // ---------------------------------------------------------------------------------- transformer block
@@ -909,13 +953,13 @@ int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hi
 
 // decoder-embed of rows of one key: Y[cmap rows] = Z[amap rows] W_dec_k^T + E_dec_k[r % mod]
 void dec_embed(m3pc_handle* h, int k, const void* Zop, RowMap amap, float* Yout, RowMap cmap, int M, int mod, int dt,
-               hipStream_t st) {
+               hipStream_t st, const float* table = nullptr) {
     const int d = h->d;
     const std::string kn = KEYN[k];
     GemmP p = gemm_basic(Zop, d, Wop(h, "decoder_embed_dict." + kn + ".weight", dt), d, M, d, d, nullptr);
     p.amap = amap;
     p.cmap = cmap;
-    p.rowtab = h->Edec[k];
+    p.rowtab = table ? table : h->Edec[k];
     p.rt_mod = mod;
     p.rt_ld = d;
     gemm_out(p, DT_F32, Yout, d);
@@ -1064,27 +1108,30 @@ int forward_impl(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, float* ou
 }
 
 // ---------------------------------------------------------------------------------- shared decoder tables
-int build_query(m3pc_handle* h, Plan* pl, int qi, int hh) {
+// toks: the decoder tokens (key * T + t) of the query set, group by group; hh: what the cached set is keyed on
+int build_query_list(m3pc_handle* h, Plan* pl, int qi, int hh, const std::vector<int>& toks, int n_groups, int key0, int key1) {
     Plan::Query& q = pl->query[qi];
     if (q.built && q.h == hh) return 0;
-    const int T = h->T, idx = T - hh;
+    const int T = h->T;
     q.h = hh;
-    q.nq = 2 * hh;
-    q.qkeys[0] = qi == 0 ? M3PC_REWARDS : M3PC_STATES;
-    q.qkeys[1] = qi == 0 ? M3PC_RETURNS : M3PC_REWARDS;
+    q.nq = (int)toks.size();
+    q.n_groups = n_groups;
+    q.grp = q.nq / n_groups;
+    q.qkeys[0] = key0;
+    q.qkeys[1] = key1;
+    if (q.nq < 1 || q.nq > 2 * T || q.grp * n_groups != q.nq) return fail(M3PC_EINVAL, "bad query set (%d tokens, %d groups)", q.nq, n_groups);
     std::vector<int> tab(q.nq), mix(q.nq);
     q.all_masked = true;
-    for (int s = 0; s < 2; ++s)
-        for (int t = 0; t < hh; ++t) {
-            const int i = q.qkeys[s] * T + idx + t;
-            tab[s * hh + t] = -i - 1;
-            if (pl->dec_src[i] >= 0) {
-                q.all_masked = false;
-                mix[s * hh + t] = pl->dec_src[i];
-            } else {
-                mix[s * hh + t] = -i - 1;
-            }
+    for (int j = 0; j < q.nq; ++j) {
+        const int i = toks[j];
+        tab[j] = -i - 1;
+        if (pl->dec_src[i] >= 0) {
+            q.all_masked = false;
+            mix[j] = pl->dec_src[i];
+        } else {
+            mix[j] = -i - 1;
         }
+    }
     if (!q.d_q_rowsrc_tab) {
         CHK(dmalloc(&q.d_q_rowsrc_tab, (size_t)2 * T));
         CHK(dmalloc(&q.d_q_rowsrc_mix, (size_t)2 * T));
@@ -1094,6 +1141,17 @@ int build_query(m3pc_handle* h, Plan* pl, int qi, int hh) {
     for (int pr = 0; pr < 2; ++pr) q.tab[pr].valid = false;
     q.built = true;
     return 0;
+}
+
+// the two scored keys of a plan step at positions idx .. T-1: qi 0 = rtg (rewards, returns), 1 = critic (states, rewards)
+int build_query(m3pc_handle* h, Plan* pl, int qi, int hh) {
+    if (pl->query[qi].built && pl->query[qi].h == hh) return 0;
+    const int T = h->T, idx = T - hh;
+    const int k0 = qi == 0 ? M3PC_REWARDS : M3PC_STATES, k1 = qi == 0 ? M3PC_RETURNS : M3PC_REWARDS;
+    std::vector<int> toks;
+    for (int s = 0; s < 2; ++s)
+        for (int t = 0; t < hh; ++t) toks.push_back((s == 0 ? k0 : k1) * T + idx + t);
+    return build_query_list(h, pl, qi, hh, toks, 2, k0, k1);
 }
 
 // Candidate-independent decoder rows for plan `pl`: run decoder-embed, LN1 and the QKV projection on a
@@ -1198,51 +1256,21 @@ int build_tables(m3pc_handle* h, Plan* pl, int qi, int dt, hipStream_t st) {
     return check_launch("tables");
 }
 
-// ---------------------------------------------------------------------------------- candidate pass
-// widx (optional, device (n,)): candidate c belongs to history window widx[c] of states (., T, S) / rewards (., T, 1);
-// without it all candidates share window 0 and the history tokens are computed once (first-layer sharing).
-// stage_from / stage_to / ln_state: the pass can be enqueued in pieces -- stage k < n_enc_layer is encoder layer k (the
-// embedding goes with stage 0), stage n_enc_layer everything behind the encoder -- so that the pieces of two candidate halves
-// can be enqueued alternately (m3pc_plan_step)
-int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* rewards, int n,
-                   const float* sample_actions, float* expect_return, float* pred_rewards, float* pred_boot, int dt,
-                   hipStream_t st, const int* widx = nullptr, int stage_from = 0, int stage_to = 1 << 30, PieceState* ln_state = nullptr) {
-    const int T = h->T, d = h->d, hh = a->horizon, idx = T - hh;
+enum { TAIL_HEADS = 0, TAIL_X = 1 };
+// The exactly pruned decoder (mtm_model.py:663-716 restricted to what the caller reads) behind an encoder pass over `n`
+// sequences of plan `pl` (encoder output in Z [bf16] / EncOut [fp32]): decoder inputs and K|V of the un-masked tokens,
+// the queries of set `q` (shared table rows when every query token is masked, per-sequence rows else), attention over
+// own + masked keys, out-proj / FFN on the n * nq query rows, then
+//   TAIL_HEADS: decoder.norm + the output head of each group's key -> h->pred[s] (n * grp, D_k) de-tokenised
+//   TAIL_X:     the fp32 block output rows (n * nq, d) -> *xrows (the caller applies decoder.norm / the action head)
+int pruned_decoder(m3pc_handle* h, Plan* pl, Plan::Query& q, SharedTables& tb, int n, int dt, hipStream_t st, int tail,
+                   float** xrows) {
+    const int d = h->d, hh = q.grp, Le = pl->Le, nq = q.nq;
     const size_t es = dtype_size(dt);
-    struct ScaleScope {
-        m3pc_handle* h;
-        ~ScaleScope() { h->pass_scale = 1.0; }
-    } scale_scope{h};
-    h->pass_scale = !widx && a->n_total > n ? (double)a->n_total / (double)n : 1.0;
-    Plan* pl = nullptr;
-    CHK(get_mask_plan(h, 1, idx, &pl));  // fd mask (finetune_omtm/masks.py:30-44)
-    const int qi = a->mode == M3PC_MODE_RTG ? 0 : 1;
-    CHK(build_query(h, pl, qi, hh));
-    CHK(build_tables(h, pl, qi, dt, st));
-    Plan::Query& q = pl->query[qi];
-    SharedTables& tb = q.tab[dt];
-    const int Le = pl->Le, nq = q.nq;
-    if ((long long)n * Le > h->R || (long long)n * nq > h->R) return fail(M3PC_ENOMEM, "n_count %d exceeds workspace", n);
-
-    TokIn in;
-    memset(&in, 0, sizeof(in));
-    in.ptr[M3PC_STATES] = states;
-    in.normalize[M3PC_STATES] = h->tok_norm[M3PC_STATES];
-    in.ptr[M3PC_ACTIONS] = h->cand;
-    in.bstride[M3PC_ACTIONS] = (long long)T * h->A;
-    in.normalize[M3PC_ACTIONS] = h->tok_norm[M3PC_ACTIONS];
-    in.ptr[M3PC_REWARDS] = rewards;
-    in.ptr[M3PC_RETURNS] = h->rtok;
-    in.widx = widx;
-    in.wstride[M3PC_STATES] = (long long)T * h->S;
-    in.wstride[M3PC_REWARDS] = T;
-    // encoder order is states 0..idx, actions 0..T-1: everything before actions[idx] is history, shared by all candidates
-    // of one window
-    const int nl_enc = h->dm.n_enc_layer;
-    if (stage_from < nl_enc) CHK(run_encoder(h, pl, in, n, dt, st, dt == DT_BF16, widx ? 0 : (idx + 1) + idx, stage_from, stage_to, ln_state));
-    if (stage_to <= nl_enc) return check_launch("candidate_pass");
-
-    // decoder inputs of the un-masked tokens (kept sets are prefixes 0..kept-1 for the fd mask)
+    CHK(ensure_edec(h, pl, st));
+    float* Y1 = h->EncOut;  // (n*nq, d) decoder residual of the query tokens (EncOut is dead: Z/Y hold its uses)
+    if (xrows) *xrows = Y1;
+    // decoder inputs of the un-masked tokens
     const void* enc_op = dt == DT_BF16 ? h->Z : (const void*)h->EncOut;
     const std::string pfx = "decoder.layers.0";
     LnP ln;
@@ -1259,7 +1287,7 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         ln.Yf = (float*)h->Hn;
     bool kv_done = false;
     static const bool no_kv_fused = M3PC_ENV("M3PC_NO_KV_FUSED") != nullptr || M3PC_ENV("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
-    if (dt == DT_BF16 && !no_kv_fused && q.all_masked && (double)n * Le * h->pass_scale >= 512.0 && h->kvstream[0] && (pl->kept[0] || pl->kept[1])) {
+    if (dt == DT_BF16 && !no_kv_fused && q.all_masked && (double)n * Le * h->pass_scale >= 512.0 && h->kvstream[0] && (pl->kept[0] || pl->kept[1]) && !pl->kept[2] && !pl->kept[3]) {
         // embedding, norm1 and the K|V projection in one launch (kv_fused_kernel): the fp32 rows Y are consumed by nothing
         // else when every scored token is masked
         KvFusedP kp;
@@ -1271,7 +1299,7 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
             if (!pl->kept[k]) continue;
             kp.M[g] = n * pl->kept[k];
             kp.map[g] = RowMap{pl->kept[k], Le, pl->enc_off[k]};
-            kp.rowtab[g] = h->Edec[k];
+            kp.rowtab[g] = pl->edec_kept[k];
             kp.rt_mod[g] = pl->kept[k];
             kp.wstream[g] = h->kvstream[k];
             ++g;
@@ -1286,10 +1314,10 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         kv_done = launch_kv_fused(kp, st);
     }
     if (!kv_done) {
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 4; ++k) {
         if (!pl->kept[k]) continue;
         RowMap mm{pl->kept[k], Le, pl->enc_off[k]};
-        dec_embed(h, k, enc_op, mm, h->Y, mm, n * pl->kept[k], pl->kept[k], dt, st);
+        dec_embed(h, k, enc_op, mm, h->Y, mm, n * pl->kept[k], pl->kept[k], dt, st, pl->edec_kept[k]);
     }
     {  // K|V of the un-masked tokens: in_proj rows [d, 3d); norm1 rides on the operand load in the few-row fp32 pass
         const char* wkv = (const char*)Wop(h, pfx + ".self_attn.in_proj_weight", dt) + (size_t)d * d * es;
@@ -1376,7 +1404,6 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         }
         launch_attention(at, dt, st);
     }
-    float* Y1 = h->EncOut;  // (n*nq, d) decoder residual of the scored tokens (EncOut is dead: Z/Y hold its uses)
     static const bool no_fused = M3PC_ENV("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
     bool tail_done = false;
     static const bool no_split = M3PC_ENV("M3PC_NO_BLOCK_SPLIT") != nullptr;  // A/B switch
@@ -1403,18 +1430,23 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         b.b2 = W(h, pfx + ".linear2.bias").f;
         b.ln2_g = W(h, pfx + ".norm2.weight").f;
         b.ln2_b = W(h, pfx + ".norm2.bias").f;
-        b.lnA_g = W(h, "decoder.norm.weight").f;
-        b.lnA_b = W(h, "decoder.norm.bias").f;
-        for (int s = 0; s < 2; ++s) {
-            b.lnB_g[s] = W(h, std::string("output_head_dict.") + KEYN[q.qkeys[s]] + ".0.weight").f;
-            b.lnB_b[s] = W(h, std::string("output_head_dict.") + KEYN[q.qkeys[s]] + ".0.bias").f;
+        if (tail == TAIL_HEADS) {
+            b.lnA_g = W(h, "decoder.norm.weight").f;
+            b.lnA_b = W(h, "decoder.norm.bias").f;
+            for (int s = 0; s < 2; ++s) {  // (one group: LN_B[0] for every row; the kernel's tables still hold two)
+                const int ks = q.qkeys[s < q.n_groups ? s : 0];
+                b.lnB_g[s] = W(h, std::string("output_head_dict.") + KEYN[ks] + ".0.weight").f;
+                b.lnB_b[s] = W(h, std::string("output_head_dict.") + KEYN[ks] + ".0.bias").f;
+            }
+            if (q.n_groups == 2) {
+                b.out_mod = nq;
+                b.out_grp = hh;
+            }
         }
-        b.out_mod = nq;
-        b.out_grp = hh;
         // both scored keys have scalar heads (rtg_guiding: rewards, returns): the heads run inside the tail, on workgroups
         // that each own rows of one key; else the heads' LayerNorm rows go to Hn and the heads are launches of their own
         static const bool no_head_fused = M3PC_ENV("M3PC_NO_HEAD_FUSED") != nullptr;  // A/B switch
-        const bool fuse_heads = !tail_split && !no_head_fused && q.qkeys[0] == M3PC_REWARDS && q.qkeys[1] == M3PC_RETURNS &&
+        const bool fuse_heads = tail == TAIL_HEADS && q.n_groups == 2 && !tail_split && !no_head_fused && q.qkeys[0] == M3PC_REWARDS && q.qkeys[1] == M3PC_RETURNS &&
                                 h->feat[M3PC_REWARDS] == 1 && h->feat[M3PC_RETURNS] == 1;
         if (tail_split) {  // few tiles: four workgroups per tile, the LayerNorms on the reduce of their partials
             b.split = 1;
@@ -1432,9 +1464,12 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
                     b.hstd[s] = h->tok_std[q.qkeys[s]];
                 }
             }
-        } else {
+        } else if (tail == TAIL_HEADS) {
             b.Hout = (bf16_t*)h->Hn;
             b.ldh = d;
+        } else {
+            b.Xout = Y1;
+            b.ldx = d;
         }
         if (h->stamp_log) {
             b.stamps = h->stamp_log + 64 * (h->stamp_i++ % h->stamp_cap);
@@ -1450,20 +1485,25 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
             memset(&r, 0, sizeof(r));
             r.slabs = (const float*)h->F;
             r.M = n * nq;
-            r.lnA_g = b.lnA_g;
-            r.lnA_b = b.lnA_b;
-            for (int s = 0; s < 2; ++s) {
-                r.lnB_g[s] = b.lnB_g[s];
-                r.lnB_b[s] = b.lnB_b[s];
+            if (tail == TAIL_HEADS) {
+                r.lnA_g = b.lnA_g;
+                r.lnA_b = b.lnA_b;
+                for (int s = 0; s < 2; ++s) {
+                    r.lnB_g[s] = b.lnB_g[s];
+                    r.lnB_b[s] = b.lnB_b[s];
+                }
+                r.out_mod = b.out_mod;
+                r.out_grp = b.out_grp;
+                r.Hout = (bf16_t*)h->Hn;
+                r.ldh = d;
+            } else {
+                r.Xout = Y1;
+                r.ldx = d;
             }
-            r.out_mod = nq;
-            r.out_grp = hh;
-            r.Hout = (bf16_t*)h->Hn;
-            r.ldh = d;
             launch_block_split_reduce(r, st);
         }
-        if (ok && !fuse_heads) {
-            for (int s = 0; s < 2; ++s)
+        if (ok && !fuse_heads && tail == TAIL_HEADS) {
+            for (int s = 0; s < q.n_groups; ++s)
                 CHK(run_head_tail(h, q.qkeys[s], (const char*)h->Hn + (size_t)s * n * hh * d * es, n * hh, h->pred[s],
                                   h->feat[q.qkeys[s]], true, dt, st));
         }
@@ -1513,12 +1553,60 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
         gemm_out(p, DT_F32, Y1, d);
         gemm(h, p, dt, st);
     }
-    // heads of the two scored keys -> pred[s] (n*h, D_k), de-tokenized
-    for (int s = 0; s < 2; ++s) {
+    // heads of the scored keys -> pred[s] (n*grp, D_k), de-tokenized
+    for (int s = 0; s < q.n_groups && tail == TAIL_HEADS; ++s) {
         RowMap xm{hh, nq, s * hh};
         CHK(run_head(h, q.qkeys[s], Y1, xm, n * hh, h->pred[s], h->feat[q.qkeys[s]], true, dt, st));
     }
     }
+    return check_launch("pruned_decoder");
+}
+
+// ---------------------------------------------------------------------------------- candidate pass
+// widx (optional, device (n,)): candidate c belongs to history window widx[c] of states (., T, S) / rewards (., T, 1);
+// without it all candidates share window 0 and the history tokens are computed once (first-layer sharing).
+// stage_from / stage_to / ln_state: the pass can be enqueued in pieces -- stage k < n_enc_layer is encoder layer k (the
+// embedding goes with stage 0), stage n_enc_layer everything behind the encoder -- so that the pieces of two candidate halves
+// can be enqueued alternately (m3pc_plan_step)
+int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* rewards, int n,
+                   const float* sample_actions, float* expect_return, float* pred_rewards, float* pred_boot, int dt,
+                   hipStream_t st, const int* widx = nullptr, int stage_from = 0, int stage_to = 1 << 30, PieceState* ln_state = nullptr) {
+    const int T = h->T, d = h->d, hh = a->horizon, idx = T - hh;
+    const size_t es = dtype_size(dt);
+    struct ScaleScope {
+        m3pc_handle* h;
+        ~ScaleScope() { h->pass_scale = 1.0; }
+    } scale_scope{h};
+    h->pass_scale = !widx && a->n_total > n ? (double)a->n_total / (double)n : 1.0;
+    Plan* pl = nullptr;
+    CHK(get_mask_plan(h, 1, idx, &pl));  // fd mask (finetune_omtm/masks.py:30-44)
+    const int qi = a->mode == M3PC_MODE_RTG ? 0 : 1;
+    CHK(build_query(h, pl, qi, hh));
+    CHK(build_tables(h, pl, qi, dt, st));
+    Plan::Query& q = pl->query[qi];
+    SharedTables& tb = q.tab[dt];
+    const int Le = pl->Le, nq = q.nq;
+    if ((long long)n * Le > h->R || (long long)n * nq > h->R) return fail(M3PC_ENOMEM, "n_count %d exceeds workspace", n);
+
+    TokIn in;
+    memset(&in, 0, sizeof(in));
+    in.ptr[M3PC_STATES] = states;
+    in.normalize[M3PC_STATES] = h->tok_norm[M3PC_STATES];
+    in.ptr[M3PC_ACTIONS] = h->cand;
+    in.bstride[M3PC_ACTIONS] = (long long)T * h->A;
+    in.normalize[M3PC_ACTIONS] = h->tok_norm[M3PC_ACTIONS];
+    in.ptr[M3PC_REWARDS] = rewards;
+    in.ptr[M3PC_RETURNS] = h->rtok;
+    in.widx = widx;
+    in.wstride[M3PC_STATES] = (long long)T * h->S;
+    in.wstride[M3PC_REWARDS] = T;
+    // encoder order is states 0..idx, actions 0..T-1: everything before actions[idx] is history, shared by all candidates
+    // of one window
+    const int nl_enc = h->dm.n_enc_layer;
+    if (stage_from < nl_enc) CHK(run_encoder(h, pl, in, n, dt, st, dt == DT_BF16, widx ? 0 : (idx + 1) + idx, stage_from, stage_to, ln_state));
+    if (stage_to <= nl_enc) return check_launch("candidate_pass");
+
+    CHK(pruned_decoder(h, pl, q, tb, n, dt, st, TAIL_HEADS, nullptr));
     const float* rw;
     const float* boot;
     float boot_scale;
@@ -1599,6 +1687,7 @@ int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out) {
     if (D.n_dec_layer != 1) return fail(M3PC_EINVAL, "n_dec_layer must be 1 (every shipped m3pc config)");
     if (D.n_enc_layer < 1 || D.max_candidates < 1 || D.max_batch < 1) return fail(M3PC_EINVAL, "bad sizes");
     if (D.critic_hidden < 0 || D.critic_hidden > 256) return fail(M3PC_EINVAL, "critic_hidden must be <= 256");
+    if (D.max_goal_batch < 0) return fail(M3PC_EINVAL, "max_goal_batch must be >= 0");
     HIPCHK(hipSetDevice(device));
     std::unique_ptr<m3pc_handle> h(new m3pc_handle());
     h->dm = D;
@@ -1631,9 +1720,12 @@ int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out) {
     // candidate workspace: max_candidates candidates of 2T token rows (or max_batch generic forwards of 4T)
     {
         const long long r1 = (long long)D.max_candidates * 2 * T, r2 = (long long)D.max_batch * 4 * T;
+        const long long r3 = (long long)D.max_goal_batch * 2 * T;  // (a goal window keeps at most 2T - 1 tokens, reads at most T)
         long long R = r1 > r2 ? r1 : r2;
+        if (r3 > R) R = r3;
         if (R < 4 * T) R = 4 * T;
-        CHK(alloc_ws(h.get(), h->base, R, D.max_candidates, 64LL << 20));
+        CHK(alloc_ws(h.get(), h->base, R, D.max_candidates > D.max_goal_batch ? D.max_candidates : D.max_goal_batch, 64LL << 20));
+        if (D.max_goal_batch > 0) CHK(dmalloc(&h->goal_ws, (size_t)D.max_goal_batch * T * h->S));
     }
     // chain workspaces: fp32 re-scores (<= max_rescore candidates) / policy passes (batch <= max_batch)
     {
@@ -1730,7 +1822,7 @@ int m3pc_destroy(m3pc_handle* h) {
         hipFree(h->slot[s].sd);
         hipFree(h->slot[s].rtok);
     }
-    void* bufs[] = {h->sel_scratch, h->d_topk, h->er_top, h->sa_buf, h->c_om, h->c_os};
+    void* bufs[] = {h->sel_scratch, h->d_topk, h->er_top, h->sa_buf, h->c_om, h->c_os, h->goal_ws};
     for (size_t i = 1; i < h->auxs.size(); ++i) {
         hipStreamDestroy(h->auxs[i]);
         hipEventDestroy(h->ev_joins[i]);
@@ -1755,7 +1847,9 @@ int m3pc_destroy(m3pc_handle* h) {
         hipFree(pl->d_tokmap);
         hipFree(pl->d_dec_rowsrc);
         hipFree(pl->d_masked_rowsrc);
-        for (int q = 0; q < 2; ++q) {
+        for (int k = 0; k < 4; ++k)
+            if (pl->edec_own[k]) hipFree(pl->edec_own[k]);
+        for (int q = 0; q < N_QUERY; ++q) {
             if (pl->query[q].d_q_rowsrc_tab) hipFree(pl->query[q].d_q_rowsrc_tab);
             if (pl->query[q].d_q_rowsrc_mix) hipFree(pl->query[q].d_q_rowsrc_mix);
             for (int pr = 0; pr < 2; ++pr) free_tables(pl->query[q].tab[pr]);
@@ -2020,6 +2114,103 @@ int m3pc_goal_step(m3pc_handle* h, int batch, const float* states, const float* 
     in.ptr[M3PC_STATES] = window_states;
     CHK(forward_impl(h, fid, in, batch, nullptr, nullptr, nullptr, out_mu, out_std, DT_F32, st));
     return check_launch("goal_step");
+}
+
+// m3pc_goal_step for many windows: the same two forwards, exactly pruned to what the reference reads of them, in the
+// arithmetic of the candidate pass (bf16 MFMA or fp32), in the candidate workspace.
+//   path inference (pi mask): the states head is read at the window rows t <= idx and idx+2 <= t <= T-2 only
+//   (zeroshot_omtm/learner.py:240-246) -- those decoder tokens are the queries; inverse dynamics (fid mask): the action
+//   distribution is read at token idx only (learner.py:250-256) -- ONE query per window, a masked token, so its query row is
+//   shared by the batch.  Neither mask keeps a rewards or returns token (zeroshot_omtm/masks.py:30-47, 72-91): those rows
+//   of the window never enter, which is why the call does not take them.
+// goal_mode M3PC_GOAL_ID: action_id_sample (learner.py:60-149) -- the second forward alone, under the gid mask (= pi mask).
+static int goal_forward(m3pc_handle* h, int kind, int qi, int idx, const float* states, const float* actions, int n, int dt,
+                        hipStream_t st, int tail, float** xrows) {
+    const int T = h->T;
+    Plan* pl = nullptr;
+    CHK(get_mask_plan(h, kind, idx, &pl));
+    std::vector<int> toks;
+    if (qi == 2) {
+        for (int t = 0; t < T; ++t)
+            if (t <= idx || (t >= idx + 2 && t < T - 1)) toks.push_back(M3PC_STATES * T + t);
+    } else {
+        toks.push_back(M3PC_ACTIONS * T + idx);
+    }
+    CHK(build_query_list(h, pl, qi, T - idx, toks, 1, qi == 2 ? M3PC_STATES : M3PC_ACTIONS, 0));
+    CHK(build_tables(h, pl, qi, dt, st));
+    Plan::Query& q = pl->query[qi];
+    if ((long long)n * pl->Le > h->R || (long long)n * q.nq > h->R) return fail(M3PC_ENOMEM, "batch %d exceeds workspace", n);
+    TokIn in;
+    memset(&in, 0, sizeof(in));
+    in.ptr[M3PC_STATES] = states;
+    in.bstride[M3PC_STATES] = (long long)T * h->S;
+    in.normalize[M3PC_STATES] = h->tok_norm[M3PC_STATES];
+    in.ptr[M3PC_ACTIONS] = actions;
+    in.bstride[M3PC_ACTIONS] = (long long)T * h->A;
+    in.normalize[M3PC_ACTIONS] = h->tok_norm[M3PC_ACTIONS];
+    CHK(run_encoder(h, pl, in, n, dt, st, dt == DT_BF16, 0));
+    return pruned_decoder(h, pl, q, q.tab[dt], n, dt, st, tail, xrows);
+}
+
+int m3pc_goal_step_batch(m3pc_handle* h, int batch, const float* states, const float* actions, int idx, int goal_mode,
+                         int precision, float* window_states, float* out_mu, float* out_std, void* stream) {
+    if (!h || !states || !actions || !out_mu || !out_std) return fail(M3PC_EINVAL, "null argument");
+    if (!h->weights_loaded) return fail(M3PC_ESTATE, "weights not loaded");
+    for (int k = 0; k < 2; ++k)
+        if (!h->tok_set[k]) return fail(M3PC_ESTATE, "tokenizer '%s' not set", KEYN[k]);
+    if (batch < 1 || batch > h->dm.max_goal_batch) return fail(M3PC_EINVAL, "batch %d outside [1, max_goal_batch=%d]", batch, h->dm.max_goal_batch);
+    if (precision != M3PC_PREC_FP32 && precision != M3PC_PREC_BF16) return fail(M3PC_EINVAL, "bad precision");
+    if (goal_mode != M3PC_GOAL_PIID && goal_mode != M3PC_GOAL_ID) return fail(M3PC_EINVAL, "bad goal_mode %d", goal_mode);
+    const int T = h->T, d = h->d;
+    if (idx < 0 || idx >= T) return fail(M3PC_EINVAL, "idx %d outside [0, T=%d)", idx, T);
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->device));
+    const int dt = precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32;
+    bind_ws(h, &h->base);
+    CHK(ws_sync(h, st));
+    // kernels chosen by the row count (split-K, the few-row fp32 kernels) stay off: a window's result must not depend on
+    // which other windows share its call (environment sharding, m3pc_amd/dist.py)
+    h->allow_splitk = false;
+    h->pass_scale = 1.0;
+    const float* second = states;
+    if (goal_mode == M3PC_GOAL_PIID) {
+        CHK(goal_forward(h, 2, 2, idx, states, actions, batch, dt, st, TAIL_HEADS, nullptr));
+        int nq = 0;
+        for (int t = 0; t < T; ++t) nq += (t <= idx || (t >= idx + 2 && t < T - 1)) ? 1 : 0;
+        float* ws = window_states ? window_states : h->goal_ws;
+        launch_goal_overlay_rows(h->pred[0], states, ws, batch, T, h->S, idx, nq, st);
+        second = ws;
+    } else if (window_states) {
+        HIPCHK(hipMemcpyAsync(window_states, states, (size_t)batch * T * h->S * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    float* xr = nullptr;
+    CHK(goal_forward(h, goal_mode == M3PC_GOAL_PIID ? 3 : 2, 3, idx, second, actions, batch, dt, st, TAIL_X, &xr));
+    // decoder.norm of the one query row per window, then the action head (mtm_model.py:705, 313-321), fp32
+    LnP ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.X = xr;
+    ln.ldx = d;
+    ln.rows = batch;
+    ln.d = d;
+    ln.g1 = W(h, "decoder.norm.weight").f;
+    ln.b1 = W(h, "decoder.norm.bias").f;
+    ln.Yf = h->G;
+    launch_layernorm(ln, st);
+    ActorP ac;
+    memset(&ac, 0, sizeof(ac));
+    ac.X = h->G;
+    ac.ldx = d;
+    ac.rows = batch;
+    ac.d = d;
+    ac.A = h->A;
+    ac.Wmu = W(h, "output_head_dict.actions.mu.weight").f;
+    ac.bmu = W(h, "output_head_dict.actions.mu.bias").f;
+    ac.Wls = W(h, "output_head_dict.actions.log_std.weight").f;
+    ac.bls = W(h, "output_head_dict.actions.log_std.bias").f;
+    ac.mu = out_mu;
+    ac.sd = out_std;
+    launch_actor_head(ac, st);
+    return check_launch("goal_step_batch");
 }
 
 // common argument checks of the plan-step entry points; binds the step's slot

@@ -124,7 +124,7 @@ class HipPlanner:
                  group=None, generator: Optional[torch.Generator] = None, max_batch: int = 1,
                  rescore: str = "bound", rescore_min: int = 8, rescore_max: int = 128, rescore_delta: Optional[float] = None,
                  max_windows: int = 1, pipeline_depth: int = 2, chain_priority: int = -1, tail_stream: bool = True,
-                 defer_join: bool = True):
+                 defer_join: bool = True, goal_batch: int = 0):
         """cfg: any object with traj_length, action_samples, horizon, discount, temperature, lmbda,
         plan_guidance (finetune.py RunConfig fields read at learner.py:276,319,342).
         tokenizer_manager: a TokenizerManager (this package's) or {key: {"mean","std","min","max"}}.
@@ -144,7 +144,9 @@ class HipPlanner:
           rescore="topk": the fixed ``rescore_topk`` best candidates (round-1 behaviour, no certificate, no host read).
           Either way the select runs on the MERGED vector: fp32 scores for the re-scored candidates, bf16 scores minus the
           estimated shift for the rest, so an un-re-scored candidate cannot win the arg-max through a constant bf16 offset.
-        pipeline_depth: how many plan steps ``action_sample_batch`` / ``rollout`` keep in flight (<= capi.SLOTS - 1)."""
+        pipeline_depth: how many plan steps ``action_sample_batch`` / ``rollout`` keep in flight (<= capi.SLOTS - 1).
+        goal_batch: the largest number of zero-shot windows one ``action_piid_sample_batch`` / ``goal_actions`` call plans
+        through the pruned many-window path (m3pc_goal_step_batch; BASELINE config 5: 8192 per GPU); 0 = that path is off."""
         self.cfg = cfg
         self.group = group
         self.rank, self.world = mdist.world_info(group)
@@ -163,7 +165,8 @@ class HipPlanner:
         self._max_batch = max(int(max_batch), nw, 1)
         self.handle = capi.Handle(S, A, T, n_embd, n_head, n_enc_layer, n_dec_layer,
                                   max_candidates=max(n_local * nw, 1), max_batch=self._max_batch,
-                                  critic_hidden=hidden, device=device, max_rescore=max_rescore)
+                                  critic_hidden=hidden, device=device, max_rescore=max_rescore, max_goal_batch=int(goal_batch))
+        self._goal_batch = int(goal_batch)
         self.device = self.handle.device
         self.S, self.A, self.T = S, A, T
         self.precision = {"fp32": capi.PREC_FP32, "bf16": capi.PREC_BF16}[precision]
@@ -754,16 +757,47 @@ class HipPlanner:
         return None
 
     @torch.no_grad()
-    def action_piid_sample_batch(self, sequence_histories, percentage=1.0, eval=True, rtg=None):
+    def goal_actions(self, states, actions, horizon: int, eval: bool = True, goal_mask: str = "piid", precision: Optional[str] = None,
+                     want_window: bool = False):
+        """The zero-shot action of E windows that are on the device already: states (E,T,S), actions (E,T,A) raw, one effective
+        horizon for all of them (BASELINE config 5: thousands of goal-reaching windows per GPU).  Exactly pruned many-window path
+        (m3pc_goal_step_batch): path inference reads the states head at the rows the overlay uses only, inverse dynamics reads
+        ONE action token (zeroshot learner.py:240-256).  goal_mask "piid" (action_piid_sample) or "id" (action_id_sample).
+        precision: "bf16" / "fp32"; default the planner's.  Returns (E, A): tanh(loc) when eval, a sample else."""
+        prec = self.precision if precision is None else {"fp32": capi.PREC_FP32, "bf16": capi.PREC_BF16}[precision]
+        idx = self.T - int(horizon)
+        self._drain()  # (m3pc_goal_step_batch runs in the candidate workspace)
+        res = self.handle.goal_step_batch(states, actions, idx, capi.GOAL_PIID if goal_mask == "piid" else capi.GOAL_ID, prec,
+                                          want_window=want_window)
+        mu, sd = res[0], res[1]
+        if want_window:
+            self.last = dict(window_states=res[2], loc=mu, std=sd)
+        if eval:
+            return torch.tanh(mu)
+        # SquashedNormal.sample (mtm_model.py:263-269): the variates of the whole (E,T,1,A) distribution are drawn, as the
+        # reference draws them, and the token's are used
+        eps = self._eps((mu.shape[0], self.T, 1, self.A))[:, idx, 0]
+        return torch.tanh(eps * sd + mu)
+
+    @torch.no_grad()
+    def action_piid_sample_batch(self, sequence_histories, percentage=1.0, eval=True, rtg=None, pruned: Optional[bool] = None):
         """E independent goal-reaching windows per launch (BASELINE config 5 / SURVEY §8 f1): the reference plans one
         env per call (zeroshot learner.py:151-261, unseen.py rollout loop); here the windows that share a horizon go
         through the pi and fid forwards as ONE batch of the same kernels.  Per window the arithmetic is that of
-        ``action_piid_sample``.  Returns (E, A).  The planner must have been built with ``max_batch >= E``."""
+        ``action_piid_sample``.  Returns (E, A).
+        pruned=False (default up to 64 windows): the fp32 few-row kernels of ``action_piid_sample`` on the whole batch
+        (``max_batch >= E``; ``last["state_inference"]`` holds every window's full states head).
+        pruned=True (default beyond, needs ``goal_batch >= E``): the exactly pruned many-window path in the planner's
+        precision (``goal_actions``)."""
         if eval:
             assert rtg is not None
         from .masks import create_fid_mask, create_pi_mask, mask_rows
         T, E = self.T, len(sequence_histories)
         S, A = self.S, self.A
+        if pruned is None:
+            pruned = E > 64 or E > self._max_batch
+        if pruned and E > self._goal_batch:
+            raise ValueError(f"{E} windows through the pruned path need HipPlanner(..., goal_batch >= {E})")
         host = np.empty((E, T * (S + A + 1)), dtype=np.float32)
         meta = [self._goal_window_host(hst, rtg, percentage, host[i]) for i, hst in enumerate(sequence_histories)]
         dev = torch.from_numpy(host).to(self.device)  # one packed H2D copy for all windows
@@ -776,6 +810,13 @@ class HipPlanner:
             sel = dev if len(ids) == E else dev[torch.tensor(ids, device=self.device)]
             s = sel[:, : T * S].reshape(-1, T, S).contiguous()
             a = sel[:, T * S : T * (S + A)].reshape(-1, T, A).contiguous()
+            if pruned:
+                act = self.goal_actions(s, a, h, eval=eval)
+                if len(ids) == E:
+                    out = act
+                else:
+                    out[torch.tensor(ids, device=self.device)] = act
+                continue
             r = sel[:, T * (S + A) :].reshape(-1, T, 1).contiguous()
             mu, sd, inferred, _ = self.handle.goal_step(s, a, r, [meta[i][1] for i in ids], mask_rows(create_pi_mask(T, "cpu", idx)),
                                                         mask_rows(create_fid_mask(T, "cpu", idx)), idx)

@@ -37,7 +37,7 @@ def test_abi_version_and_error_string(lib):
 
 
 def test_struct_layouts_match_header():
-    assert ctypes.sizeof(capi.Dims) == 11 * 4
+    assert ctypes.sizeof(capi.Dims) == 12 * 4 and capi.Dims.max_goal_batch.offset == 44  # (ABI v4: max_goal_batch appended)
     assert ctypes.sizeof(capi.PlanArgs) == 6 * 4 + 3 * 8 + 2 * 4 + 8 + 2 * 4
     assert capi.PlanArgs.flags.offset == 64 and capi.PlanArgs.window.offset == 68
     assert capi.PlanArgs.lmbda.offset == 24 and capi.PlanArgs.rtg.offset == 40
