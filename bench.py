@@ -66,6 +66,69 @@ def alg_flops(N, T, H, S, A, d=512, n_enc=2, mode="rtg"):
     return N * per_cand + pass1 + critic
 
 
+def alg_flops_goal(E, T, H, S, A, d=512, n_enc=2):
+    """Algorithmic (exactly pruned) FLOPs of E zero-shot piid windows (zeroshot_omtm/learner.py:151-261): path inference under
+    the pi mask with the states head on the rows the overlay reads, inverse dynamics under the fid mask with ONE action token.
+    Same accounting as alg_flops: encoder layers on the kept tokens, decoder embedding + K|V of the kept tokens,
+    Q of the un-masked query tokens, attention / out-proj / FFN / head on the query tokens only."""
+    idx = T - H
+    c, q, e = 24 * d * d, 4 * d, 2 * d * d
+    Ld = 4 * T
+    ns_a = T if idx == 0 else idx + 2          # pi mask: states 0..idx and T-1 (all of them when idx == 0)
+    na = idx                                   # actions[:idx]
+    nq_a = (idx + 1) + max(0, T - idx - 3)     # rows t <= idx and idx+2 .. T-2
+    nq_a_unmasked = (idx + 1) if idx > 0 else nq_a
+    le_a, le_b = ns_a + na, T + na
+    pass_a = (n_enc * (c * le_a + q * le_a * le_a) + 2 * d * (S * ns_a + A * na) + le_a * 3 * e + nq_a_unmasked * e
+              + nq_a * Ld * q + nq_a * e + nq_a * 16 * d * d + nq_a * (e + 2 * d * S))
+    pass_b = (n_enc * (c * le_b + q * le_b * le_b) + 2 * d * (S * T + A * na) + le_b * 3 * e + Ld * q + e + 16 * d * d + 2 * 2 * d * A)
+    return E * (pass_a + pass_b)
+
+
+def goal_leg(local_rank, E, T=8, H=4, S=11, A=3, steps=20, warm=3, precisions=("bf16", "fp32"), world=1):
+    """BASELINE configs[4] on this GPU: E zero-shot goal-reaching windows (config_hopper: T=8, H=4; 64 environments x 1024 over
+    8 GPUs = 8192 windows per GPU) per call through the pruned many-window path (m3pc_goal_step_batch), windows resident in
+    HBM.  Per precision: ms per call (event-bracketed, the calls back to back), windows/s, the F_alg-based MFMA fraction."""
+    import types
+
+    from m3pc_amd import capi, synth
+    from m3pc_amd.planner import HipPlanner
+    dims = synth.Dims(S, A, T)
+    cfg = types.SimpleNamespace(traj_length=T, action_samples=1, horizon=H, discount=0.99, temperature=1.0, lmbda=0.6,
+                                plan_guidance="rtg_guiding", index_jump=4)
+    p = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None, precision="bf16",
+                   device=local_rank, goal_batch=E)
+    g = torch.Generator().manual_seed(5 + int(os.environ.get("RANK", "0")))
+    st = torch.randn((E, T, S), generator=g).cuda()
+    ac = (torch.rand((E, T, A), generator=g) * 2 - 1).cuda()
+    out_buf = (torch.empty((E, A), device="cuda"), torch.empty((E, A), device="cuda"))
+    res = {"what": f"BASELINE configs[4]: zero-shot piid (pi mask -> overlay -> fid mask), hopper shapes T={T} H={H}, {E} windows per call"
+                   f" (= 64 environments x 1024 / 8 GPUs), exactly pruned (path inference: {H + 2 if H < T else T} state rows of 4T; inverse "
+                   "dynamics: one action token), windows resident in HBM",
+           "alg_tflop_per_call": round(alg_flops_goal(E, T, H, S, A) / 1e12, 4), "windows": E}
+    mus = {}
+    for prec in precisions:
+        pc = capi.PREC_BF16 if prec == "bf16" else capi.PREC_FP32
+        n = steps if prec == "bf16" else max(3, steps // 4)
+        for _ in range(warm):
+            p.handle.goal_step_batch(st, ac, T - H, capi.GOAL_PIID, pc, out=out_buf)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            p.handle.goal_step_batch(st, ac, T - H, capi.GOAL_PIID, pc, out=out_buf)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        mus[prec] = out_buf[0].clone()
+        res[prec] = {"ms_per_call": round(1e3 * dt, 4), "windows_per_s": round(E / dt, 1), "calls": n,
+                     "mfma_frac": round(alg_flops_goal(E, T, H, S, A) / dt / 1e12 / MFMA_PEAK_TFLOPS[prec], 4)}
+    if "bf16" in mus and "fp32" in mus:
+        res["bf16_vs_fp32_loc_err"] = float((mus["bf16"] - mus["fp32"]).abs().max())
+    p.handle.close()
+    return res
+
+
 def alg_bytes(N, T, S, A, n_params=11_326_995):
     """Algorithmic HBM bytes of one plan step: bf16 weights once + window + eps + outputs."""
     return 2 * n_params + 4 * T * (S + A + 2) + 4 * N * T * A + 4 * N + 4 * N * A
