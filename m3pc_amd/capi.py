@@ -172,6 +172,9 @@ class HostStats:
             spins += 1
             if (spins & 1023) == 0 and _t.perf_counter() - t0 > timeout:  # never hang on the mapped buffer
                 if fallback is not None:
+                    # the device copy of the statistics is written on another stream than the current one: order behind
+                    # everything on the device before reading it (this path is taken when the mapped buffer misbehaved)
+                    torch.cuda.synchronize(fallback.device)
                     return [float(x) for x in fallback.cpu()]
                 raise M3pcError("timed out waiting for kernel statistics in host-mapped memory")
         return self.read()

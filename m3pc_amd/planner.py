@@ -58,7 +58,7 @@ class _Slot:
         self.b_top = self.f_top = self.stats = self.mstats = None
         self.hs_win = self.hs_mrg = None
         self.win = self.win_np = self.win_dev = self.eps_buf = self.expo_buf = None
-        self.ev_in = self.ev_pol = self.ev_cand = self.ev_done = None
+        self.ev_in = self.ev_pol = self.ev_cand = self.ev_done = self.ev_h2d = None
 
     def ready(self, planner):
         if self.b_top is None:
@@ -79,7 +79,7 @@ class _Slot:
             self.win_dev = torch.empty((planner.T * (planner.S + planner.A + 1),), dtype=torch.float32, device=dev)
             self.eps_buf = torch.empty((n * planner.T * planner.A,), dtype=torch.float32, device=dev)
             self.expo_buf = torch.empty((n,), dtype=torch.float32, device=dev)
-            self.ev_in, self.ev_pol, self.ev_cand, self.ev_done = (torch.cuda.Event() for _ in range(4))
+            self.ev_in, self.ev_pol, self.ev_cand, self.ev_done, self.ev_h2d = (torch.cuda.Event() for _ in range(5))
         return self
 
 
@@ -842,12 +842,17 @@ class HipPlanner:
         assert guidance in _MODES, guidance
         lmbda = 0.6 if guidance == "rtg_guiding" else float(self.cfg.lmbda)  # learner.py:405-407
         sl = self._acquire_slot().ready(self)
+        # pinned per-slot staging, refilled only once the copy that read it last has EXECUTED: resolving the slot's previous
+        # owner blocks the host in the certified bf16 mode only -- in fp32 / top-k mode the host runs many steps ahead of
+        # the device, and the copy of this slot's previous window may still be queued
+        sl.ev_h2d.synchronize()
         h, return_to_go = self._window_host(sequence_history, rtg, percentage, sl.win_np)
-        # pinned per-slot staging (the slot is free, so its last copy is done), copied on the CHAIN stream: the current
-        # stream is in order behind the previous step's candidate pass, the chain stream is not
+        # copied on the CHAIN stream: the current stream is in order behind the previous step's candidate pass, the chain
+        # stream is not
         with torch.cuda.stream(self._chain_stream()) as _:
             self._chain.wait_event(sl.ev_done)  # (the slot's previous owner has finished with the slot's device buffers)
             dev = sl.win_dev.copy_(sl.win, non_blocking=True)
+            sl.ev_h2d.record(self._chain)
         states, actions, rewards = self._blocks(dev)
         tk = self._issue(_MODES[guidance], states, actions, rewards, return_to_go, h, lmbda, pipelined=True, slot=sl,
                          inputs_ready=True)

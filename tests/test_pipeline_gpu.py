@@ -117,33 +117,55 @@ def test_tickets_resolve_out_of_order_and_slots_recycle():
 
 
 def test_weight_update_between_pipelined_steps_is_ordered():
-    """load_state_dict resolves the steps in flight before it touches the weights."""
+    """load_state_dict resolves the steps in flight before it touches the weights: the tickets issued before it hold the OLD
+    weights' results, the step issued after it the NEW weights' -- each compared by value with a serial planner fed the same
+    variates (the values, not the shapes)."""
     dims = synth.Dims(11, 3, 16)
     wins = _windows(dims, 3)
-    pp = _planner(dims, 128, 8, "rtg_guiding", "fp32", seed=3)
+    eps = synth.make_eps(128, dims, 1).cuda()
+    sd1 = synth.make_state_dict(dims, 1)
+
+    def fixed(p):
+        p._eps = lambda shape: eps
+        return p
+
+    pp = fixed(_planner(dims, 128, 8, "rtg_guiding", "fp32", seed=3))
     t0 = pp.plan_async(wins[0], eval=True, rtg=3.0)
     t1 = pp.plan_async(wins[1], eval=True, rtg=3.0)
-    sd1 = synth.make_state_dict(dims, 1)
     pp.load_state_dict(sd1)
     assert t0.out is not None and t1.out is not None
     a = pp.action_sample(wins[2], plan=True, eval=True, rtg=3.0).clone()
+    old0, old1 = t0.result().clone(), t1.result().clone()
     pp.handle.close()
-    pq = HipPlanner(pp.cfg, sd1, synth.make_tokenizer_stats(dims, 0), None, precision="fp32",
-                    generator=torch.Generator(device="cuda").manual_seed(99))
-    for _ in range(2):  # (advance nothing: eval action does not depend on the multinomial draw)
-        pass
-    b = pq.action_sample(wins[2], plan=True, eval=True, rtg=3.0)
-    # eps differs between the two planners' generators, so compare through a fixed eps instead
-    eps = synth.make_eps(128, dims, 1).cuda()
-    pq._eps = lambda shape: eps
-    b = pq.action_sample(wins[2], plan=True, eval=True, rtg=3.0).clone()
-    pq.handle.close()
-    pr = _planner(dims, 128, 8, "rtg_guiding", "fp32", seed=3)
+    po = fixed(_planner(dims, 128, 8, "rtg_guiding", "fp32", seed=3))  # the old weights, serial
+    assert torch.equal(po.action_sample(wins[0], plan=True, eval=True, rtg=3.0), old0)
+    assert torch.equal(po.action_sample(wins[1], plan=True, eval=True, rtg=3.0), old1)
+    stale = po.action_sample(wins[2], plan=True, eval=True, rtg=3.0).clone()  # what stale weights would have planned
+    po.handle.close()
+    pr = fixed(_planner(dims, 128, 8, "rtg_guiding", "fp32", seed=3))  # the new weights, serial
     pr.load_state_dict(sd1)
-    pr._eps = lambda shape: eps
     c = pr.action_sample(wins[2], plan=True, eval=True, rtg=3.0)
-    assert torch.equal(b, c) and a.shape == b.shape
+    assert torch.equal(a, c) and not torch.equal(a, stale)
     pr.handle.close()
+
+
+@pytest.mark.parametrize("prec,rescore", [("fp32", "bound"), ("bf16", "topk")])
+def test_more_windows_than_twice_the_slots_without_host_reads(prec, rescore):
+    """fp32 mode and the fixed top-k re-score read nothing back per step, so the host runs far ahead of the device and re-fills a
+    slot's pinned window buffer while -- without the slot's copy event -- the H2D copy of the window that used it before may still be
+    queued.  2 SLOTS + 3 windows through action_sample_batch against the serial calls."""
+    dims = synth.Dims(11, 3, 32)
+    n = 2 * capi.SLOTS + 3
+    wins = _windows(dims, n)
+    kw = dict(rescore=rescore) if prec == "bf16" else {}
+    ps = _planner(dims, 1024, 16, "rtg_guiding", prec, seed=5, **kw)
+    serial = [ps.action_sample(w, plan=True, eval=True, rtg=3.0).clone() for w in wins]
+    ps.handle.close()
+    pp = _planner(dims, 1024, 16, "rtg_guiding", prec, seed=5, **kw)
+    got = pp.action_sample_batch(wins, eval=True, rtg=3.0)
+    for i in range(n):
+        assert torch.equal(got[i], serial[i]), i
+    pp.handle.close()
 
 
 def test_deferred_join_orders_other_users_of_the_candidate_workspace():
