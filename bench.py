@@ -27,8 +27,13 @@ Multi-GPU (`--shard`):
                   `--strong` (N = 1024 in total; `replicated_ms` tells what every rank repeats).
   `--config c4`   BASELINE configs[3]: halfcheetah shapes, rtg_guiding, N=16384, H=32, T=64, candidate-sharded over the
                   ranks (strong scaling: 16384 candidates in total), value = plan steps of 16384 candidates per second.
-With --shard env at N > 1 GPUs and `--with-c4` the line also carries `c4` (the candidate-sharded config 4 through RCCL on the
-same ranks, a few steps).
+  `--config c5`   BASELINE configs[4]: zero-shot goal reaching, 8192 windows (64 environments x 1024 / 8 GPUs) per GPU and call
+                  through the pruned many-window path, environment-sharded (no collective), value = windows/s.
+With --shard env at N > 1 GPUs (the default multi-GPU run) the line also carries `c4` (BASELINE configs[3], candidate-sharded
+through RCCL's all-gather on the same ranks, strong scaling), `c2_candidates_strong` (the headline shape with its 1024 candidates
+sharded, `replicated_ms` beside it) and `rccl_ranks_seen`; these legs run behind the headline measurement under a wall-clock
+watchdog (`--collective-timeout`): a leg that hangs costs its own entry ({"error": "timeout"}), never the headline.
+At 1 GPU the line carries the legs `c5`, `c3` (walker2d critic N=4096) and `c4_shard` (2048 halfcheetah candidates at H=32/T=64).
 
 Prints ONE JSON line on rank 0.
 """
@@ -85,7 +90,7 @@ def alg_flops_goal(E, T, H, S, A, d=512, n_enc=2):
     return E * (pass_a + pass_b)
 
 
-def goal_leg(local_rank, E, T=8, H=4, S=11, A=3, steps=20, warm=3, precisions=("bf16", "fp32"), world=1):
+def goal_leg(local_rank, E, T=8, H=4, S=11, A=3, steps=20, warm=3, precisions=("bf16", "fp32"), world=1, fp32_steps=None):
     """BASELINE configs[4] on this GPU: E zero-shot goal-reaching windows (config_hopper: T=8, H=4; 64 environments x 1024 over
     8 GPUs = 8192 windows per GPU) per call through the pruned many-window path (m3pc_goal_step_batch), windows resident in
     HBM.  Per precision: ms per call (event-bracketed, the calls back to back), windows/s, the F_alg-based MFMA fraction."""
@@ -109,7 +114,7 @@ def goal_leg(local_rank, E, T=8, H=4, S=11, A=3, steps=20, warm=3, precisions=("
     mus = {}
     for prec in precisions:
         pc = capi.PREC_BF16 if prec == "bf16" else capi.PREC_FP32
-        n = steps if prec == "bf16" else max(3, steps // 4)
+        n = steps if prec == "bf16" else (fp32_steps or max(3, steps // 4))
         for _ in range(warm):
             p.handle.goal_step_batch(st, ac, T - H, capi.GOAL_PIID, pc, out=out_buf)
         if world > 1:
@@ -118,8 +123,15 @@ def goal_leg(local_rank, E, T=8, H=4, S=11, A=3, steps=20, warm=3, precisions=("
         t0 = time.perf_counter()
         for _ in range(n):
             p.handle.goal_step_batch(st, ac, T - H, capi.GOAL_PIID, pc, out=out_buf)
+        if world > 1:
+            torch.distributed.barrier()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tt.item())
+        dt /= n
         mus[prec] = out_buf[0].clone()
         res[prec] = {"ms_per_call": round(1e3 * dt, 4), "windows_per_s": round(E / dt, 1), "calls": n,
                      "mfma_frac": round(alg_flops_goal(E, T, H, S, A) / dt / 1e12 / MFMA_PEAK_TFLOPS[prec], 4)}
@@ -232,10 +244,17 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / closed-loop / shipped-config / parity side measurements")
     ap.add_argument("--shard", default="env", choices=["env", "candidates"], help="what the ranks of a multi-GPU run divide")
     ap.add_argument("--strong", action="store_true", help="--shard candidates: keep the global candidate count fixed")
-    ap.add_argument("--config", default="c2", choices=["c2", "c4"], help="c4: BASELINE configs[3] (halfcheetah N=16384 H=32 T=64, candidate-sharded)")
-    ap.add_argument("--with-c4", action="store_true",
-                    help="--shard env at N > 1 GPUs: also run BASELINE configs[3] candidate-sharded through RCCL on the same ranks (a "
-                         "few steps; off by default: the collective path has run on one GPU only, a hang there must not cost the run)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"],
+                    help="c4: BASELINE configs[3] (halfcheetah N=16384 H=32 T=64, candidate-sharded); c5: BASELINE configs[4] (zero-shot "
+                         "goal reaching, 64 envs x 1024 = 8192 windows per GPU per call, environment-sharded, no collective)")
+    ap.add_argument("--windows", type=int, default=8192, help="--config c5: zero-shot windows per GPU and call")
+    ap.add_argument("--with-c4", action="store_true", help="(kept for old command lines: the collective legs now run by default)")
+    ap.add_argument("--no-collective-legs", action="store_true",
+                    help="N > 1 GPUs, --shard env: skip the candidate-sharded legs (c4, c2 strong) that run through RCCL's all-gather "
+                         "behind the headline measurement")
+    ap.add_argument("--collective-timeout", type=float, default=300.0,
+                    help="wall-clock limit of the collective legs: past it rank 0 prints the headline line with "
+                         '"c4": {"error": "timeout"} and every rank exits with code 0')
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alone-pass", action="store_true",
                     help="skip the extra instrumented pass with the candidate halves serialised (roofline.alone); "
@@ -257,18 +276,23 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.dry_run:
         import torch.distributed as dist
+        out = {"metric": "MPC plan-steps/sec (N=1024, H=16, hopper-medium-v2)", "dry_run": True, "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup}
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo")
             t = torch.tensor([rank + 1.0])
             dist.all_reduce(t)
             assert float(t) == world * (world + 1) / 2
-            dist.destroy_process_group()
         if os.environ.get("M3PC_BENCH_FAIL_RANK") == str(rank):
             raise SystemExit(3)
+        if world > 1 and not args.no_collective_legs:
+            finish_with_collective_legs(args, out, rank, local_rank, world)
+            return
         if rank == 0:
-            print(json.dumps({"metric": "MPC plan-steps/sec (N=1024, H=16, hopper-medium-v2)", "dry_run": True, "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup}), flush=True)
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
         return
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -280,6 +304,8 @@ def main():
     from m3pc_amd.planner import HipPlanner
     import types
 
+    if args.config == "c5":
+        return main_c5(args, rank, local_rank, world)
     if args.config == "c4":
         args.env, args.guidance, args.candidates, args.horizon, args.traj_length = "halfcheetah", "rtg_guiding", 16384, 32, 64
         args.shard, args.strong = "candidates", True
@@ -430,10 +456,7 @@ def main():
                 "step_alg_bytes": alg_bytes(n_local, T, S, A),
                 "step_hbm_frac_alg": round(alg_bytes(n_local, T, S, A) / step_s / 1e9 / HBM_PEAK_GBS, 5)}
 
-    c4 = None
-    if world > 1 and not shard_cand and args.config == "c2" and args.with_c4:
-        c4 = c4_sharded(rank, local_rank, world)
-
+    out = None
     if rank == 0:
         if shard_cand:
             par = f"candidate-shard x{world}" + (" (strong)" if args.strong else " (weak)")
@@ -456,6 +479,9 @@ def main():
                                          else f"top-{args.rescore_topk}") + f"); {flight_txt}; window resident in HBM",
                           "candidates_per_gpu": n_local, "global_candidates": n_global, "horizon": H, "traj_length": T,
                           "steps_in_flight": depth, "settle_steps": args.settle, "parallelism": par},
+               # what `value` is and is not: the rate of INDEPENDENT plan steps with `steps_in_flight` of them in
+               # flight; one step alone -- what a single environment's loop can use -- is serial_steps_per_s
+               "serial_steps_per_s": round(1e3 / latency["p50"], 2),
                "latency_ms": latency, "roofline": roofline,
                "rescore": {"mode": args.rescore, "n_mean": round(sum(n_re) / max(len(n_re), 1), 2), "n_max": max(n_re) if n_re else None,
                            "delta": planner.last.get("delta"), "delta_grown": planner.delta_grown,
@@ -463,8 +489,6 @@ def main():
         if shard_cand and args.strong:
             # what every rank repeats whatever the shard size: the policy pass and the re-score + select
             out["replicated_ms"] = round(latency["p50"] - candidate_only_ms(planner, mode, states, actions, rewards, h), 4)
-        if c4 is not None:
-            out["c4"] = c4
         if world == 1 and not args.no_extras:
             try:
                 out.update(extras(args, dims, cfg, hist, planner, S, A))
@@ -478,10 +502,202 @@ def main():
                     out["parity"] = parity(args, dims, cfg, hist, ref, eps)
                 except Exception as e:
                     out["parity_error"] = repr(e)[:300]
+    if world > 1 and not shard_cand and args.config == "c2" and not args.no_collective_legs:
+        planner.handle.close()
+        finish_with_collective_legs(args, out, rank, local_rank, world)
+        return
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def finish_with_collective_legs(args, out, rank, local_rank, world):
+    """Behind the headline measurement of an environment-sharded multi-GPU run: the candidate-sharded legs (RCCL all-gather
+    on the data path) under a wall-clock watchdog, then rank 0's ONE JSON line.  A leg that hangs or fails costs its own
+    entry, never the headline: on timeout rank 0 prints the line with {"error": "timeout"} and every rank exits with code 0."""
+    def on_timeout():
+        if rank == 0:
+            out["c4"] = {"error": "timeout"}
+            out["c2_candidates_strong"] = {"error": "timeout"}
+            out["collective_timeout_s"] = args.collective_timeout
+            print(json.dumps(out), flush=True)
+
+    def legs():
+        try:
+            res = collective_legs(args, rank, local_rank, world)
+        except Exception as e:  # (every rank fails alike or the others time out)
+            res = {"c4": {"error": repr(e)[:300]}}
+        torch.distributed.barrier()
+        return res
+
+    res = run_guarded(legs, args.collective_timeout, on_timeout)
+    if rank == 0:
+        out.update(res)
+        print(json.dumps(out), flush=True)
+    run_guarded(torch.distributed.destroy_process_group, 30.0, lambda: None)
+
+
+def main_c5(args, rank, local_rank, world):
+    """--config c5: BASELINE configs[4], zero-shot goal reaching.  64 environments x 1024 windows over 8 GPUs = 8192 windows per
+    GPU and call; the windows are independent, so the ranks share nothing (environment sharding, no collective): weak scaling,
+    value = windows planned per second over all ranks."""
+    E = args.windows
+    T, H, S, A = 8, 4, 11, 3   # zeroshot_omtm/config_hopper.yaml:6,78
+    precs = (args.precision,) if args.no_extras else (("bf16", "fp32") if args.precision == "bf16" else ("fp32",))
+    res = goal_leg(local_rank, E, T, H, S, A, steps=args.steps, warm=max(args.warmup, 1), precisions=precs, world=world,
+                   fp32_steps=max(3, args.steps // 8))
+    if rank == 0:
+        r = res[args.precision]
+        out = {"metric": "zero-shot goal-reaching windows/sec (zeroshot_omtm config_hopper, 64 envs x N=1024)",
+               "value": round(world * r["windows_per_s"], 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": r["ms_per_call"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": args.precision, "data": "synthetic",
+               "config": {"workload": res["what"], "windows_per_gpu": E, "traj_length": T, "horizon": H,
+                          "parallelism": f"env-shard x{world} (no collective)" if world > 1 else "1 GPU"},
+               "roofline": {"bound": "mfma", "achieved": round(res["alg_tflop_per_call"] / (r["ms_per_call"] * 1e-3), 2),
+                            "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s", "frac": r["mfma_frac"], "traffic": None,
+                            "kernel": "whole call (two chained pruned forwards): F_alg / wall time per call"},
+               "c5": res}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def plan_leg(local_rank, env, guidance, N, H, T, steps=20, warm=4, settle=12, depth=2, group=None, what=""):
+    """Another BASELINE plan-step shape on this GPU (or, with `group`, candidate-sharded over the ranks of this run): `steps`
+    plan steps, `depth` in flight (0: serial -- a sharded step gathers on the current stream), with the F_alg-based MFMA fraction."""
+    import types
+
+    from m3pc_amd import capi, synth
+    from m3pc_amd.planner import HipPlanner
+    from m3pc_amd.dist import shard_range, world_info
+    S, A = synth.ENV_DIMS[env]
+    critic = guidance == "critic_lambda_guiding"
+    dims = synth.Dims(S, A, T)
+    cfg = types.SimpleNamespace(traj_length=T, action_samples=N, horizon=H, discount=0.99, temperature=1.0 if critic else 0.01,
+                                lmbda=0.6, plan_guidance=guidance)
+    qsd, om, os_ = synth.make_critic(dims, 0) if critic else (None, None, None)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    p = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), qsd, om, os_, precision="bf16",
+                   device=local_rank, generator=gen, group=group, pipeline_depth=max(1, min(depth, capi.SLOTS - 1)))
+    rank, world = world_info(group)
+    hist = synth.make_history(dims, 0)
+    hist["path_length"] = 500
+    s_, a_, r_, h, rtg = p.assemble_window(hist, rtg=3.0)
+    mode = capi.MODE_CRITIC if critic else capi.MODE_RTG
+
+    def run(k):
+        if depth == 0:
+            for _ in range(k):
+                p._guide(mode, s_, a_, r_, rtg, h, 0.6)
+            return
+        flight = deque()
+        for _ in range(k):
+            flight.append(p._issue(mode, s_, a_, r_, rtg, h, 0.6, pipelined=True, inputs_ready=True))
+            if len(flight) > depth:
+                flight.popleft().pair()
+        while flight:
+            flight.popleft().pair()
+
+    run(settle)
+    run(warm)
+    if world > 1:
+        torch.distributed.barrier(group)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    if world > 1:
+        torch.distributed.barrier(group)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
+        dt = float(t.item())
+    ms = 1e3 * dt / steps
+    n_local = shard_range(N, rank, world)[1]
+    f_rank = alg_flops(n_local, T, H, S, A, mode="critic" if critic else "rtg")
+    out = {"what": what or f"{env} shapes (S={S},A={A}) {guidance} N={N} H={H} T={T} bf16",
+           "ms_per_step": round(ms, 4), "plan_steps_per_s": round(1e3 / ms, 2), "steps": steps, "steps_in_flight": depth,
+           "alg_tflop_per_step_per_gpu": round(f_rank / 1e12, 4), "mfma_frac": round(f_rank / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["bf16"], 4),
+           "argmax": int(p.last["argmax"].item()), "n_rescored": p.last.get("n_rescored")}
+    if world > 1:
+        out["candidates_per_gpu"] = n_local
+        out["replicated_ms"] = round(_replicated_ms(p, mode, s_, a_, r_, rtg, h), 4)
+    p.handle.close()
+    return out
+
+
+def _replicated_ms(planner, mode, states, actions, rewards, rtg, h):
+    """What every rank of a candidate-sharded step repeats whatever the shard size (policy pass, re-score + select): one
+    serial step minus the sharded part alone."""
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(8)]
+    for e0, e1 in pairs:
+        e0.record()
+        planner._guide(mode, states, actions, rewards, rtg, h, 0.6)
+        e1.record()
+    torch.cuda.synchronize()
+    lat = sorted(e0.elapsed_time(e1) for e0, e1 in pairs)
+    return lat[len(lat) // 2] - candidate_only_ms(planner, mode, states, actions, rewards, h)
+
+
+def rccl_ranks_seen(group=None):
+    """The world size as observed INSIDE a collective of the data path's kind (all_gather_into_tensor on the compute stream):
+    every rank contributes its rank id; the count of distinct ids that arrived."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    mine = torch.tensor([float(dist.get_rank(group))], device=dev)
+    out = torch.full((world,), -1.0, device=dev)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return int(torch.unique(out[out >= 0]).numel())
+
+
+def collective_legs(args, rank, local_rank, world):
+    """The candidate-sharded configurations of a multi-GPU run, through RCCL's all-gather on the data path (north_star:
+    "candidate batches shard across the GPUs with an RCCL all-gather of per-shard scores"): BASELINE configs[3] (halfcheetah
+    N=16384 H=32 T=64, strong scaling) and the headline shape with its 1024 candidates sharded (strong; `replicated_ms` is what
+    caps it).  Serial steps: the gather sits on the step's path."""
+    grp = torch.distributed.group.WORLD
+    res = {"rccl_ranks_seen": rccl_ranks_seen(grp)}
+    if args.dry_run:
+        if os.environ.get("M3PC_BENCH_HANG_LEG"):
+            time.sleep(3600)
+        res["c4"] = {"dry_run": True}
+        res["c2_candidates_strong"] = {"dry_run": True}
+        return res
+    res["c4"] = plan_leg(local_rank, "halfcheetah", "rtg_guiding", 16384, 32, 64, steps=12, warm=3, settle=6, depth=0, group=grp,
+                         what=f"BASELINE configs[3]: halfcheetah shapes rtg_guiding N=16384 H=32 T=64 bf16, candidates sharded over {world} "
+                              f"ranks, one RCCL all-gather of scores + first actions per step, serial steps (strong scaling)")
+    res["c2_candidates_strong"] = plan_leg(local_rank, "hopper", "rtg_guiding", 1024, 16, 32, steps=20, warm=4, settle=12, depth=0, group=grp,
+                                           what=f"the headline shape with its 1024 candidates sharded over {world} ranks (strong), one "
+                                                "RCCL all-gather per step, serial steps")
+    return res
+
+
+def run_guarded(fn, timeout_s, on_timeout):
+    """fn() with a watchdog: when it has not returned after timeout_s seconds (a collective that never completes cannot be
+    interrupted from Python), on_timeout() runs on the watchdog thread and the process ends with exit code 0 -- the
+    headline measurement is done by then and must not be lost with the side legs."""
+    import threading
+    done = threading.Event()
+
+    def watch():
+        if not done.wait(timeout_s):
+            try:
+                on_timeout()
+            finally:
+                sys.stdout.flush()
+                os._exit(0)
+
+    threading.Thread(target=watch, daemon=True).start()
+    try:
+        return fn()
+    finally:
+        done.set()
 
 
 def candidate_only_ms(planner, mode, states, actions, rewards, h):
@@ -503,42 +719,6 @@ def candidate_only_ms(planner, mode, states, actions, rewards, h):
         ts.append(e0.elapsed_time(e1))
     ts.sort()
     return ts[len(ts) // 2]
-
-
-def c4_sharded(rank, local_rank, world, steps=12, warm=3):
-    """BASELINE configs[3] on the ranks of this run: halfcheetah shapes, rtg_guiding, N=16384, H=32, T=64, the candidates sharded
-    over the ranks, one RCCL all-gather of scores + first actions per step (serial steps: the collective sits on the path)."""
-    import types
-
-    from m3pc_amd import capi, synth
-    from m3pc_amd.planner import HipPlanner
-    S, A = synth.ENV_DIMS["halfcheetah"]
-    dims = synth.Dims(S, A, 64)
-    cfg = types.SimpleNamespace(traj_length=64, action_samples=16384, horizon=32, discount=0.99, temperature=0.01, lmbda=0.6,
-                                plan_guidance="rtg_guiding")
-    gen = torch.Generator(device="cuda").manual_seed(1)
-    p = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None, precision="bf16",
-                   device=local_rank, generator=gen, group=torch.distributed.group.WORLD)
-    hist = synth.make_history(dims, 0)
-    hist["path_length"] = 500
-    s, a, r, h, rtg = p.assemble_window(hist, rtg=3.0)
-    for _ in range(warm):
-        p._guide(capi.MODE_RTG, s, a, r, rtg, h, 0.6)
-    torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        p._guide(capi.MODE_RTG, s, a, r, rtg, h, 0.6)
-    torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-    torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
-    am = int(p.last["argmax"].item())
-    p.handle.close()
-    ms = 1e3 * float(dt.item()) / steps
-    return {"what": f"BASELINE configs[3]: halfcheetah shapes rtg_guiding N=16384 H=32 T=64 bf16, candidates sharded over {world} ranks "
-                    f"({16384 // world} per GPU), one RCCL all-gather per step, serial steps",
-            "ms_per_step": round(ms, 4), "plan_steps_per_s": round(1e3 / ms, 2), "steps": steps, "argmax": am}
 
 
 def _time_calls(fn, n, warm=3):
@@ -675,6 +855,18 @@ def extras(args, dims, cfg, hist, planner, S, A):
         out["batched"] = {"what": "action_sample_batch: E env windows x N=%d candidates per call, one pipelined plan step per window "
                                   "(incl. host window assembly and H2D copies; the call returns when all E are resolved)" % cfg.action_samples,
                           **bat}
+    if args.precision == "bf16" and args.config == "c2" and cfg.plan_guidance == "rtg_guiding":
+        # the other BASELINE configurations on this GPU, each with its F_alg-based MFMA fraction
+        for name, fn in (("c5", lambda: goal_leg(0, 8192, steps=20, fp32_steps=4)),
+                         ("c3", lambda: plan_leg(0, "walker2d", "critic_lambda_guiding", 4096, 16, 32, steps=20, settle=12,
+                                                 what="BASELINE configs[2]: walker2d shapes critic_lambda_guiding N=4096 H=16 T=32 bf16")),
+                         ("c4_shard", lambda: plan_leg(0, "halfcheetah", "rtg_guiding", 2048, 32, 64, steps=20, settle=12,
+                                                       what="one rank's share of BASELINE configs[3] as a plan step of its own: halfcheetah "
+                                                            "shapes rtg_guiding, 2048 of the 16384 candidates, H=32 T=64 bf16"))):
+            try:
+                out[name] = fn()
+            except Exception as e:
+                out[name] = {"error": repr(e)[:300]}
     return out
 
 

@@ -33,3 +33,33 @@ def test_bench_fails_when_a_rank_fails():
 def test_bench_single_process_needs_no_launcher():
     r = _run(["--gpus", "1"])
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_multi_gpu_default_runs_the_collective_legs():
+    """N > 1 without flags: behind the headline, the candidate-sharded legs run through the all-gather of the data path (gloo
+    here) and the line says how many ranks that collective saw."""
+    r = _run(["--gpus", "2", "--steps", "5", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert d["rccl_ranks_seen"] == 2 and "c4" in d and "c2_candidates_strong" in d
+
+
+def test_a_hung_collective_leg_costs_its_entry_not_the_headline():
+    """A leg that never returns (a collective that hangs): the watchdog prints the headline line with the leg marked as timed
+    out and every rank exits with code 0."""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--steps", "5", "--warmup", "1", "--collective-timeout", "4"], {"M3PC_BENCH_HANG_LEG": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert time.time() - t0 < 120
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["c4"] == {"error": "timeout"} and d["n_gpus"] == 2 and d["steps"] == 5
+
+
+def test_no_collective_legs_flag():
+    r = _run(["--gpus", "2", "--no-collective-legs"])
+    assert r.returncode == 0
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "c4" not in d
