@@ -494,54 +494,47 @@ class HipPlanner:
         top = None
         if self.rescore == "bound":
             N = tk.er_b.numel()
-            kmin, kmax = tk.kmin, tk.kmax
-            saturated = False
-            n_first_need = None
-            while True:
-                shift, dev, need, margin = sl.hs_mrg.wait(tk.seq_mrg, sl.mstats)
-                need = int(need)
-                if n_first_need is None:
-                    n_first_need = need
-                redo = False
-                # delta bounds the deviation of (bf16 - fp32) from the common shift: every step checks it on its re-scored set
-                # and raises it -- for itself at once, for the steps from SLOTS later on through _adapt -- when 1.5 x what it
-                # saw is more (the same numbers, hence the same decision, on every rank and at any pipeline depth)
-                if self._delta_fixed is None and 1.5 * dev > tk.delta:
-                    tk.delta = 1.5 * dev
-                    self.delta_grown += 1
-                    redo = tk.n_done < N and not saturated
-                if saturated or tk.n_done >= N:
-                    break
-                with self._on(tk):
-                    if need > tk.n_done and not redo:
-                        if need <= kmax:
-                            rs, tail = self._rescore_args(tk)
-                            hd.rescore(*rs, tk.top[tk.n_done : need], *tail, N, slot=sl.i, out=sl.f_top[tk.n_done : need],
-                                       want_actions=False)
-                            tk.n_done = need
-                            redo = True
-                        else:
-                            top = self._rescore_window_set(tk, need)
-                            saturated = True
-                            continue
-                    if not redo:
-                        break
-                    self._merge(tk, tk.n_done)
-                    tk.sel = hd.select(tk.er, tk.a0, float(cfg.temperature), tk.expo, out=tk.outbuf)
-                    if tk.tchain is not None:
-                        sl.ev_done.record(tk.tchain)
-            n_re = int(top.numel()) if top is not None else tk.n_done
-            if top is None:
-                top = tk.top[:n_re]
+            planner = self
+
+            class _TicketOps:
+                top = None
+
+                def read(self):
+                    return sl.hs_mrg.wait(tk.seq_mrg, sl.mstats)
+
+                def extend(self, lo, hi):
+                    with planner._on(tk):
+                        rs, tail = planner._rescore_args(tk)
+                        hd.rescore(*rs, tk.top[lo:hi], *tail, N, slot=sl.i, out=sl.f_top[lo:hi], want_actions=False)
+                    tk.n_done = hi
+
+                def window_set(self, need, delta):
+                    tk.delta = delta
+                    with planner._on(tk):
+                        self.top = planner._rescore_window_set(tk, need)
+                    return tk.n_done
+
+                def merge_select(self, n, delta):
+                    tk.delta = delta
+                    with planner._on(tk):
+                        planner._merge(tk, n)
+                        tk.sel = hd.select(tk.er, tk.a0, float(cfg.temperature), tk.expo, out=tk.outbuf)
+                        if tk.tchain is not None:
+                            sl.ev_done.record(tk.tchain)
+
+            ops = _TicketOps()
+            extra = self._resolve_certificate(N, tk.kmax, tk.n_done, tk.delta, ops)
+            tk.delta = extra["delta"]
+            extra["n_first"] = tk.kmin
+            top = ops.top if ops.top is not None else tk.top[: extra["n_rescored"]]
+            extra["n_rescored"] = int(top.numel())
             # what this step saw feeds the steps from SLOTS later on (_adapt): the bound, and the size of the first pass
-            self._hist[tk.index] = (float(dev), min(int(n_first_need), kmax))
+            self._hist[tk.index] = (float(extra["deviation"]), min(int(extra["n_in_window"]), tk.kmax))
             for i in [i for i in self._hist if i < tk.index - 64]:
                 # (old enough that every step still to come would count it anyway: fold its deviation into the base bound)
                 if self._delta_fixed is None:
                     self._delta0 = max(self._delta0, 1.5 * self._hist[i][0])
                 del self._hist[i]
-            extra = dict(n_rescored=n_re, n_in_window=n_first_need, min_margin_outside=float(margin), delta=tk.delta, n_first=kmin,
-                         saturated=saturated, shift=shift, deviation=dev)
         elif self.rescore == "topk":
             top = tk.top[: tk.kmin]
         if tk.chain is not None:
@@ -557,16 +550,59 @@ class HipPlanner:
             sl.owner = None
         return tk.out
 
+    def _resolve_certificate(self, N, kmax, n_done, delta, ops):
+        """The certified re-score's protocol (HipPlanner.__init__: rescore="bound"), in ONE place for the pipelined ticket
+        (``_finish``) and the lock-step batch (``_action_sample_lockstep``).  A first pass has been enqueued already: the
+        ``n_done`` best candidates by bf16 score re-scored in fp32, merged, selected.  ``ops`` does the device work:
+            read()                 -> (shift, deviation, need, margin) of the LAST merge (blocks the host until they are there)
+            extend(lo, hi)         fp32 re-score of the entries [lo, hi) of the sorted candidate list
+            window_set(need)       -> (n_done, needs_merge): the list is too short -- re-score the `need` best candidates
+                                   (or, beyond 1024, every candidate) and leave the merged vector + select enqueued
+            merge_select(n, delta) merge + select again over the n re-scored entries
+        Loop: read the certificate; raise delta when this step's re-scored set deviates by more than it allows (then merge
+        again: `need` depends on delta); re-score up to `need` when the certificate asks for more; stop when it is satisfied,
+        when everything has been re-scored, or after the window-set slow path.  Returns the step's record."""
+        saturated, first_need = False, None
+        while True:
+            shift, dev, need, margin = ops.read()
+            need = int(need)
+            if first_need is None:
+                first_need = need
+            redo = False
+            # delta bounds the deviation of (bf16 - fp32) from the common shift: every step checks it on its re-scored set
+            # and raises it when 1.5 x what it saw is more (the same numbers, hence the same decision, on every rank and at
+            # any pipeline depth)
+            if self._delta_fixed is None and 1.5 * dev > delta:
+                delta = 1.5 * dev
+                self.delta_grown += 1
+                redo = n_done < N and not saturated
+            if saturated or n_done >= N:
+                break
+            if need > n_done and not redo:
+                if need <= kmax:
+                    ops.extend(n_done, need)
+                    n_done = need
+                    redo = True
+                else:
+                    if not self._warned_saturated:
+                        self._warned_saturated = True
+                        warnings.warn(f"m3pc_amd: {need} candidates may still hold the fp32 arg-max (delta={delta:.3g}, rescore_max="
+                                      f"{self.rescore_max}); re-scoring the whole window set in fp32 (slow path)")
+                    n_done = ops.window_set(need, delta)
+                    saturated = True
+                    continue
+            if not redo:
+                break
+            ops.merge_select(n_done, delta)
+        return dict(n_rescored=n_done, n_in_window=first_need, min_margin_outside=float(margin), delta=delta, saturated=saturated,
+                    shift=shift, deviation=dev)
+
     def _rescore_window_set(self, tk, need):
         """The certificate asks for more candidates than the rescore_max the list holds: re-score the whole set -- the `need`
         best candidates by bf16 score -- in chunks of the chain workspace (or, beyond 1024 of them, every candidate in fp32).
         Slow path, taken only when the bf16 noise exceeds the score spread.  Called inside the tail's stream context."""
         cfg, hd, sl = self.cfg, self.handle, tk.slot
         N = tk.er_b.numel()
-        if not self._warned_saturated:
-            self._warned_saturated = True
-            warnings.warn(f"m3pc_amd: {need} candidates may still hold the fp32 arg-max (delta={tk.delta:.3g}, rescore_max="
-                          f"{self.rescore_max}); re-scoring the whole window set in fp32 (slow path)")
         rs, tail = self._rescore_args(tk)
         cnt = min(need, N)
         if cnt <= 1024:
@@ -988,47 +1024,74 @@ class HipPlanner:
             expos = [torch.empty((N,), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
                      for _ in range(Eg)]
             sels = [self.handle.select(merged[j], acts[j, :, 0], float(cfg.temperature), expos[j]) for j in range(Eg)]
+            certs = [None] * Eg
             if self.rescore == "bound":
                 stats_h = torch.stack(mstats).cpu()  # the one host read of the group: [shift, deviation, need, margin] per window
+                planner, hdl, cap = self, self.handle, max(self.handle.max_rescore, 1)
+                disc, temp = float(cfg.discount), float(cfg.temperature)
+
+                class _WindowOps:
+                    """The device work of ``_resolve_certificate`` for window w of the group (fp32 re-scores through
+                    m3pc_score_actions on the window's own rows)."""
+
+                    def __init__(self, w):
+                        self.w, self.pending = w, None
+
+                    def read(self):
+                        w = self.w
+                        if self.pending is not None:
+                            stats_h[w], self.pending = self.pending.cpu(), None
+                        return [float(v) for v in stats_h[w]]
+
+                    def _score(self, ix):
+                        w = self.w
+                        return torch.cat([hdl.score_actions(smode, s[w], a[w], r[w], acts[w, ix[c0 : c0 + cap].long()], None, h, lmbda, disc)
+                                          for c0 in range(0, ix.numel(), cap)])
+
+                    def extend(self, lo, hi):
+                        w = self.w
+                        ftops[w] = torch.cat([ftops[w][:lo], self._score(tops[w][lo:hi])]).contiguous()
+
+                    def window_set(self, need, dlt):
+                        w = self.w
+                        cnt = min(need, N)
+                        if cnt <= 1024:  # the `need` best candidates by bf16 score, re-scored in chunks of the chain workspace
+                            vals, idx = torch.topk(er[w], cnt)
+                            tops[w], btops[w] = idx.to(torch.int32).contiguous(), vals.contiguous()
+                            ftops[w] = self._score(tops[w]).contiguous()
+                            self.merge_select(cnt, dlt)
+                            return cnt
+                        # beyond what the merge kernel lists: EVERY candidate of the window in fp32 -- the select then runs on
+                        # fp32 scores alone (a merge of the best entry with itself keeps the statistics protocol alive)
+                        er32 = hdl.score_actions(smode, s[w], a[w], r[w], acts[w], None, h, lmbda, disc).contiguous()
+                        best = torch.argmax(er32).to(torch.int32).reshape(1)
+                        bval = er32.max().reshape(1).contiguous()
+                        tops[w], btops[w], ftops[w] = best, bval, bval
+                        merged[w], self.pending = hdl.rescore_merge(er32, best, 1, bval, bval, delta=0.0)
+                        sels[w] = hdl.select(merged[w], acts[w, :, 0], temp, expos[w])
+                        return N
+
+                    def merge_select(self, n, dlt):
+                        w = self.w
+                        merged[w], self.pending = hdl.rescore_merge(er[w], tops[w], n, btops[w], ftops[w], delta=dlt)
+                        sels[w] = hdl.select(merged[w], acts[w, :, 0], temp, expos[w])
+
+                delta_first = delta
                 for w in range(Eg):
-                    n_done = counts[w]
-                    while True:
-                        dev_w, need = float(stats_h[w, 1]), int(stats_h[w, 2])
-                        grown = self._delta_fixed is None and 1.5 * dev_w > delta
-                        if grown:  # this window saw a larger deviation than the bound: raise it (for everybody from here on)
-                            delta = self._delta = 1.5 * dev_w
-                            self.delta_grown += 1
-                        if need <= n_done and not grown:
-                            break
-                        if need > n_done:
-                            cnt = min(need, N, 1024)
-                            if cnt > kmax:  # beyond the list: the `need` best candidates by bf16 score, re-scored in chunks
-                                if not self._warned_saturated:
-                                    self._warned_saturated = True
-                                    warnings.warn(f"m3pc_amd: {need} candidates may still hold the fp32 arg-max (delta={delta:.3g}); "
-                                                  "re-scoring the whole window set in fp32 (slow path)")
-                                vals, idx = torch.topk(er[w], cnt)
-                                tops[w], btops[w] = idx.to(torch.int32).contiguous(), vals.contiguous()
-                                ftops[w], n_done = torch.empty((0,), dtype=torch.float32, device=self.device), 0
-                            cap = max(self.handle.max_rescore, 1)
-                            parts = [ftops[w]]
-                            for c0 in range(n_done, cnt, cap):
-                                ix = tops[w][c0 : min(cnt, c0 + cap)].long()
-                                parts.append(self.handle.score_actions(smode, s[w], a[w], r[w], acts[w, ix], None, h, lmbda,
-                                                                       float(cfg.discount)))
-                            ftops[w], n_done = torch.cat(parts).contiguous(), cnt
-                        merged[w], st_w = self.handle.rescore_merge(er[w], tops[w], n_done, btops[w], ftops[w], delta=delta)
-                        sels[w] = self.handle.select(merged[w], acts[w, :, 0], float(cfg.temperature), expos[w])
-                        stats_h[w] = st_w.cpu()
-                        if n_done >= min(N, 1024):
-                            break
-                    counts[w] = n_done
+                    ops_w = _WindowOps(w)
+                    if delta > delta_first:  # an earlier window of the group raised the bound: this window's certificate again, under it
+                        ops_w.merge_select(counts[w], delta)
+                    certs[w] = self._resolve_certificate(N, kmax, counts[w], delta, ops_w)
+                    if certs[w]["delta"] > delta:  # this window saw a larger deviation than the bound: raised for everybody from here on
+                        delta = self._delta = certs[w]["delta"]
+                    counts[w] = certs[w]["n_rescored"]
             for j, i in enumerate(ids):
                 p, ev, am, si, sa = sels[j]
                 out[i] = ev if eval else sa[0]
                 info[i] = dict(expect_return=merged[j], argmax=am, sample_idx=si, eval_action=ev, sample_action=sa, horizon=h,
-                               n_rescored=None if stats_h is None else counts[j],
-                               min_margin_outside=None if stats_h is None else float(stats_h[j, 3]),
+                               n_rescored=None if certs[j] is None else counts[j],
+                               min_margin_outside=None if certs[j] is None else certs[j]["min_margin_outside"],
+                               saturated=None if certs[j] is None else certs[j]["saturated"],
                                delta=self._delta)
         self.last = dict(windows=info, delta=self._delta)
         return out
