@@ -136,7 +136,7 @@ class HipPlanner:
             only candidates that can still beat f* (m3pc_rescore_merge).  need <= what was re-scored certifies the arg-max; else
             the candidates up to ``need`` are re-scored too (a second pass, at most ``rescore_max`` through the list; beyond
             that the whole set goes through a chunked slow path with a warning, ``last["saturated"]``).  delta is calibrated
-            per weight load on 64 candidates scored in both arithmetics (1.5 x the largest deviation from the median), checked
+            per weight load on 256 candidates scored in both arithmetics (1.5 x the largest deviation from the median), checked
             on every step's re-scored set and raised when 1.5 x what that step saw is more (``delta_grown``), or fixed by
             ``rescore_delta``.  ``planner.last`` reports n_rescored, n_in_window (the first certificate's count),
             min_margin_outside (the threshold's margin over the best bf16 score NOT re-scored, >= 0 when certified), shift,
@@ -160,7 +160,7 @@ class HipPlanner:
         hidden = 0 if q_state_dict is None else q_state_dict["q1.net.0.weight"].shape[0]
         nw = max(int(max_windows), 1)
         # chain workspace: the fp32 re-score sets (all windows of a lock-step batch together), the calibration subset
-        self._n_cal = min(64, N)
+        self._n_cal = min(256, N)  # (r4 sweep: with 64 the bound was exceeded by some candidate in 9 % of 320 trials)
         max_rescore = max(int(rescore_max) * nw, int(rescore_topk), self._n_cal, 1) if precision == "bf16" else 1
         self._max_batch = max(int(max_batch), nw, 1)
         self.handle = capi.Handle(S, A, T, n_embd, n_head, n_enc_layer, n_dec_layer,
@@ -213,6 +213,7 @@ class HipPlanner:
         self._bf16_offset = 0.0     # test hook: a constant added to the bf16 scores before the re-score
         self._predrawn = None       # (mode, h, eps, expo) drawn by action_sample ahead of the window copy
         self._stage, self._stage_i = None, 0  # two pinned window staging buffers (+ the event of the copy that read each last)
+        self._ev_main = None        # recorded behind the last use of the chain workspaces on the CALLER's stream (_mark_main)
 
     # ---------------------------------------------------------------------------------------- weights
     def load_state_dict(self, state_dict):
@@ -348,6 +349,15 @@ class HipPlanner:
         for tk in [sl.owner for sl in self._slots if sl.owner is not None and sl.owner.chain is not None]:
             self._finish(tk)
 
+    def _mark_main(self):
+        """The current stream has just used the library's chain workspaces (a serial plan step's fp32 chains, a generic
+        forward, the zero-shot calls): the chain streams of the pipelined steps that follow must not start in them before it
+        is through.  (Found by the soak test: in fp32 mode nothing makes the host wait per step, and the policy pass of the
+        next plan_async on the chain stream overwrote the workspace of a serial step still running on the caller's stream.)"""
+        if self._ev_main is None:
+            self._ev_main = torch.cuda.Event()
+        self._ev_main.record(torch.cuda.current_stream(self.device))
+
     def _guide(self, mode: int, states, actions, rewards, rtg: float, h: int, lmbda: float, eps=None, returns=None):
         """One plan step, serial: everything on the current stream, results when the call returns (device-resident)."""
         return self._issue(mode, states, actions, rewards, rtg, h, lmbda, eps=eps, returns=returns, pipelined=False).result()
@@ -396,6 +406,8 @@ class HipPlanner:
             self._predrawn = None
             if chain is not None:
                 chain.wait_event(sl.ev_done)  # (see _Slot.ready: the slot's buffers are free once its previous owner is done)
+                if self._ev_main is not None:
+                    chain.wait_event(self._ev_main)  # (_mark_main: the caller's stream was in the policy workspace)
             if eps is None:
                 eps = self._draw_eps(mode, h, sl.eps_buf if chain is not None else None)
             tk.eps = eps = eps.reshape(N, -1, A)
@@ -427,6 +439,7 @@ class HipPlanner:
                 self._enqueue_tail(prev)
         else:
             self._enqueue_tail(tk)
+            self._mark_main()
         return tk
 
     def _rescore_args(self, tk):
@@ -443,6 +456,8 @@ class HipPlanner:
         tk.tail_enqueued = True
         if tk.tchain is not None:
             tk.tchain.wait_event(sl.ev_cand)  # (the candidate pass waited for the policy pass: ordered behind both)
+            if self._ev_main is not None:
+                tk.tchain.wait_event(self._ev_main)  # (_mark_main: the caller's stream was in the re-score workspace)
         with self._on(tk):
             if tk.deferred:
                 hd.candidate_join(sl.i)
@@ -539,6 +554,8 @@ class HipPlanner:
             top = tk.top[: tk.kmin]
         if tk.chain is not None:
             torch.cuda.current_stream(self.device).wait_event(sl.ev_done)
+        else:
+            self._mark_main()  # (a serial step's second re-score passes ran on the caller's stream)
         p, eval_action, argmax, sample_idx, sample_action = tk.sel
         res = tk.res
         self.last = dict(expect_return=tk.er, expect_return_bf16=tk.er_b if self.rescore != "none" else None, p=p, argmax=argmax,
@@ -701,6 +718,7 @@ class HipPlanner:
         toks = [self.handle.tokenize(capi.STATES, s[None]), a[None], None, self._returns_tokens(rtg, ret)]
         from .masks import create_rcbc_mask, mask_rows
         out = self.handle.forward(toks, mask_rows(create_rcbc_mask(T, "cpu", T - h)), want=("actions",))
+        self._mark_main()
         mu, sd = out["actions"]
         dist_ = SquashedNormal(mu.unsqueeze(2), sd.unsqueeze(2))
         eps = self._eps(tuple(dist_.loc.shape))
@@ -745,6 +763,7 @@ class HipPlanner:
     def _policy_from(self, toks, masks, h, eval):
         from .masks import mask_rows
         mu, sd = self.handle.forward(toks, mask_rows(masks), want=("actions",))["actions"]
+        self._mark_main()
         dist_ = SquashedNormal(mu.unsqueeze(2), sd.unsqueeze(2))
         if eval:
             return dist_.mean[0, self.T - h]
@@ -774,6 +793,7 @@ class HipPlanner:
         # both forwards and the hand-over between them in one library call on the raw window (m3pc_goal_step)
         mu, sd, inferred, window = self.handle.goal_step(s[None], a[None], r[None], [rtg_v], mask_rows(create_pi_mask(T, "cpu", idx)),
                                                          mask_rows(create_fid_mask(T, "cpu", idx)), idx)
+        self._mark_main()
         self.last = dict(state_inference=inferred, window_states=window[0])
         dist_ = SquashedNormal(mu.unsqueeze(2), sd.unsqueeze(2))
         if eval:
@@ -861,6 +881,7 @@ class HipPlanner:
             out[torch.tensor(ids, device=self.device)] = act[:, idx, 0]
             for j, i in enumerate(ids):
                 infer[i] = inferred[j]
+        self._mark_main()
         self.last = dict(state_inference=infer)
         return out
 
@@ -1093,6 +1114,7 @@ class HipPlanner:
                                min_margin_outside=None if certs[j] is None else certs[j]["min_margin_outside"],
                                saturated=None if certs[j] is None else certs[j]["saturated"],
                                delta=self._delta)
+        self._mark_main()
         self.last = dict(windows=info, delta=self._delta)
         return out
 
@@ -1133,6 +1155,7 @@ class HipPlanner:
             std = elite.std(dim=0) if k > 1 else torch.zeros_like(mean)
             trace.append(dict(expect_return=er, top=top, mean=mean, std=std))
             cand = torch.clamp(mean[None] + std[None] * noise[it + 1], -1.0, 1.0)
+        self._mark_main()
         self.last = dict(cem=trace, candidates=cand)
         return cand[0, 0][None], mean[0]
 

@@ -1,0 +1,157 @@
+"""The certified bf16 -> fp32 re-score, quantified, and a soak of the step pipeline (4b).
+
+Sweep: for many (weight seed, window, eps) trials the bf16 planner's step is compared with a FULL fp32 pass over the same
+candidates: the arg-max must be the reference's in every trial (learner.py:318-325 picks by it; "argmax indices bit-exact" is
+the north star's bar), and the largest deviation of (bf16 - fp32) from the common shift over ALL candidates -- not only the
+re-scored set -- is recorded relative to the bound delta the step used.  The table goes to gpurun_out/ (copied to profiles/).
+
+Soak: a few hundred plan steps issued through plan_async / action_sample / load_state_dict in random order and at random
+pipeline depths, with allocator churn on the caller's stream between the issues, against the same sequence planned serially:
+every result bit-identical (the test that would have caught the recycled per-step tensor of commit db93b75)."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from m3pc_amd import capi, synth
+from m3pc_amd.planner import HipPlanner
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(T, N, H):
+    return types.SimpleNamespace(traj_length=T, action_samples=N, horizon=H, discount=0.99, temperature=0.01, lmbda=0.6,
+                                 plan_guidance="rtg_guiding", device="cuda")
+
+
+def _window(dims, i):
+    h = synth.make_history(dims, i % 7)
+    h["path_length"] = [500, 37, 321, 998, 640, 77, 250, 123, 864][i % 9]
+    return h
+
+
+@pytest.mark.parametrize("N,T,H,seeds,per_seed", [(1024, 32, 16, 5, 40), (256, 32, 16, 4, 30)])
+def test_certificate_sweep_argmax_and_deviation(N, T, H, seeds, per_seed):
+    dims = synth.Dims(11, 3, T)
+    rows = []
+    mismatches = 0
+    for ws in range(seeds):
+        sd, st = synth.make_state_dict(dims, ws), synth.make_tokenizer_stats(dims, ws)
+        pb = HipPlanner(_cfg(T, N, H), sd, st, None, precision="bf16", generator=torch.Generator(device="cuda").manual_seed(1))
+        pf = HipPlanner(_cfg(T, N, H), sd, st, None, precision="fp32", generator=torch.Generator(device="cuda").manual_seed(1))
+        for t in range(per_seed):
+            hist = _window(dims, t)
+            eps = synth.make_eps(N, dims, 1000 * ws + t).cuda()
+            rtg = 3.0 + 0.25 * (t % 5)
+            sb, ab, rb, h, g = pb.assemble_window(hist, rtg=rtg)
+            pb._guide(capi.MODE_RTG, sb, ab, rb, g, h, 0.6, eps=eps)
+            lb = pb.last
+            b, merged = lb["expect_return_bf16"].clone(), lb["expect_return"].clone()
+            am_b = int(lb["argmax"].item())
+            pf._guide(capi.MODE_RTG, sb, ab, rb, g, h, 0.6, eps=eps)
+            f = pf.last["expect_return"]
+            am_f = int(pf.last["argmax"].item())
+            d = b - f
+            c = float(lb["shift"])
+            ratio = float((d - c).abs().max()) / float(lb["delta"])
+            gap = torch.topk(f, 2).values
+            mismatches += int(am_b != am_f)
+            # the re-scored entries of the merged vector ARE the fp32 scores
+            top = lb["topk"].long()
+            assert float((merged[top] - f[top]).abs().max()) <= 5e-5 * float(f.abs().max())
+            rows.append(dict(weight_seed=ws, trial=t, argmax_match=am_b == am_f, ratio=round(ratio, 4), delta=round(float(lb["delta"]), 4),
+                             n_rescored=int(lb["n_rescored"]), need_first=int(lb["n_in_window"]), saturated=bool(lb["saturated"]),
+                             top1_top2_gap=round(float(gap[0] - gap[1]), 4), score_sigma=round(float(f.std()), 3)))
+        pb.handle.close()
+        pf.handle.close()
+    ratios = np.array([r["ratio"] for r in rows])
+    summary = dict(config=f"hopper rtg_guiding N={N} T={T} H={H}", trials=len(rows), argmax_mismatches=mismatches,
+                   ratio_max=float(ratios.max()), ratio_p99=float(np.quantile(ratios, 0.99)), ratio_median=float(np.median(ratios)),
+                   trials_with_ratio_above_1=int((ratios > 1).sum()),
+                   n_rescored_mean=float(np.mean([r["n_rescored"] for r in rows])), n_rescored_max=int(max(r["n_rescored"] for r in rows)),
+                   saturated_trials=int(sum(r["saturated"] for r in rows)),
+                   what="ratio = max over ALL candidates of |(bf16 - fp32) - shift| / delta of the step; > 1 means a candidate outside "
+                        "the bound existed in that trial (the arg-max may still be right: it needs such a candidate inside the gap)")
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, f"r04_certificate_sweep_N{N}.json"), "w") as fh:
+            json.dump(dict(summary=summary, rows=rows), fh, indent=0)
+    print(json.dumps(summary))
+    assert len(rows) >= 120
+    assert mismatches == 0, summary
+
+
+def _churn(rng, keep):
+    """Allocator traffic on the CALLER's stream between two issues: blocks of random sizes allocated, written, some kept for
+    a while, most freed at once (what a rollout loop's own tensor code does around the planner)."""
+    for _ in range(int(rng.integers(1, 5))):
+        n = int(rng.choice([256, 4096, 65536, 1 << 20, 3 << 20]))
+        x = torch.empty((n,), device="cuda", dtype=torch.float32)
+        x.fill_(float(rng.random()))
+        y = x * 2.0 + 1.0
+        if rng.random() < 0.3:
+            keep.append(y)
+    while len(keep) > 6:
+        keep.pop(int(rng.integers(0, len(keep))))
+
+
+@pytest.mark.parametrize("precision,N,T,H,steps", [("bf16", 1024, 32, 16, 160), ("fp32", 256, 16, 8, 160), ("bf16", 256, 16, 8, 200)])
+def test_pipeline_soak_with_allocator_churn(precision, N, T, H, steps):
+    dims = synth.Dims(11, 3, T)
+    rng = np.random.default_rng(7)
+    script = []
+    for i in range(steps):
+        u = rng.random()
+        if u < 0.03 and i > 5:
+            script.append(("load", int(rng.integers(0, 3))))
+        elif u < 0.25:
+            script.append(("sync", int(rng.integers(0, 50))))
+        else:
+            script.append(("async", int(rng.integers(0, 50)), int(rng.integers(1, 4))))  # window, depth limit
+    sds = [synth.make_state_dict(dims, k) for k in range(3)]
+
+    def planner():
+        return HipPlanner(_cfg(T, N, H), sds[0], synth.make_tokenizer_stats(dims, 0), None, precision=precision,
+                          generator=torch.Generator(device="cuda").manual_seed(21), pipeline_depth=3)
+
+    # the serial order: every step one blocking action_sample
+    ps = planner()
+    serial = []
+    for op in script:
+        if op[0] == "load":
+            ps.load_state_dict(sds[op[1]])
+            serial.append(None)
+        else:
+            serial.append(ps.action_sample(_window(dims, op[1]), plan=True, eval=(op[1] % 2 == 0), rtg=3.0).clone())
+    ps.handle.close()
+    # the same script, pipelined at varying depth, with allocator churn on the caller's stream
+    pp = planner()
+    got = [None] * len(script)
+    flight = []
+    keep = []
+    crng = np.random.default_rng(11)
+
+    def resolve_one():
+        i, tk = flight.pop(0)
+        got[i] = tk.result().clone()
+
+    for i, op in enumerate(script):
+        _churn(crng, keep)
+        if op[0] == "load":
+            pp.load_state_dict(sds[op[1]])  # resolves what is in flight first (the tickets keep their results)
+        elif op[0] == "sync":
+            got[i] = pp.action_sample(_window(dims, op[1]), plan=True, eval=(op[1] % 2 == 0), rtg=3.0).clone()
+        else:
+            flight.append((i, pp.plan_async(_window(dims, op[1]), eval=(op[1] % 2 == 0), rtg=3.0)))
+            while len(flight) > op[2]:
+                resolve_one()
+    while flight:
+        resolve_one()
+    torch.cuda.synchronize()
+    bad = [i for i, (a, b) in enumerate(zip(serial, got)) if a is not None and not torch.equal(a, b)]
+    assert not bad, (bad[:10], len(bad))
+    pp.handle.close()
