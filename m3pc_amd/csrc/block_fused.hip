@@ -33,8 +33,9 @@
 // Per byte of L2->LDS traffic a 128-row tile does 128 FLOP (a 128x128 GEMM tile that also streams its A operand: 64).
 //
 // Phase order (144 phases of 32 MFMAs = one ring stage each per tile):
-//   out-proj, phase sb = 0..15:  k-steps 2 sb, 2 sb + 1 of all 16 feature tiles; the two O fragments of a phase are
-//            loaded from global memory one phase ahead (the attention output is read exactly once)
+//   out-proj, phase jn = 0..15:  all 32 k-steps of feature tile jn (one accumulator chain of 32 MFMAs); tile jn's
+//            accumulator starts at (residual + bias) of its 32 features, fetched three phases ahead: the residual rows
+//            -- two thirds of a tile's input bytes -- stream in UNDER the out-proj instead of in front of it (round 4)
 //   FFN, chunk c = 0..31 of 64 hidden units:  A0 A1 B1 B2
 //            A0 / A1: hidden tile 64c..+31 / 64c+32..+63 over the 32 k-steps of the model width (FFN1)
 //            B1 / B2: hidden k-steps 0,1 / 2,3 of the chunk into all 16 feature tiles (FFN2)
@@ -80,7 +81,7 @@ constexpr int ACT_LDS = 8;                       // LayerNorm-2 fragments of k-s
 constexpr int ACT_OFF = NSLOT * RS_B;
 // parameter tables (floats) behind them
 constexpr int T_B1 = 0, T_B2 = T_B1 + BFF, T_G2 = T_B2 + BD, T_BE2 = T_G2 + BD, T_GA = T_BE2 + BD, T_BA = T_GA + BD,
-              T_GB = T_BA + BD, T_BB = T_GB + 2 * BD, T_END = T_BB + 2 * BD;
+              T_GB = T_BA + BD, T_BB = T_GB + 2 * BD, T_BO = T_BB + 2 * BD, T_END = T_BO + BD;
 constexpr int TAB_OFF = ACT_OFF + 4 * ACT_LDS * 1024;
 constexpr int LDS_BYTES = TAB_OFF + T_END * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
@@ -96,10 +97,10 @@ __global__ __launch_bounds__(256) void pack_block_stream_kernel(const bf16_t* __
     if (gid >= FR_TOTAL * 64) return;
     const int f = gid >> 6, lane = gid & 63, r = lane & 31, h = lane >> 5;
     bf16_t v[8];
-    if (f < FR_OUT) {  // phase sb: (kk, jn) -> k-step 2 sb + kk of feature tile jn, natural k order
-        const int sb = f / 32, kk = (f % 32) / 16, jn = f % 16;
+    if (f < FR_OUT) {  // phase jn: the 32 k-steps of feature tile jn, natural k order (the operand is loaded from O)
+        const int jn = f / 32, ks = f % 32;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = Wo[(size_t)(32 * jn + r) * BD + 16 * (2 * sb + kk) + 8 * h + j];
+        for (int j = 0; j < 8; ++j) v[j] = Wo[(size_t)(32 * jn + r) * BD + 16 * ks + 8 * h + j];
     } else {
         const int g = f - FR_OUT, c = g / 128, w = g % 128;
         if (w < 64) {  // A0 | A1: hidden tile t, MFMA i (permuted k order: the operand is a LayerNorm-2 accumulator)
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
         if (tid < BD / 4) {
             const int i = 4 * tid;
             *(f32x4*)(tab + T_B2 + i) = *(const f32x4*)(p.b2 + i);
+            *(f32x4*)(tab + T_BO + i) = *(const f32x4*)(p.bo + i);
             *(f32x4*)(tab + T_G2 + i) = *(const f32x4*)(p.ln2_g + i);
             *(f32x4*)(tab + T_BE2 + i) = *(const f32x4*)(p.ln2_b + i);
             if (p.Hout || QKV || HEADS) {
@@ -284,51 +286,63 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
             }
         }
     }
-    f32x16 acc[NT];
-    {
-        // residual + out-proj bias -> accumulators, four feature tiles (64 registers of loads) per batch, the next batch's
-        // loads in flight while a batch is added
-        int rres = rld;
-        if (p.res_L > 0) {  // shared leading rows of a sequence: read from sequence 0
-            const int jj = rld % p.res_L;
-            if (jj < p.res_nshared) rres = jj;
-        }
-        const float* rrow = p.rowtab ? p.rowtab + (size_t)(rld % p.rt_mod) * BD : p.res + (size_t)rres * p.ldr;
-        f32x4 xb[2][16];
-        auto loads = [&](int bt) {
-#pragma unroll
-            for (int u = 0; u < 16; ++u) xb[bt & 1][u] = *(const f32x4*)(rrow + 32 * (4 * bt + u / 4) + 8 * (u % 4) + 4 * lh);
-        };
-        auto adds = [&](int bt) {
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const f32x4 b = *(const f32x4*)(p.bo + 32 * (4 * bt + u / 4) + 8 * (u % 4) + 4 * lh);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[4 * bt + u / 4][4 * (u % 4) + i] = xb[bt & 1][u][i] + b[i];
-            }
-        };
-        loads(0);
-        loads(1);
-        __builtin_amdgcn_sched_barrier(0);
-        adds(0);
-        __builtin_amdgcn_sched_barrier(0);
-        loads(2);
-        __builtin_amdgcn_sched_barrier(0);
-        adds(1);
-        __builtin_amdgcn_sched_barrier(0);
-        loads(3);
-        __builtin_amdgcn_sched_barrier(0);
-        adds(2);
-        __builtin_amdgcn_sched_barrier(0);
-        adds(3);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    u32x4 ofr[KS];  // O fragments (B operand of the out-proj): dead after it, the LayerNorm-2 fragments take their place
+    // O fragments (B operand of the out-proj): all 32 k-steps, needed from the first phase on.  The residual rows come tile
+    // by tile: the out-proj runs feature tile by feature tile, tile jn's accumulator starts at (res + bo) of its 32 features,
+    // and only the first three tiles' residual values are fetched here -- every tile of a launch starts at the same time, so
+    // what the prologue waits for is an HBM burst of all CUs at once (~11 B/clk/CU): 176 KB per workgroup instead of 384.
+    u32x4 ofr[KS];  // dead after the out-proj, the LayerNorm-2 fragments take their place
     {
         const bf16_t* const orow = p.O + (size_t)rld * p.ldo + 8 * lh;
 #pragma unroll
         for (int s = 0; s < KS; ++s) ofr[s] = *(const u32x4*)(orow + 16 * s);
     }
+    // Residual staging: this wave's 8 KiB of the LayerNorm-2 fragment region are idle until the out-proj is over -- two
+    // buffers of one feature tile (32 rows x 128 B) each, filled by LDS-DMA in whole-line pieces (8 rows x 128 B: lane
+    // 8 r + c of piece pp fetches chunk c ^ r of row 8 pp + r, a source-side swizzle that keeps the read-back conflict-free)
+    // and read back by the lane that owns the values: nothing is held in registers while the loads are in flight, and the
+    // compiler never sees a load it would have to wait for.
+    unsigned rsrc[4];  // piece pp: this lane's byte offset (row 8 pp + (lane >> 3) of the wave's 32, swizzled chunk)
+    {
+        const int rr8 = lane >> 3, cc = lane & 7;
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            const int il = 8 * pp + rr8;  // row of the wave's 32
+            int rt;
+            if (HEADS) {
+                int g2 = (int)(blockIdx.x >> 1) * 128 + 32 * wu + il;
+                if (g2 >= p.M / 2) g2 = p.M / 2 - 1;
+                rt = (g2 / p.out_grp) * p.out_mod + hs * p.out_grp + g2 % p.out_grp;
+            } else {
+                rt = row0 + 32 * wu + il;
+                if (rt >= p.M) rt = p.M - 1;
+            }
+            int rs = rt;
+            if (p.res_L > 0) {  // shared leading rows of a sequence: read from sequence 0
+                const int jj = rt % p.res_L;
+                if (jj < p.res_nshared) rs = jj;
+            }
+            rsrc[pp] = (unsigned)(((p.rowtab ? (size_t)(rt % p.rt_mod) * BD : (size_t)rs * p.ldr) + 4 * (cc ^ rr8)) * 4);
+        }
+    }
+    char* const rstage = smem + ACT_OFF + wu * ACT_LDS * 1024;
+    // (the buffer form, as the weight pieces: hipcc orders LDS reads behind a global_load_lds it cannot tell apart with a
+    // full vmcnt(0), which would drain the weight stream every phase)
+    const __amdgpu_buffer_rsrc_t r_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.rowtab ? p.rowtab : p.res), 0, 0xfffffff0u, 0x00020000);
+    (void)r_rs;
+    auto rdma = [&](int t) {  // residual values of feature tile t -> buffer t & 1
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rs, (lptr_t)(rstage + (t & 1) * 4096 + pp * 1024), 16, rsrc[pp], 128 * t, 0, 0);
+#endif
+    };
+    rdma(0);
+    rdma(1);
+    // this lane's read-back position of chunk 2 q + lh of its row l31: piece l31 >> 3, lane 8 (l31 & 7) + (chunk ^ (l31 & 7))
+    typedef const char __attribute__((address_space(3))) * lds_cc_t;  // (an LDS pointer: laundered as a generic one the reads become flat loads)
+    lds_cc_t rback = (lds_cc_t)(rstage + (l31 >> 3) * 1024 + (l31 & 7) * 128);
+    asm volatile("" : "+v"(rback));
+    f32x16 acc[NT];
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     stamps[1] = __builtin_readcyclecounter();
 
@@ -346,13 +360,18 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     //   extra(gn): further LDS reads for group gn of this phase (gn = 8: group 0 of the next phase)
     //   mma(i, a, g): MFMA i (0..31) with weight fragment a, group g;  valu(g, k): VALU work beside MFMA k of group g
     // Every MFMA slot is its own scheduling region, so the VALU slices stay between the MFMAs they are written beside.
-    auto phase = [&](int ph, auto sl_c, auto&& extra, auto&& mma, auto&& valu) {
+    // NRES: vector-memory operations issued behind the previous phase's last piece that may stay in flight across the sync
+    // besides the 7 pieces of the stage after next (the 4 loads of a residual tile issued at the end of the previous phase)
+    auto phase_n = [&](int ph, auto sl_c, auto nres_c, auto&& extra, auto&& mma, auto&& valu) {
         constexpr int SL = decltype(sl_c)::value;
         constexpr int RB = (2 * SL) % 3;
+        constexpr int NRES = decltype(nres_c)::value;
+        static_assert(NRES == 0 || NRES == 4, "sync counts");
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             if (g == 6) {  // every read of this stage is issued (two groups ahead): sync, then on into the next stage's slot
                 if (DBG == 6) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+                else if (NRES == 4) asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             if (DBG != 7) {
@@ -373,16 +392,43 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
             }
         }
     };
+    auto phase = [&](int ph, auto sl_c, auto&& extra, auto&& mma, auto&& valu) {
+        phase_n(ph, sl_c, std::integral_constant<int, 0>{}, extra, mma, valu);
+    };
     auto no_valu = [](int, int) {};
     auto no_extra = [](int) {};
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     using S2 = std::integral_constant<int, 2>;
 
-    // ---- out-proj: phase sb = k-steps 2 sb, 2 sb + 1 of all 16 feature tiles (straight-line: the O fragment index is static)
-#define OUTPROJ(sb, SL) phase(sb, SL{}, no_extra, [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], a, ofr[2 * (sb) + i / 16]); }, no_valu);
-    OUTPROJ(0, S0) OUTPROJ(1, S1) OUTPROJ(2, S2) OUTPROJ(3, S0) OUTPROJ(4, S1) OUTPROJ(5, S2) OUTPROJ(6, S0) OUTPROJ(7, S1)
-    OUTPROJ(8, S2) OUTPROJ(9, S0) OUTPROJ(10, S1) OUTPROJ(11, S2) OUTPROJ(12, S0) OUTPROJ(13, S1) OUTPROJ(14, S2) OUTPROJ(15, S0)
+    // ---- out-proj: phase jn = the 32 k-steps of feature tile jn.  Its accumulator starts at the residual + bias of its 32
+    // features, read back from the staging buffer its pieces were sent to two phases ago.
+    auto acc_init = [&](int jn) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 x = *(const f32x4 __attribute__((address_space(3)))*)(rback + (jn & 1) * 4096 + (((2 * q + lh) ^ (l31 & 7)) << 4));
+            const f32x4 b = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_BO + 32 * jn + 8 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[jn][4 * q + i] = x[i] + b[i];
+        }
+    };
+    // vmcnt bookkeeping (operations complete in issue order): the 4 pieces of residual tile jn + 2 are issued when phase jn
+    // STARTS (right behind acc_init(jn), which has just emptied their buffer): they have two phases to land -- with one phase
+    // (issued when phase jn + 1 starts) a tile alone on the chip measures the same, but beside the other streams' kernels every
+    // phase waits for its residual tile and a pipelined step takes 2.2 ms instead of 1.25.
+    // At the sync of phase jn the operations issued behind stage (jn + 1)'s last piece are one weight piece, these 4 and the
+    // phase's first 6 pieces: vmcnt(11).  In front of acc_init(jn) the operations behind tile jn's pieces are 8 weight pieces,
+    // the 4 of tile jn + 1 and 8 more weight pieces: vmcnt(20) (16 behind the last tile's).  Wave-private data: no barrier.
+#define OUTPROJ(jn, SL, NR, WAIT)                                                                                            \
+    asm volatile("s_waitcnt vmcnt(" #WAIT ")" ::: "memory");                                                                 \
+    acc_init(jn);                                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                                       \
+    if ((jn) + 2 < NT) rdma((jn) + 2);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                       \
+    phase_n(jn, SL{}, std::integral_constant<int, NR>{}, no_extra, [&](int i, u32x4 a, int) { mfma_a(acc[jn], a, ofr[i]); }, no_valu);
+    OUTPROJ(0, S0, 4, 0) OUTPROJ(1, S1, 4, 20) OUTPROJ(2, S2, 4, 20) OUTPROJ(3, S0, 4, 20) OUTPROJ(4, S1, 4, 20) OUTPROJ(5, S2, 4, 20)
+    OUTPROJ(6, S0, 4, 20) OUTPROJ(7, S1, 4, 20) OUTPROJ(8, S2, 4, 20) OUTPROJ(9, S0, 4, 20) OUTPROJ(10, S1, 4, 20) OUTPROJ(11, S2, 4, 20)
+    OUTPROJ(12, S0, 4, 20) OUTPROJ(13, S1, 4, 20) OUTPROJ(14, S2, 0, 20) OUTPROJ(15, S0, 0, 16)
 #undef OUTPROJ
     mfma_done_a(acc);  // (the accumulators are next read by v_accvgpr_read)
     stamps[2] = __builtin_readcyclecounter();

@@ -83,6 +83,95 @@ class _Slot:
         return self
 
 
+class _TicketOps:
+    """The device work of ``HipPlanner._resolve_certificate`` for one plan step in flight (its re-scores run through the
+    step's slot, on the step's tail stream).  A plain object per resolution -- NOT a class defined per call: a class object
+    sits in reference cycles, and a cycle that reaches the ticket keeps the step's device tensors alive until the cyclic
+    collector runs; the caching allocator then has to hipMalloc fresh blocks (a device synchronisation each) and the step
+    pipeline falls apart (measured: 780 -> 400 plan-steps/s in most runs)."""
+    __slots__ = ("planner", "tk", "top")
+
+    def __init__(self, planner, tk):
+        self.planner, self.tk, self.top = planner, tk, None
+
+    def read(self):
+        sl = self.tk.slot
+        return sl.hs_mrg.wait(self.tk.seq_mrg, sl.mstats)
+
+    def extend(self, lo, hi):
+        pl, tk = self.planner, self.tk
+        sl, N = tk.slot, tk.er_b.numel()
+        with pl._on(tk):
+            rs, tail = pl._rescore_args(tk)
+            pl.handle.rescore(*rs, tk.top[lo:hi], *tail, N, slot=sl.i, out=sl.f_top[lo:hi], want_actions=False)
+        tk.n_done = hi
+
+    def window_set(self, need, delta):
+        pl, tk = self.planner, self.tk
+        tk.delta = delta
+        with pl._on(tk):
+            self.top = pl._rescore_window_set(tk, need)
+        return tk.n_done
+
+    def merge_select(self, n, delta):
+        pl, tk = self.planner, self.tk
+        tk.delta = delta
+        with pl._on(tk):
+            pl._merge(tk, n)
+            tk.sel = pl.handle.select(tk.er, tk.a0, float(pl.cfg.temperature), tk.expo, out=tk.outbuf)
+            if tk.tchain is not None:
+                tk.slot.ev_done.record(tk.tchain)
+
+
+class _WindowOps:
+    """The device work of ``HipPlanner._resolve_certificate`` for window w of a lock-step group (fp32 re-scores through
+    m3pc_score_actions on the window's own rows).  ``c``: the group's state (a plain namespace; see _TicketOps on why this is
+    not a class defined inside the call)."""
+    __slots__ = ("c", "w", "pending")
+
+    def __init__(self, c, w):
+        self.c, self.w, self.pending = c, w, None
+
+    def read(self):
+        c, w = self.c, self.w
+        if self.pending is not None:
+            c.stats_h[w], self.pending = self.pending.cpu(), None
+        return [float(v) for v in c.stats_h[w]]
+
+    def _score(self, ix):
+        c, w = self.c, self.w
+        return torch.cat([c.hdl.score_actions(c.smode, c.s[w], c.a[w], c.r[w], c.acts[w, ix[c0 : c0 + c.cap].long()], None, c.h,
+                                              c.lmbda, c.disc) for c0 in range(0, ix.numel(), c.cap)])
+
+    def extend(self, lo, hi):
+        c, w = self.c, self.w
+        c.ftops[w] = torch.cat([c.ftops[w][:lo], self._score(c.tops[w][lo:hi])]).contiguous()
+
+    def window_set(self, need, dlt):
+        c, w = self.c, self.w
+        cnt = min(need, c.N)
+        if cnt <= 1024:  # the `need` best candidates by bf16 score, re-scored in chunks of the chain workspace
+            vals, idx = torch.topk(c.er[w], cnt)
+            c.tops[w], c.btops[w] = idx.to(torch.int32).contiguous(), vals.contiguous()
+            c.ftops[w] = self._score(c.tops[w]).contiguous()
+            self.merge_select(cnt, dlt)
+            return cnt
+        # beyond what the merge kernel lists: EVERY candidate of the window in fp32 -- the select then runs on fp32 scores
+        # alone (a merge of the best entry with itself keeps the statistics protocol alive)
+        er32 = c.hdl.score_actions(c.smode, c.s[w], c.a[w], c.r[w], c.acts[w], None, c.h, c.lmbda, c.disc).contiguous()
+        best = torch.argmax(er32).to(torch.int32).reshape(1)
+        bval = er32.max().reshape(1).contiguous()
+        c.tops[w], c.btops[w], c.ftops[w] = best, bval, bval
+        c.merged[w], self.pending = c.hdl.rescore_merge(er32, best, 1, bval, bval, delta=0.0)
+        c.sels[w] = c.hdl.select(c.merged[w], c.acts[w, :, 0], c.temp, c.expos[w])
+        return c.N
+
+    def merge_select(self, n, dlt):
+        c, w = self.c, self.w
+        c.merged[w], self.pending = c.hdl.rescore_merge(c.er[w], c.tops[w], n, c.btops[w], c.ftops[w], delta=dlt)
+        c.sels[w] = c.hdl.select(c.merged[w], c.acts[w, :, 0], c.temp, c.expos[w])
+
+
 class PlanTicket:
     """One plan step in flight (``HipPlanner.plan_async``).  ``result()`` -> what ``action_sample`` returns for the window:
     the eval action (A,) when the step was issued with eval=True, else the sampled action (1, A); ``pair()`` -> both;
@@ -509,35 +598,7 @@ class HipPlanner:
         top = None
         if self.rescore == "bound":
             N = tk.er_b.numel()
-            planner = self
-
-            class _TicketOps:
-                top = None
-
-                def read(self):
-                    return sl.hs_mrg.wait(tk.seq_mrg, sl.mstats)
-
-                def extend(self, lo, hi):
-                    with planner._on(tk):
-                        rs, tail = planner._rescore_args(tk)
-                        hd.rescore(*rs, tk.top[lo:hi], *tail, N, slot=sl.i, out=sl.f_top[lo:hi], want_actions=False)
-                    tk.n_done = hi
-
-                def window_set(self, need, delta):
-                    tk.delta = delta
-                    with planner._on(tk):
-                        self.top = planner._rescore_window_set(tk, need)
-                    return tk.n_done
-
-                def merge_select(self, n, delta):
-                    tk.delta = delta
-                    with planner._on(tk):
-                        planner._merge(tk, n)
-                        tk.sel = hd.select(tk.er, tk.a0, float(cfg.temperature), tk.expo, out=tk.outbuf)
-                        if tk.tchain is not None:
-                            sl.ev_done.record(tk.tchain)
-
-            ops = _TicketOps()
+            ops = _TicketOps(self, tk)
             extra = self._resolve_certificate(N, tk.kmax, tk.n_done, tk.delta, ops)
             tk.delta = extra["delta"]
             extra["n_first"] = tk.kmin
@@ -1048,58 +1109,13 @@ class HipPlanner:
             certs = [None] * Eg
             if self.rescore == "bound":
                 stats_h = torch.stack(mstats).cpu()  # the one host read of the group: [shift, deviation, need, margin] per window
-                planner, hdl, cap = self, self.handle, max(self.handle.max_rescore, 1)
-                disc, temp = float(cfg.discount), float(cfg.temperature)
-
-                class _WindowOps:
-                    """The device work of ``_resolve_certificate`` for window w of the group (fp32 re-scores through
-                    m3pc_score_actions on the window's own rows)."""
-
-                    def __init__(self, w):
-                        self.w, self.pending = w, None
-
-                    def read(self):
-                        w = self.w
-                        if self.pending is not None:
-                            stats_h[w], self.pending = self.pending.cpu(), None
-                        return [float(v) for v in stats_h[w]]
-
-                    def _score(self, ix):
-                        w = self.w
-                        return torch.cat([hdl.score_actions(smode, s[w], a[w], r[w], acts[w, ix[c0 : c0 + cap].long()], None, h, lmbda, disc)
-                                          for c0 in range(0, ix.numel(), cap)])
-
-                    def extend(self, lo, hi):
-                        w = self.w
-                        ftops[w] = torch.cat([ftops[w][:lo], self._score(tops[w][lo:hi])]).contiguous()
-
-                    def window_set(self, need, dlt):
-                        w = self.w
-                        cnt = min(need, N)
-                        if cnt <= 1024:  # the `need` best candidates by bf16 score, re-scored in chunks of the chain workspace
-                            vals, idx = torch.topk(er[w], cnt)
-                            tops[w], btops[w] = idx.to(torch.int32).contiguous(), vals.contiguous()
-                            ftops[w] = self._score(tops[w]).contiguous()
-                            self.merge_select(cnt, dlt)
-                            return cnt
-                        # beyond what the merge kernel lists: EVERY candidate of the window in fp32 -- the select then runs on
-                        # fp32 scores alone (a merge of the best entry with itself keeps the statistics protocol alive)
-                        er32 = hdl.score_actions(smode, s[w], a[w], r[w], acts[w], None, h, lmbda, disc).contiguous()
-                        best = torch.argmax(er32).to(torch.int32).reshape(1)
-                        bval = er32.max().reshape(1).contiguous()
-                        tops[w], btops[w], ftops[w] = best, bval, bval
-                        merged[w], self.pending = hdl.rescore_merge(er32, best, 1, bval, bval, delta=0.0)
-                        sels[w] = hdl.select(merged[w], acts[w, :, 0], temp, expos[w])
-                        return N
-
-                    def merge_select(self, n, dlt):
-                        w = self.w
-                        merged[w], self.pending = hdl.rescore_merge(er[w], tops[w], n, btops[w], ftops[w], delta=dlt)
-                        sels[w] = hdl.select(merged[w], acts[w, :, 0], temp, expos[w])
-
+                ctx = types.SimpleNamespace(hdl=self.handle, cap=max(self.handle.max_rescore, 1), disc=float(cfg.discount),
+                                            temp=float(cfg.temperature), stats_h=stats_h, smode=smode, s=s, a=a, r=r, acts=acts, h=h,
+                                            lmbda=lmbda, N=N, er=er, tops=tops, btops=btops, ftops=ftops, merged=merged, sels=sels,
+                                            expos=expos)
                 delta_first = delta
                 for w in range(Eg):
-                    ops_w = _WindowOps(w)
+                    ops_w = _WindowOps(ctx, w)
                     if delta > delta_first:  # an earlier window of the group raised the bound: this window's certificate again, under it
                         ops_w.merge_select(counts[w], delta)
                     certs[w] = self._resolve_certificate(N, kmax, counts[w], delta, ops_w)
