@@ -321,7 +321,14 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
                 const int jj = rt % p.res_L;
                 if (jj < p.res_nshared) rs = jj;
             }
-            rsrc[pp] = (unsigned)(((p.rowtab ? (size_t)(rt % p.rt_mod) * BD : (size_t)rs * p.ldr) + 4 * (cc ^ rr8)) * 4);
+            size_t rowoff;
+            if (p.rowtab) {
+                const int w = rt % p.rt_mod;
+                rowoff = (size_t)(w < p.res_nu ? p.rt_mod + (rt / p.rt_mod) * p.res_nu + w : w) * BD;
+            } else {
+                rowoff = (size_t)rs * p.ldr;
+            }
+            rsrc[pp] = (unsigned)((rowoff + 4 * (cc ^ rr8)) * 4);
         }
     }
     char* const rstage = smem + ACT_OFF + wu * ACT_LDS * 1024;
@@ -1243,9 +1250,11 @@ bool launch_kv_fused(const KvFusedP& p, hipStream_t st) {
 bool launch_block_fused(const BlockP& p, hipStream_t st) {
     if (p.M <= 0) return true;
     if (((uintptr_t)p.O & 15) || (p.ldo % 8) || ((uintptr_t)p.wstream & 1023)) return false;
-    if (!p.rowtab && (((uintptr_t)p.res & 15) || (p.ldr % 4))) return false;
+    if (!p.rowtab && (((uintptr_t)p.res & 15) || (p.ldr % 4) || (unsigned long long)p.M * p.ldr * 4 >= 0xfffffff0ull)) return false;  // (32-bit buffer offsets)
     if (p.Xout && (((uintptr_t)p.Xout & 15) || (p.ldx % 4))) return false;
-    if (p.res_L > 0 && (p.rowtab || p.Xout == p.res || p.res_nshared > p.res_L)) return false;  // (in place, the shared rows would be overwritten while read)
+    if (p.res_L > 0 && (p.rowtab || p.Xout == p.res || p.res_nshared > p.res_L)) return false;
+    if (p.res_nu < 0 || (p.res_nu > 0 && (!p.rowtab || p.res_nu > p.rt_mod || p.split))) return false;
+    if (p.rowtab && (unsigned long long)(p.rt_mod + (p.res_nu > 0 ? (unsigned long long)((p.M + p.rt_mod - 1) / p.rt_mod) * p.res_nu : 0)) * BD * 4 >= 0xfffffff0ull) return false;  // (in place, the shared rows would be overwritten while read)
     if (p.Hout && (((uintptr_t)p.Hout & 7) || (p.ldh % 4))) return false;
     if (p.out_mod > 0 && (p.M % p.out_mod != 0 || p.out_mod != 2 * p.out_grp)) return false;
     if (p.QKVout) {  // the next layer's Q|K|V rows instead of its norm1 rows

@@ -93,6 +93,8 @@ struct BlockP {
                             // same and are read from sequence 0 (the history tokens of a candidate pass: stored once)
     const float* rowtab;    // (rt_mod, d): row r takes rowtab[r % rt_mod] as its residual (res unused)
     int rt_mod;
+    int res_nu;             // > 0 (with rowtab): rows with w = r % rt_mod < res_nu have residual rows of their own, stored behind the
+                            // table: rowtab[rt_mod + (r / rt_mod) * res_nu + w]
     const bf16_t* wstream;  // packed weight fragments of the layer (launch_pack_block_stream)
     const float* bo;        // out_proj.bias (d)
     const float* b1;        // linear1.bias (ff)

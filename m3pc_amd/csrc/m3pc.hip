@@ -96,6 +96,10 @@ struct Plan {
         int n_groups = 2, grp = 0;
         int qkeys[2] = {0, 0};
         bool all_masked = true;
+        // nu > 0: the un-masked query tokens are exactly the first nu queries, consecutive tokens of ONE key whose encoder rows
+        // are consecutive too (critic_lambda_guiding: states[idx]; goal path inference: states[0..idx]) -- the decoder then
+        // builds per-sequence rows for those nu queries only and takes the others from the shared tables
+        int nu = 0, nu_key = 0, nu_enc0 = 0, nu_kept0 = 0;
         int* d_q_rowsrc_tab = nullptr;  // (nq): -(i)-1 rows of (4T,*) tables
         int* d_q_rowsrc_mix = nullptr;  // (nq): enc row or -(i)-1 rows of Yall
         SharedTables tab[2];
@@ -1132,6 +1136,21 @@ int build_query_list(m3pc_handle* h, Plan* pl, int qi, int hh, const std::vector
             mix[j] = -i - 1;
         }
     }
+    q.nu = 0;
+    if (!q.all_masked) {
+        int nu = 0;
+        while (nu < q.nq && pl->dec_src[toks[nu]] >= 0) ++nu;
+        bool ok = nu > 0;
+        for (int j = nu; j < q.nq && ok; ++j) ok = pl->dec_src[toks[j]] < 0;                       // a prefix, nothing behind it
+        for (int j = 1; j < nu && ok; ++j)                                                           // consecutive tokens / rows of one key
+            ok = toks[j] == toks[0] + j && toks[j] / T == toks[0] / T && pl->dec_src[toks[j]] == pl->dec_src[toks[0]] + j;
+        if (ok) {
+            q.nu = nu;
+            q.nu_key = toks[0] / T;
+            q.nu_enc0 = pl->dec_src[toks[0]];
+            q.nu_kept0 = q.nu_enc0 - pl->enc_off[q.nu_key];  // index among the key's kept tokens (the compact position table's row)
+        }
+    }
     if (!q.d_q_rowsrc_tab) {
         CHK(dmalloc(&q.d_q_rowsrc_tab, (size_t)2 * T));
         CHK(dmalloc(&q.d_q_rowsrc_mix, (size_t)2 * T));
@@ -1287,7 +1306,16 @@ int pruned_decoder(m3pc_handle* h, Plan* pl, Plan::Query& q, SharedTables& tb, i
         ln.Yf = (float*)h->Hn;
     bool kv_done = false;
     static const bool no_kv_fused = M3PC_ENV("M3PC_NO_KV_FUSED") != nullptr || M3PC_ENV("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
-    if (dt == DT_BF16 && !no_kv_fused && q.all_masked && (double)n * Le * h->pass_scale >= 512.0 && h->kvstream[0] && (pl->kept[0] || pl->kept[1]) && !pl->kept[2] && !pl->kept[3]) {
+    static const bool no_fused_tail = M3PC_ENV("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
+    static const bool no_mix_prefix = M3PC_ENV("M3PC_NO_MIX_PREFIX") != nullptr;   // A/B switch
+    const bool kv_fusable = dt == DT_BF16 && !no_kv_fused && (double)n * Le * h->pass_scale >= 512.0 && h->kvstream[0] &&
+                            (pl->kept[0] || pl->kept[1]) && !pl->kept[2] && !pl->kept[3];
+    // Some query tokens un-masked, as a prefix (Query::nu): the fused decoder input still serves K|V, the nu per-sequence
+    // query rows get their decoder inputs / Q projection from few-row GEMMs of their own, and the fused tail takes their
+    // residual rows from behind the shared table (many-row bf16 passes only: the choice goes by the size of the whole step)
+    const bool mixp = kv_fusable && !q.all_masked && q.nu > 0 && !no_mix_prefix && !no_fused_tail && h->wstream.count(pfx) &&
+                      (double)n * nq * h->pass_scale >= (double)FUSED_MIN_ROWS && (long long)nq + (long long)n * q.nu <= h->R;
+    if (kv_fusable && (q.all_masked || mixp)) {
         // embedding, norm1 and the K|V projection in one launch (kv_fused_kernel): the fp32 rows Y are consumed by nothing
         // else when every scored token is masked
         KvFusedP kp;
@@ -1342,7 +1370,26 @@ int pruned_decoder(m3pc_handle* h, Plan* pl, Plan::Query& q, SharedTables& tb, i
     float* Yq_rows = nullptr;  // per-candidate residual rows (n*nq, d) when some scored token is un-masked
     char* kvu = (char*)h->QKV;
     char* qbuf = kvu + (size_t)n * Le * 2 * d * es;  // behind K|V in the same buffer
-    if (q.all_masked) {
+    float* Rcomb = nullptr;  // mixp: [shared residual table (nq rows)] [per-sequence residual rows of the nu un-masked queries (n nu)]
+    if (mixp) {
+        const int nu = q.nu, kq = q.nu_key;
+        Rcomb = h->X;  // (the encoder residual stream is dead by now)
+        float* Yu = Rcomb + (size_t)nq * d;
+        HIPCHK(hipMemcpyAsync(Rcomb, tb.Yq, (size_t)nq * d * sizeof(float), hipMemcpyDeviceToDevice, st));
+        // decoder inputs of the nu query tokens of every sequence: Z rows nu_enc0 .. of the sequence, the key's embedding
+        RowMap am{nu, Le, q.nu_enc0};
+        dec_embed(h, kq, enc_op, am, Yu, rowmap_identity(), n * nu, nu, dt, st, pl->edec_kept[kq] + (size_t)q.nu_kept0 * d);
+        ln.X = Yu;
+        ln.rows = n * nu;
+        launch_layernorm(ln, st);
+        GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".self_attn.in_proj_weight", dt), d, n * nu, d, d,
+                             W(h, pfx + ".self_attn.in_proj_bias").f);
+        gemm_out(p, dt, qbuf, d);
+        gemm(h, p, dt, st);
+        Qp = qbuf;
+        q_bstride = (long long)nu * d;
+        ldq = d;
+    } else if (q.all_masked) {
         Qp = tb.QKVq;
         q_bstride = 0;
         ldq = 3 * d;
@@ -1393,6 +1440,16 @@ int pruned_decoder(m3pc_handle* h, Plan* pl, Plan::Query& q, SharedTables& tb, i
         at.hd = h->hd;
         at.Lq = nq;
         at.scale = 1.0f / sqrtf((float)h->hd);
+        if (mixp) {  // queries [0, nu) per sequence, the others from the shared table behind them
+            at.Lq = q.nu;
+            at.orow1 = 0;
+            if (nq > q.nu) {
+                at.Q2 = (const char*)tb.QKVq + (size_t)q.nu * 3 * d * es;
+                at.ldq2 = 3 * d;
+                at.Lq2 = nq - q.nu;
+                at.orow2 = q.nu;
+            }
+        }
         if (dt == DT_BF16 && q.all_masked && tb.pre_m) {
             // the masked tokens' keys meet the same (shared) queries for every candidate: that block of the softmax
             // was reduced when the tables were built, only the candidate's own Le keys are visited here
@@ -1417,7 +1474,11 @@ int pruned_decoder(m3pc_handle* h, Plan* pl, Plan::Query& q, SharedTables& tb, i
         b.O = (const bf16_t*)h->O;
         b.ldo = d;
         b.M = n * nq;
-        if (q.all_masked) {
+        if (mixp) {
+            b.rowtab = Rcomb;
+            b.rt_mod = nq;
+            b.res_nu = q.nu;
+        } else if (q.all_masked) {
             b.rowtab = tb.Yq;
             b.rt_mod = nq;
         } else {
@@ -1509,6 +1570,7 @@ int pruned_decoder(m3pc_handle* h, Plan* pl, Plan::Query& q, SharedTables& tb, i
         }
         tail_done = ok;
     }
+    if (!tail_done && mixp) return fail(M3PC_EINVAL, "pruned_decoder: the fused layer tail did not take a pass set up for it");
     if (!tail_done) {
     {
         GemmP p = gemm_basic(h->O, d, Wop(h, pfx + ".self_attn.out_proj.weight", dt), d, n * nq, d, d,
