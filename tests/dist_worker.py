@@ -54,9 +54,9 @@ def rccl_world_one(port):
     print("rank 0/1 case rccl1: sharded == single (all_gather_into_tensor through RCCL on the compute stream)", flush=True)
 
 
-def attach_case(rank, world, port):
+def attach_case(rank, world):
     """attach(learner, group=..., generator=...): every rank attaches its own replica of
-    a reference-shaped learner and must return the single-rank action, bit for bit."""
+    a reference-shaped learner and must return the single-rank action, bit for bit.  Returns (reference run, sharded run)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from fake_learner import make_learner
     from m3pc_amd.planner import attach
@@ -65,7 +65,6 @@ def attach_case(rank, world, port):
                                 plan_guidance="rtg_guiding", device="cuda")
     hist = synth.make_history(dims, 0)
     hist["path_length"] = 300
-    torch.cuda.set_device(0)
 
     def run(group):
         learner = make_learner(dims, cfg)
@@ -77,21 +76,18 @@ def attach_case(rank, world, port):
         planner.handle.close()
         return out, w
 
-    ref, w1 = run(None)
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    got, w2 = run(dist.group.WORLD)
-    ok = w1 == 1 and w2 == world and all(torch.equal(a, b) for a, b in zip(ref, got))
-    try:
-        attach(make_learner(dims, cfg), precision="bf16", group=dist.group.WORLD)  # no generator: must be refused
-        ok = False
-    except ValueError:
-        pass
-    dist.barrier()
-    dist.destroy_process_group()
-    if not ok:
-        print(f"rank {rank}/{world} case attach: MISMATCH", flush=True)
-        sys.exit(3)
-    print(f"rank {rank}/{world} case attach: sharded == single (attach with group + generator)", flush=True)
+    def sharded(ref):
+        (ref_out, w1) = ref
+        got, w2 = run(dist.group.WORLD)
+        bad = [] if (w1 == 1 and w2 == world and all(torch.equal(a, b) for a, b in zip(ref_out, got))) else ["action"]
+        try:
+            attach(make_learner(dims, cfg), precision="bf16", group=dist.group.WORLD)  # no generator: must be refused
+            bad.append("missing-generator not refused")
+        except ValueError:
+            pass
+        return bad, "attach with group + generator"
+
+    return (lambda: run(None)), sharded
 
 
 CASES = {
@@ -103,17 +99,11 @@ CASES = {
 }
 
 
-def main():
-    rank, world, port, case = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
-    if case == "attach":
-        return attach_case(rank, world, port)
-    if case == "rccl1":
-        return rccl_world_one(port)
+def plan_case(case, rank, world):
     env, guidance, mode, n_rank, H, T, temp = CASES[case]
     N = n_rank * world + (1 if case == "odd" else 0)
     S, A = synth.ENV_DIMS[env]
     dims = synth.Dims(S, A, T)
-    torch.cuda.set_device(0)
     cfg = types.SimpleNamespace(traj_length=T, action_samples=N, horizon=H, discount=0.99, temperature=temp, lmbda=0.6,
                                 plan_guidance=guidance, device="cuda")
     sd, st = synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0)
@@ -133,26 +123,49 @@ def main():
         p.handle.close()
         return out
 
-    ref = plan(None, False)  # before the process group exists: world 1
-    assert ref["world"] == 1
+    def sharded(ref):
+        assert ref["world"] == 1
+        got = plan(dist.group.WORLD, True)
+        assert got["world"] == world
+        bad = [k for k in ("expect_return", "argmax", "sample_idx", "eval_action", "sample_action") if not torch.equal(ref[k], got[k])]
+        if got["n_rescored"] != ref["n_rescored"]:
+            bad.append("n_rescored")
+        # a planner without an explicit generator must be refused when sharded (silent RNG divergence)
+        try:
+            HipPlanner(cfg, sd, st, qsd, om, os_, precision="bf16", group=dist.group.WORLD)
+            bad.append("missing-generator not refused")
+        except ValueError:
+            pass
+        return bad, f"{N} candidates, {got['n_rescored']} re-scored"
+
+    return (lambda: plan(None, False)), sharded
+
+
+def main():
+    """<case> may be a comma-separated list: every case's single-rank reference first (before the process group exists: a
+    planner without a group is then world 1), ONE process group, then every case sharded -- one interpreter start per rank
+    for the whole list (the driver's box starts interpreters slowly)."""
+    rank, world, port, cases = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4].split(",")
+    if cases == ["rccl1"]:
+        return rccl_world_one(port)
+    torch.cuda.set_device(0)
+    todo = []
+    for case in cases:
+        ref_fn, sharded_fn = attach_case(rank, world) if case == "attach" else plan_case(case, rank, world)
+        todo.append((case, ref_fn(), sharded_fn))
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    got = plan(dist.group.WORLD, True)
-    assert got["world"] == world
-    bad = [k for k in ("expect_return", "argmax", "sample_idx", "eval_action", "sample_action") if not torch.equal(ref[k], got[k])]
-    if got["n_rescored"] != ref["n_rescored"]:
-        bad.append("n_rescored")
-    # a planner without an explicit generator must be refused when sharded (silent RNG divergence)
-    try:
-        HipPlanner(cfg, sd, st, qsd, om, os_, precision="bf16", group=dist.group.WORLD)
-        bad.append("missing-generator not refused")
-    except ValueError:
-        pass
+    failed = False
+    for case, ref, sharded_fn in todo:
+        bad, what = sharded_fn(ref)
+        if bad:
+            print(f"rank {rank}/{world} case {case}: MISMATCH in {bad}", flush=True)
+            failed = True
+        else:
+            print(f"rank {rank}/{world} case {case}: sharded == single ({what})", flush=True)
     dist.barrier()
     dist.destroy_process_group()
-    if bad:
-        print(f"rank {rank}/{world} case {case}: MISMATCH in {bad}", flush=True)
+    if failed:
         sys.exit(3)
-    print(f"rank {rank}/{world} case {case}: sharded == single ({N} candidates, {got['n_rescored']} re-scored)", flush=True)
 
 
 if __name__ == "__main__":

@@ -34,6 +34,7 @@ def _window(dims, i):
     return h
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("N,T,H,seeds,per_seed", [(1024, 32, 16, 5, 40), (256, 32, 16, 4, 30)])
 def test_certificate_sweep_argmax_and_deviation(N, T, H, seeds, per_seed):
     dims = synth.Dims(11, 3, T)
@@ -99,7 +100,8 @@ def _churn(rng, keep):
         keep.pop(int(rng.integers(0, len(keep))))
 
 
-@pytest.mark.parametrize("precision,N,T,H,steps", [("bf16", 1024, 32, 16, 160), ("fp32", 256, 16, 8, 160), ("bf16", 256, 16, 8, 200)])
+@pytest.mark.slow
+@pytest.mark.parametrize("precision,N,T,H,steps", [("bf16", 1024, 32, 16, 120), ("fp32", 256, 16, 8, 120), ("bf16", 256, 16, 8, 120)])
 def test_pipeline_soak_with_allocator_churn(precision, N, T, H, steps):
     dims = synth.Dims(11, 3, T)
     rng = np.random.default_rng(7)

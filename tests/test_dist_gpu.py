@@ -20,7 +20,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,case", [(2, "c2"), (3, "c2"), (2, "c3"), (2, "c4"), (2, "odd"), (2, "attach"), (1, "rccl1")])
+# (the world-2 cases share one pair of child processes: interpreter start-up dominates this file on a cold box)
+@pytest.mark.parametrize("world,case", [(2, "c2,c3,c4,odd,attach"), (3, "c2"), (1, "rccl1")])
 def test_sharded_planner_equals_single_gpu(world, case):
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
@@ -37,4 +38,4 @@ def test_sharded_planner_equals_single_gpu(world, case):
                 p.kill()
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} exited {p.returncode}:\n{out[-3000:]}"
-        assert "sharded == single" in out
+        assert out.count("sharded == single") == len(case.split(",")), out[-3000:]

@@ -274,7 +274,8 @@ def test_c3_critic_bf16_screen_quality():
 
 
 # ------------------------------------------------------------------------------------ edge shapes vs the oracle
-@pytest.mark.parametrize("T,H,N,mode", [(8, 4, 625, "rtg"), (8, 4, 625, "critic"), (8, 1, 37, "rtg"), (8, 8, 130, "critic"),
+# (the oracle runs on the CPU: one case at the shipped N=625, the critic one at N=250 -- the same kernels, less oracle time)
+@pytest.mark.parametrize("T,H,N,mode", [(8, 4, 625, "rtg"), (8, 4, 250, "critic"), (8, 1, 37, "rtg"), (8, 8, 130, "critic"),
                                         (16, 5, 1, "rtg"), (8, 4, 64, "noise")])
 def test_odd_shapes_match_oracle(T, H, N, mode):
     """The reference's shipped planning config (N=625, H=4, T=8, finetune_omtm/config.yaml:5,77-78) and ragged
@@ -303,7 +304,7 @@ def test_odd_shapes_match_oracle(T, H, N, mode):
     h.close()
 
 
-@pytest.mark.parametrize("T,H,N,mode", [(8, 4, 625, "rtg"), (8, 4, 625, "critic"), (16, 8, 300, "rtg")])
+@pytest.mark.parametrize("T,H,N,mode", [(8, 4, 625, "rtg"), (8, 4, 320, "critic"), (16, 8, 300, "rtg")])
 def test_few_tile_bf16_passes_match_oracle(T, H, N, mode):
     """bf16 candidate passes of 16..96 fused-tail tiles (the reference's shipped N=625 / H=4 / T=8 config among them) take the
     four-workgroups-per-tile form of the fused layer tail + its reduce launch (DESIGN.md section 4 "Small problems"): scores
