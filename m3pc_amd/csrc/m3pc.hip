@@ -2186,8 +2186,8 @@ int m3pc_goal_step(m3pc_handle* h, int batch, const float* states, const float* 
 //   shared by the batch.  Neither mask keeps a rewards or returns token (zeroshot_omtm/masks.py:30-47, 72-91): those rows
 //   of the window never enter, which is why the call does not take them.
 // goal_mode M3PC_GOAL_ID: action_id_sample (learner.py:60-149) -- the second forward alone, under the gid mask (= pi mask).
-static int goal_forward(m3pc_handle* h, int kind, int qi, int idx, const float* states, const float* actions, int n, int dt,
-                        hipStream_t st, int tail, float** xrows) {
+// plan tables, query set and candidate-independent decoder rows of one goal forward (cached per idx / weights)
+static int goal_prepare(m3pc_handle* h, int kind, int qi, int idx, int dt, hipStream_t st, Plan** pl_out, Plan::Query** q_out) {
     const int T = h->T;
     Plan* pl = nullptr;
     CHK(get_mask_plan(h, kind, idx, &pl));
@@ -2200,7 +2200,19 @@ static int goal_forward(m3pc_handle* h, int kind, int qi, int idx, const float* 
     }
     CHK(build_query_list(h, pl, qi, T - idx, toks, 1, qi == 2 ? M3PC_STATES : M3PC_ACTIONS, 0));
     CHK(build_tables(h, pl, qi, dt, st));
-    Plan::Query& q = pl->query[qi];
+    CHK(ensure_edec(h, pl, st));
+    if (pl_out) *pl_out = pl;
+    if (q_out) *q_out = &pl->query[qi];
+    return 0;
+}
+
+static int goal_forward(m3pc_handle* h, int kind, int qi, int idx, const float* states, const float* actions, int n, int dt,
+                        hipStream_t st, int tail, float** xrows) {
+    const int T = h->T;
+    Plan* pl = nullptr;
+    Plan::Query* qp = nullptr;
+    CHK(goal_prepare(h, kind, qi, idx, dt, st, &pl, &qp));
+    Plan::Query& q = *qp;
     if ((long long)n * pl->Le > h->R || (long long)n * q.nq > h->R) return fail(M3PC_ENOMEM, "batch %d exceeds workspace", n);
     TokIn in;
     memset(&in, 0, sizeof(in));
@@ -2234,44 +2246,75 @@ int m3pc_goal_step_batch(m3pc_handle* h, int batch, const float* states, const f
     // which other windows share its call (environment sharding, m3pc_amd/dist.py)
     h->allow_splitk = false;
     h->pass_scale = 1.0;
-    const float* second = states;
-    if (goal_mode == M3PC_GOAL_PIID) {
-        CHK(goal_forward(h, 2, 2, idx, states, actions, batch, dt, st, TAIL_HEADS, nullptr));
-        int nq = 0;
-        for (int t = 0; t < T; ++t) nq += (t <= idx || (t >= idx + 2 && t < T - 1)) ? 1 : 0;
-        float* ws = window_states ? window_states : h->goal_ws;
-        launch_goal_overlay_rows(h->pred[0], states, ws, batch, T, h->S, idx, nq, st);
-        second = ws;
-    } else if (window_states) {
-        HIPCHK(hipMemcpyAsync(window_states, states, (size_t)batch * T * h->S * sizeof(float), hipMemcpyDeviceToDevice, st));
+    int nq_a = 0;
+    for (int t = 0; t < T; ++t) nq_a += (t <= idx || (t >= idx + 2 && t < T - 1)) ? 1 : 0;
+    float* const ws_all = window_states ? window_states : h->goal_ws;
+    // windows [c0, c0 + cnt) on stream s, in the workspace rows of those windows (set_view: 2T rows per window)
+    auto run_part = [&](int c0, int cnt, hipStream_t s) -> int {
+        set_view(h, c0, cnt);
+        const float* st_p = states + (size_t)c0 * T * h->S;
+        const float* ac_p = actions + (size_t)c0 * T * h->A;
+        const float* second = st_p;
+        if (goal_mode == M3PC_GOAL_PIID) {
+            CHK(goal_forward(h, 2, 2, idx, st_p, ac_p, cnt, dt, s, TAIL_HEADS, nullptr));
+            float* ws = ws_all + (size_t)c0 * T * h->S;
+            launch_goal_overlay_rows(h->pred[0], st_p, ws, cnt, T, h->S, idx, nq_a, s);
+            second = ws;
+        } else if (window_states) {
+            HIPCHK(hipMemcpyAsync(window_states + (size_t)c0 * T * h->S, st_p, (size_t)cnt * T * h->S * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+        float* xr = nullptr;
+        CHK(goal_forward(h, goal_mode == M3PC_GOAL_PIID ? 3 : 2, 3, idx, second, ac_p, cnt, dt, s, TAIL_X, &xr));
+        // decoder.norm of the one query row per window, then the action head (mtm_model.py:705, 313-321), fp32
+        LnP ln;
+        memset(&ln, 0, sizeof(ln));
+        ln.X = xr;
+        ln.ldx = d;
+        ln.rows = cnt;
+        ln.d = d;
+        ln.g1 = W(h, "decoder.norm.weight").f;
+        ln.b1 = W(h, "decoder.norm.bias").f;
+        ln.Yf = h->G;
+        launch_layernorm(ln, s);
+        ActorP ac;
+        memset(&ac, 0, sizeof(ac));
+        ac.X = h->G;
+        ac.ldx = d;
+        ac.rows = cnt;
+        ac.d = d;
+        ac.A = h->A;
+        ac.Wmu = W(h, "output_head_dict.actions.mu.weight").f;
+        ac.bmu = W(h, "output_head_dict.actions.mu.bias").f;
+        ac.Wls = W(h, "output_head_dict.actions.log_std.weight").f;
+        ac.bls = W(h, "output_head_dict.actions.log_std.bias").f;
+        ac.mu = out_mu + (size_t)c0 * h->A;
+        ac.sd = out_std + (size_t)c0 * h->A;
+        launch_actor_head(ac, s);
+        return 0;
+    };
+    // Many windows in bf16: two halves on two streams, as the candidate pass runs its halves -- the encoder launches of the
+    // whole call are 2.5 and 3 rounds of fused-tail tiles, and the other half's attention / embedding kernels (HBM-bound) run
+    // beside a half's tiles.  The kernel choice goes by the size of the whole call (pass_scale): same bits either way.
+    int rc = 0;
+    if (h->two_stream && dt == DT_BF16 && batch >= 2048 && !h->prof_serial) {
+        const int n0 = ((batch / 2 + 63) / 64) * 64;
+        // what is built once per (weights, idx) -- plan tables, query sets, the shared decoder rows -- before the streams fork
+        if (goal_mode == M3PC_GOAL_PIID) CHK(goal_prepare(h, 2, 2, idx, dt, st, nullptr, nullptr));
+        CHK(goal_prepare(h, goal_mode == M3PC_GOAL_PIID ? 3 : 2, 3, idx, dt, st, nullptr, nullptr));
+        HIPCHK(hipEventRecord(h->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+        h->pass_scale = (double)batch / (double)n0;
+        rc = run_part(0, n0, st);
+        h->pass_scale = (double)batch / (double)(batch - n0);
+        if (rc == 0) rc = run_part(n0, batch - n0, h->aux);
+        HIPCHK(hipEventRecord(h->ev_join, h->aux));
+        HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
+    } else {
+        rc = run_part(0, batch, st);
     }
-    float* xr = nullptr;
-    CHK(goal_forward(h, goal_mode == M3PC_GOAL_PIID ? 3 : 2, 3, idx, second, actions, batch, dt, st, TAIL_X, &xr));
-    // decoder.norm of the one query row per window, then the action head (mtm_model.py:705, 313-321), fp32
-    LnP ln;
-    memset(&ln, 0, sizeof(ln));
-    ln.X = xr;
-    ln.ldx = d;
-    ln.rows = batch;
-    ln.d = d;
-    ln.g1 = W(h, "decoder.norm.weight").f;
-    ln.b1 = W(h, "decoder.norm.bias").f;
-    ln.Yf = h->G;
-    launch_layernorm(ln, st);
-    ActorP ac;
-    memset(&ac, 0, sizeof(ac));
-    ac.X = h->G;
-    ac.ldx = d;
-    ac.rows = batch;
-    ac.d = d;
-    ac.A = h->A;
-    ac.Wmu = W(h, "output_head_dict.actions.mu.weight").f;
-    ac.bmu = W(h, "output_head_dict.actions.mu.bias").f;
-    ac.Wls = W(h, "output_head_dict.actions.log_std.weight").f;
-    ac.bls = W(h, "output_head_dict.actions.log_std.bias").f;
-    ac.mu = out_mu;
-    ac.sd = out_std;
-    launch_actor_head(ac, st);
+    h->pass_scale = 1.0;
+    set_view(h, 0, h->base.max_cand);
+    if (rc) return rc;
     return check_launch("goal_step_batch");
 }
 
