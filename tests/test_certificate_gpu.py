@@ -29,14 +29,15 @@ def _cfg(T, N, H):
 
 
 def _window(dims, i):
-    h = synth.make_history(dims, i % 7)
-    h["path_length"] = [500, 37, 321, 998, 640, 77, 250, 123, 864][i % 9]
+    h = synth.make_history(dims, i % 11)
+    h["path_length"] = [500, 37, 321, 998, 640, 77, 250, 123, 864][i % 9] if i < 9 else 33 + (i * 37) % 960
     return h
 
 
 @pytest.mark.slow
 @pytest.mark.parametrize("N,T,H,seeds,per_seed", [(1024, 32, 16, 5, 40), (256, 32, 16, 4, 30)])
 def test_certificate_sweep_argmax_and_deviation(N, T, H, seeds, per_seed):
+    per_seed *= int(os.environ.get("M3PC_SWEEP_SCALE", "1"))  # (a longer sweep for the record: profiles/r04_certificate_sweep_long_*)
     dims = synth.Dims(11, 3, T)
     rows = []
     mismatches = 0
@@ -79,7 +80,8 @@ def test_certificate_sweep_argmax_and_deviation(N, T, H, seeds, per_seed):
                         "the bound existed in that trial (the arg-max may still be right: it needs such a candidate inside the gap)")
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
-        with open(os.path.join(out_dir, f"r04_certificate_sweep_N{N}.json"), "w") as fh:
+        tag = "_long" if os.environ.get("M3PC_SWEEP_SCALE") else ""
+        with open(os.path.join(out_dir, f"r04_certificate_sweep{tag}_N{N}.json"), "w") as fh:
             json.dump(dict(summary=summary, rows=rows), fh, indent=0)
     print(json.dumps(summary))
     assert len(rows) >= 120
