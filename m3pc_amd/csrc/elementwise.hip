@@ -204,6 +204,9 @@ void launch_embed(const EmbedP& p, hipStream_t st) {
     if (p.d % 256 == 0 && p.d <= 1024) {
         int CB = p.batch / 64;
         CB = CB < 1 ? 1 : (CB > 16 ? 16 : CB);
+        // a long chunk pays where tokens are shared by the batch (computed once per wave); without shared tokens (zero-shot
+        // windows, batched window passes) more, shorter waves keep more stores in flight: 155 -> see DESIGN.md section 10
+        if (p.n_indep == 0 && CB > 4) CB = 4;
         const int nchunk = (p.batch + CB - 1) / CB;
         const int waves = p.L * nchunk;
         const dim3 grid((waves + 3) / 4), block(256);
