@@ -36,10 +36,10 @@
 //   out-proj, phase jn = 0..15:  all 32 k-steps of feature tile jn (one accumulator chain of 32 MFMAs); tile jn's
 //            accumulator starts at (residual + bias) of its 32 features, fetched three phases ahead: the residual rows
 //            -- two thirds of a tile's input bytes -- stream in UNDER the out-proj instead of in front of it (round 4)
-//   FFN, chunk c = 0..31 of 64 hidden units:  A0 A1 B1 B2
+//   FFN, chunk c = 0..31 of 64 hidden units:  A0 A1 B1 B2, interleaved with the neighbouring chunks' (A0(c) B2(c-1) A1(c) B1(c))
 //            A0 / A1: hidden tile 64c..+31 / 64c+32..+63 over the 32 k-steps of the model width (FFN1)
 //            B1 / B2: hidden k-steps 0,1 / 2,3 of the chunk into all 16 feature tiles (FFN2)
-//            gelu of hidden tile 0 runs on the VALU beside the MFMAs of A1, that of tile 1 beside B1.
+//            gelu of hidden tile 0 runs on the VALU beside the MFMAs of B2(c-1) and A1, that of tile 1 beside B1 and A0(c+1).
 // Registers: 256 accumulators + the 32 LayerNorm-2 fragments (128) + hidden tiles, their bf16 fragments and the
 // fragment window do not fit 512 with room for the compiler, so the fragments of k-steps 24..31 live in LDS (8 KiB per
 // wave, private to it) and are read like the weights, one per group of four MFMAs.
@@ -102,14 +102,26 @@ __global__ __launch_bounds__(256) void pack_block_stream_kernel(const bf16_t* __
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = Wo[(size_t)(32 * jn + r) * BD + 16 * ks + 8 * h + j];
     } else {
-        const int g = f - FR_OUT, c = g / 128, w = g % 128;
-        if (w < 64) {  // A0 | A1: hidden tile t, MFMA i (permuted k order: the operand is a LayerNorm-2 accumulator)
-            const int t = w / KS, s = a_kstep(w % KS);
+        // FFN phases in EXECUTION order (ffn_phase_pos below): A0(0) A1(0) B1(0), then A0(c) B2(c-1) A1(c) B1(c) for c = 1..31, B2(31)
+        const int g = f - FR_OUT, P = g / 32, i = g % 32;
+        int kind, c;  // 0: A0, 1: A1, 2: B1, 3: B2 of chunk c
+        if (P < 3) {
+            c = 0, kind = P;
+        } else if (P == 4 * NCH - 1) {
+            c = NCH - 1, kind = 3;
+        } else {
+            const int q = P - 3, k = q % 4;
+            c = 1 + q / 4;
+            kind = k == 0 ? 0 : k == 1 ? 3 : k == 2 ? 1 : 2;
+            if (k == 1) c -= 1;
+        }
+        if (kind < 2) {  // A0 | A1: hidden tile t, MFMA i (permuted k order: the operand is a LayerNorm-2 accumulator)
+            const int t = kind, s = a_kstep(i);
             const size_t row = (size_t)(64 * c + 32 * t + r) * BD;
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = W1[row + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
-        } else {       // B1 | B2: hidden k-step s2 of the chunk, feature tile jn
-            const int s2 = (w - 64) / 16, jn = (w - 64) % 16;
+        } else {         // B1 | B2: hidden k-step s2 of the chunk, feature tile jn
+            const int s2 = 2 * (kind - 2) + i / 16, jn = i % 16;
             const size_t row = (size_t)(32 * jn + r) * BFF + 64 * c + 16 * s2;
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = W2[row + 8 * (j >> 2) + 4 * h + (j & 3)];
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     // chunks this workgroup takes; every quarter repeats the out-proj and LayerNorm-2 (11 % of a tile), adds its share of
     // FFN2 to zero (quarter 0: to X' + b2) and stores the fp32 partial to its slab; block_split_reduce sums the slabs in order
     constexpr int NCHL = SPLIT ? NCH / SPLIT_N : NCH;  // hidden chunks of this workgroup
-    static_assert((NCHL - 2) % 3 == 0, "the chunk loop runs in rounds of three behind the first two");
+    static_assert((NCHL - 2) % 3 == 0 && (NCHL - 1) % 3 == 1, "the FFN loop runs three chunks at a time between the first and the last");
     constexpr int NST = QKV ? NRS_QKV : HEADS ? NRS_HEAD : SPLIT ? FR_OUT / RS_FR + 4 * NCHL : NRS;  // ring stages a workgroup consumes
     const int cbase = SPLIT ? (int)blockIdx.y * NCHL : 0;  // first hidden chunk
     __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
@@ -240,7 +252,10 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
         if (DBG == 1) return;
         int sw = st >= NST ? st - NST : st;  // past the end: the head of the stream again (never read)
         if (HEADS && sw >= NRS) sw += hs * (HEAD_FR / RS_FR);  // (this workgroup's head)
-        if (SPLIT && sw >= FR_OUT / RS_FR) sw += 4 * cbase;    // (this workgroup's hidden chunks)
+        if (SPLIT && sw >= FR_OUT / RS_FR) {  // (this workgroup's hidden chunks: its first A0 and last B2 sit one phase away from the run between them)
+            const int n = sw - FR_OUT / RS_FR;
+            sw += 4 * cbase - (n == 0 && cbase > 0) + (n == 4 * NCHL - 1 && cbase + NCHL < NCH);
+        }
         const int fo = (wu + 4 * pc) * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lptr_t)(smem + slot * RS_B + fo), 16, lane16, sw * RS_B + fo, 0, 0);
 #endif
@@ -492,49 +507,55 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     // ---- FFN
     f32x16 h0, h1;   // hidden accumulators of the chunk
     u32x4 hb[4];     // its four bf16 k-step fragments (B operand of FFN2)
-    auto bias_init = [&](f32x16& hh, int c, int t) {  // hidden accumulator := linear1 bias of its 32 units
+    auto bias_quarter = [&](f32x16& hh, int c, int t, int q) {  // registers 4 q.. of a hidden accumulator := linear1 bias of their units
+        const f32x4 b = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_B1 + 64 * c + 32 * t + 8 * q);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_B1 + 64 * c + 32 * t + 8 * q);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) hh[4 * q + i] = b[i];
-        }
+        for (int i = 0; i < 4; ++i) hh[4 * q + i] = b[i];
     };
-    // gelu of registers e, e + 1 (e even) of hidden tile t.  The wave's VALU issue bounds these phases (transcendentals
+    auto bias_init = [&](f32x16& hh, int c, int t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bias_quarter(hh, c, t, q);
+    };
+    // gelu of register e of hidden tile t.  The wave's VALU issue bounds these phases (transcendentals
     // cost 1.8 ordinary instructions, packed fp32 arithmetic does not overlap the MFMAs), so the cheapest form that
     // stays below the bf16 rounding of the hidden activations is used:
     //     gelu(x) = x / (1 + exp(-s(x))),  s(x) = x (c0 + c1 x^2 + c2 x^4),  x^2 clamped at 50
     // fitted (minimax over [-8, 8]) to x Phi(x): |d gelu| <= 2.6e-5 everywhere, where the exact-erf form of the GEMM
     // epilogues (gemm_epilogue.h, A&S 7.1.26) costs 13 instructions + 2 transcendentals per value against 7 + 2 here.
-    // Both values advance by a quarter per MFMA slot of the group (neighbouring instructions belong to different
-    // dependency chains); the last quarter packs the pair into fragment 2 t + (e >> 3) of hb.
+    // A value advances by a quarter per MFMA slot of its group (the transcendental of one slot is consumed in the next);
+    // the last quarter of an odd value packs its pair into fragment 2 t + (e >> 3) of hb.
     float gx[2], gq[2], gs[2];
-    auto gelu_slice = [&](const f32x16& hh, int t, int e, int k) {
+    auto gelu_val = [&](const f32x16& hh, int t, int e, int k) {
         constexpr float C0 = -2.3011212f, C1 = -0.10677572f, C2 = 0.001014263f;  // -log2(e) * (c0, c1, c2)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (k == 0) {
-                const float x = hh[e + j];
-                gx[j] = x;
-                gs[j] = fminf(x * x, 50.0f);
-                gq[j] = fmaf(gs[j], C2, C1);
-            } else if (k == 1) {
-                gq[j] = fmaf(gs[j], gq[j], C0);
-                gq[j] = __builtin_amdgcn_exp2f(gx[j] * gq[j]);
-            } else if (k == 2) {
-                gq[j] = __builtin_amdgcn_rcpf(gq[j] + 1.0f);
-            } else {
-                gx[j] = DBG == 2 ? gx[j] : gx[j] * gq[j];
+        const int j = e & 1;
+        if (k == 0) {
+            const float x = hh[e];
+            gx[j] = x;
+            gs[j] = fminf(x * x, 50.0f);
+            gq[j] = fmaf(gs[j], C2, C1);
+        } else if (k == 1) {
+            gq[j] = fmaf(gs[j], gq[j], C0);
+            gq[j] = __builtin_amdgcn_exp2f(gx[j] * gq[j]);
+        } else if (k == 2) {
+            gq[j] = __builtin_amdgcn_rcpf(gq[j] + 1.0f);
+        } else {
+            gx[j] = DBG == 2 ? gx[j] : gx[j] * gq[j];
+            if (j == 1) {
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                bf16x2 w;
+                w[0] = (bf16_t)gx[0];
+                w[1] = (bf16_t)gx[1];
+                hb[2 * t + (e >> 3)][(e & 7) >> 1] = __builtin_bit_cast(unsigned, w);
             }
         }
-        if (k == 3) {
-            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-            bf16x2 w;
-            w[0] = (bf16_t)gx[0];
-            w[1] = (bf16_t)gx[1];
-            hb[2 * t + (e >> 3)][(e & 7) >> 1] = __builtin_bit_cast(unsigned, w);
-        }
     };
+    // the whole tile beside one phase (two values per group) | half hf of it (one value per group)
+    auto gelu_full = [&](const f32x16& hh, int t, int g, int k) {
+        if (DBG == 5 && g % 2) return;
+        gelu_val(hh, t, 2 * g, k);
+        gelu_val(hh, t, 2 * g + 1, k);
+    };
+    auto gelu_half = [&](const f32x16& hh, int t, int hf, int g, int k) { gelu_val(hh, t, 8 * hf + g, k); };
     // B operand of MFMA i of an FFN1 phase (group g = i / 4): registers for the first three of a group, LDS for the fourth
     u32x4 R2[2];  // the LDS-resident LayerNorm-2 fragment of an FFN1 group, by group parity
     auto a_operand = [&](int i, int g) -> u32x4 { return i % 4 < 3 ? act[a_kstep(i)] : R2[g & 1]; };
@@ -550,46 +571,73 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     bias_init(h0, cbase, 0);
     bias_init(h1, cbase, 1);
     act_reads(0);
-    // one chunk = four phases A0 A1 B1 B2 starting in ring slot SL0 (the slot pattern repeats every three chunks)
-    auto chunk = [&](int c, auto s0_c) {
+    // The four phases of a chunk are interleaved with its neighbours' so that every phase carries half a tile of gelu (the
+    // wave's instruction issue bounds a phase that carries a whole one: 56 against 41 clocks per MFMA):
+    //     A0(0) A1(0) B1(0) | A0(c) B2(c-1) A1(c) B1(c), c = 1.. | B2(last)
+    // gelu of tile 0 of chunk c: first half beside B2(c-1), second beside A1(c); of tile 1: beside B1(c) and A0(c+1).  The
+    // linear1 bias of the next use goes into a hidden accumulator in the phase after its gelu is over (h0: B1, h1: B2).
+    // FFN2's k order (chunk by chunk, k-steps 0..3) is unchanged, and so is every bit of the result.
+    auto stamp_kind = [&](int kind) {
+        if (DBG == 3) { const long long t = __builtin_readcyclecounter(); psum[kind] += t - pt; pt = t; }
+    };
+    auto a_extra = [&](int gn) { if (gn < 8) act_reads(gn); };         // (a B phase follows)
+    auto b_extra = [&](int gn) { if (gn == 8) act_reads(8); };         // (an A phase follows)
+    if (DBG == 3) pt = __builtin_readcyclecounter();
+    // chunk 0: A0 A1 B1 (ring slots 1 2 0)
+    phase(16, S1{}, act_reads, [&](int i, u32x4 a, int g) { mfma_v(h0, a, a_operand(i, g)); }, no_valu);
+    mfma_done_v(h0);
+    stamp_kind(0);
+    phase(17, S2{}, a_extra, [&](int i, u32x4 a, int g) { mfma_v(h1, a, a_operand(i, g)); },
+          [&](int g, int k) { gelu_full(h0, 0, g, k); });
+    mfma_done_v(h1);
+    stamp_kind(1);
+    // B1(c): hidden k-steps 0, 1; gelu of tile 1 (first half; all of it in the last chunk, whose B2 follows directly)
+    auto phase_b1 = [&](int c, auto sl_c, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
+        phase(16 + 4 * c + 2, sl_c, b_extra, [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], a, hb[i / 16]); },
+              [&](int g, int k) {
+                  if (LAST) {
+                      gelu_full(h1, 1, g, k);
+                  } else {
+                      gelu_half(h1, 1, 0, g, k);
+                      if (g % 2 == 1 && k == 0) bias_quarter(h0, c + 1 + cbase, 0, g >> 1);
+                  }
+              });
+        stamp_kind(2);
+    };
+    phase_b1(0, S0{}, std::false_type{});
+    auto rnd4 = [&](int c, auto s0_c, auto last_c) {  // A0(c) B2(c-1) A1(c) B1(c), starting in ring slot SL0
         constexpr int SL0 = decltype(s0_c)::value;
         using P0 = std::integral_constant<int, SL0 % 3>;
         using P1 = std::integral_constant<int, (SL0 + 1) % 3>;
         using P2 = std::integral_constant<int, (SL0 + 2) % 3>;
-        const int ph = 16 + 4 * c;
-        const int cn = (c + 1 < NCHL ? c + 1 : c) + cbase;
-        if (DBG == 3) pt = __builtin_readcyclecounter();
-        // A0: hidden tile 0
-        phase(ph, P0{}, act_reads, [&](int i, u32x4 a, int g) { mfma_v(h0, a, a_operand(i, g)); }, no_valu);
+        const int ph = 16 + 4 * c - 1;
+        phase(ph, P0{}, a_extra, [&](int i, u32x4 a, int g) { mfma_v(h0, a, a_operand(i, g)); },
+              [&](int g, int k) { gelu_half(h1, 1, 1, g, k); });
         mfma_done_v(h0);
-        if (DBG == 3) { const long long t = __builtin_readcyclecounter(); psum[0] += t - pt; pt = t; }
-        // A1: hidden tile 1; gelu of tile 0 (two values per group)
-        phase(ph + 1, P1{}, [&](int gn) { if (gn < 8) act_reads(gn); },
-              [&](int i, u32x4 a, int g) { mfma_v(h1, a, a_operand(i, g)); },
-              [&](int g, int k) { if (DBG != 5 || g % 2 == 0) gelu_slice(h0, 0, 2 * g, k); });
-        mfma_done_v(h1);
-        if (DBG == 3) { const long long t = __builtin_readcyclecounter(); psum[1] += t - pt; pt = t; }
-        // B1: hidden k-steps 0, 1 into the 16 feature tiles; gelu of tile 1
-        phase(ph + 2, P2{}, no_extra, [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], a, hb[i / 16]); },
-              [&](int g, int k) { if (DBG != 5 || g % 2 == 0) gelu_slice(h1, 1, 2 * g, k); });
-        if (DBG == 3) { const long long t = __builtin_readcyclecounter(); psum[2] += t - pt; pt = t; }
-        // B2: hidden k-steps 2, 3; the next chunk's linear1 bias goes into the (now free) hidden accumulators
-        phase(ph + 3, P0{}, [&](int gn) { if (gn == 8) act_reads(8); },
-              [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], a, hb[2 + i / 16]); },
+        stamp_kind(0);
+        phase(ph + 1, P1{}, b_extra, [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], a, hb[2 + i / 16]); },
               [&](int g, int k) {
-                  if (g == 1 && k == 0) bias_init(h0, cn, 0);
-                  if (g == 4 && k == 0) bias_init(h1, cn, 1);
+                  gelu_half(h0, 0, 0, g, k);
+                  if (g % 2 == 1 && k == 0) bias_quarter(h1, c + cbase, 1, g >> 1);
               });
-        if (DBG == 3) psum[3] += __builtin_readcyclecounter() - pt;
+        stamp_kind(3);
+        phase(ph + 2, P2{}, a_extra, [&](int i, u32x4 a, int g) { mfma_v(h1, a, a_operand(i, g)); },
+              [&](int g, int k) { gelu_half(h0, 0, 1, g, k); });
+        mfma_done_v(h1);
+        stamp_kind(1);
+        phase_b1(c, P0{}, last_c);
     };
-    // phase 16 = slot 1; a chunk advances the slot by 4 = 1 (mod 3)
-    chunk(0, S1{});
-    chunk(1, S2{});
-    for (int c = 2; c < NCHL; c += 3) {  // chunks 2..31 = ten rounds of three
-        chunk(c, S0{});
-        chunk(c + 1, S1{});
-        chunk(c + 2, S2{});
+    // round c starts in slot (16 + 4 c - 1) % 3 = c % 3
+    for (int c = 1; c < NCHL - 1; c += 3) {  // rounds 1..30 = ten times three
+        rnd4(c, S1{}, std::false_type{});
+        rnd4(c + 1, S2{}, std::false_type{});
+        rnd4(c + 2, S0{}, std::false_type{});
     }
+    rnd4(NCHL - 1, S1{}, std::true_type{});
+    // B2 of the last chunk (slot 2)
+    phase(16 + 4 * NCHL - 1, S2{}, no_extra, [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], a, hb[2 + i / 16]); }, no_valu);
+    stamp_kind(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the pieces issued past the end of the stream
     mfma_done_a(acc);
     stamps[4] = __builtin_readcyclecounter();
