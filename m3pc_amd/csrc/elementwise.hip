@@ -662,8 +662,123 @@ __global__ __launch_bounds__(256) void critic_kernel(CriticP p) {
         }
     }
 }
+// The same network on the matrix cores in fp32 (v_mfma_f32_32x32x2_f32: every product an exact fp32 fma), transposed like
+// the fused layer tail: weights = A operand, data rows = B operand, so a lane owns ONE data row (lane & 31) and its
+// registers run over hidden units -- acc[i] <-> unit 32 t + 8 (i / 4) + 4 (lane >> 5) + i % 4.  An accumulator after
+// bias + ReLU therefore IS the B operand of the next layer's MFMAs: step (g, j) of layer 2 multiplies the k pair
+// {8 g + j, 8 g + 4 + j} (one per lane half), which is register 4 (g % 4) + j of hidden tile g / 4 in both halves.  The 256
+// hidden values of a row never leave the registers; no LDS, no barrier.  Weights are packed once (m3pc_set_critic) in
+// operand order, four steps per lane and load: one 1-KiB coalesced load per four MFMAs and wave, read four groups ahead.
+//   W1F: [tile t][group g < 4][lane][j]  = W1[32 t + (lane & 31)][2 (4 g + j) + (lane >> 5)]   (features padded to 32 with zeros)
+//   W2F: [tile u][group g < hidden / 8][lane][j] = W2[32 u + (lane & 31)][8 g + 4 (lane >> 5) + j]   (+ 4 KiB of padding)
+// A wave = 32 data rows, 2 x (16 + hidden / 2) x hidden / 32 MFMAs of 64 clocks: 65536 rows (walker2d critic N = 4096) take
+// what 2048 waves on 1024 SIMDs take, ~2 x 143 k clocks, where the scalar kernel above (LDS-broadcast bound) took 680 us of
+// chip time.  Row results do not depend on the row's position or on the number of rows.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void critic_mfma_kernel(CriticP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f32x16v __attribute__((ext_vector_type(16)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int r = (blockIdx.x * 4 + wave) * 32 + l31;
+    if ((blockIdx.x * 4 + wave) * 32 >= p.rows) return;  // (wave-uniform; no barriers in this kernel)
+    const long long rl = r < p.rows ? r : p.rows - 1;
+    const int SA = p.S + p.A;
+    float x[16];  // feature 2 s + lh of this lane's row
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int f = 2 * s + lh;
+        float v = 0.f;
+        if (f < p.S) v = (p.states[rl * p.S + f] - p.om[f]) / p.os[f];
+        else if (f < SA) v = p.actions[rl * p.A + (f - p.S)];
+        x[s] = v;
+    }
+    float qmin = 0.f;
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {
+        f32x16v h1[NT];
+        const f32x4v* w1p = (const f32x4v*)p.W1F[net] + lane;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4v b = *(const f32x4v*)(p.b1[net] + 32 * t + 8 * q + 4 * lh);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h1[t][4 * q + i] = b[i];
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4v w = w1p[(t * 4 + g) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j], x[4 * g + j], h1[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) h1[t][i] = fmaxf(h1[t][i], 0.f);
+        }
+        const f32x4v* w2p = (const f32x4v*)p.W2F[net] + lane;
+        f32x4v wf[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wf[g] = w2p[g * 64];
+        float qa = 0.f;
+        for (int u = 0; u < NT; ++u) {
+            f32x16v acc;
+            f32x4v w3[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4v b = *(const f32x4v*)(p.b2[net] + 32 * u + 8 * q + 4 * lh);
+                w3[q] = *(const f32x4v*)(p.W3[net] + 32 * u + 8 * q + 4 * lh);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[4 * q + i] = b[i];
+            }
+#pragma unroll
+            for (int g = 0; g < 4 * NT; ++g) {
+                const f32x4v w = wf[g % 4];
+                wf[g % 4] = w2p[((u * 4 * NT) + g + 4) * 64];  // (runs 4 groups past the end: the buffer is padded)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j], h1[g / 4][4 * (g % 4) + j], acc, 0, 0, 0);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum = fmaf(fmaxf(acc[i], 0.f), w3[i / 4][i % 4], sum);
+            sum += __shfl_xor(sum, 32);
+            qa += sum;
+        }
+        const float q = qa + p.b3[net][0];
+        qmin = net == 0 ? q : fminf(qmin, q);
+    }
+    if (lh == 0 && r < p.rows) p.q[r] = qmin;
+#endif
+}
+bool critic_mfma_covers(int S, int A, int hidden) { return S + A <= 32 && (hidden == 64 || hidden == 128 || hidden == 256); }
+size_t critic_w1f_floats(int hidden) { return (size_t)(hidden / 32) * 4 * 256; }
+size_t critic_w2f_floats(int hidden) { return (size_t)(hidden / 32) * (hidden / 8) * 256 + 1024; }
+// host-side packing of one network's two weight matrices (W1: hidden x SA, W2: hidden x hidden, row-major as in the state dict)
+void critic_pack(const float* W1, const float* W2, int SA, int hidden, float* w1f, float* w2f) {
+    const int NT = hidden / 32;
+    for (int t = 0; t < NT; ++t)
+        for (int g = 0; g < 4; ++g)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int f = 2 * (4 * g + j) + (lane >> 5);
+                    w1f[(((size_t)t * 4 + g) * 64 + lane) * 4 + j] = f < SA ? W1[(size_t)(32 * t + (lane & 31)) * SA + f] : 0.f;
+                }
+    const int NG = hidden / 8;
+    for (int u = 0; u < NT; ++u)
+        for (int g = 0; g < NG; ++g)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j)
+                    w2f[(((size_t)u * NG + g) * 64 + lane) * 4 + j] = W2[(size_t)(32 * u + (lane & 31)) * hidden + 8 * g + 4 * (lane >> 5) + j];
+    for (size_t i = (size_t)NT * NG * 256; i < critic_w2f_floats(hidden); ++i) w2f[i] = 0.f;
+}
 void launch_critic(const CriticP& p, hipStream_t st) {
     if (p.rows <= 0) return;
+    if (p.W1F[0] && critic_mfma_covers(p.S, p.A, p.hidden)) {
+        const dim3 grid((p.rows + 127) / 128), block(256);
+        if (p.hidden == 256) hipLaunchKernelGGL(critic_mfma_kernel<8>, grid, block, 0, st, p);
+        else if (p.hidden == 128) hipLaunchKernelGGL(critic_mfma_kernel<4>, grid, block, 0, st, p);
+        else hipLaunchKernelGGL(critic_mfma_kernel<2>, grid, block, 0, st, p);
+        return;
+    }
     hipLaunchKernelGGL(critic_kernel, dim3((p.rows + CR_ROWS - 1) / CR_ROWS), dim3(256), 0, st, p);
 }
 

@@ -333,9 +333,15 @@ struct CriticP {
     const float* b2[2];
     const float* W3[2];   // (hidden,)
     const float* b3[2];
+    const float* W1F[2];  // the two weight matrices in MFMA operand order (critic_pack), or null: the scalar kernel runs
+    const float* W2F[2];
     float* q;             // (rows,)
 };
 void launch_critic(const CriticP& p, hipStream_t st);
+bool critic_mfma_covers(int S, int A, int hidden);
+size_t critic_w1f_floats(int hidden);
+size_t critic_w2f_floats(int hidden);
+void critic_pack(const float* W1, const float* W2, int SA, int hidden, float* w1f, float* w2f);
 
 // TD(lambda) scoring (learner.py:300-316)
 struct ScoreP {

@@ -138,6 +138,7 @@ struct m3pc_handle {
     bool critic_set = false;
     float *cW1T[2] = {nullptr, nullptr}, *cb1[2] = {nullptr, nullptr}, *cW2T[2] = {nullptr, nullptr},
           *cb2[2] = {nullptr, nullptr}, *cW3[2] = {nullptr, nullptr}, *cb3[2] = {nullptr, nullptr};
+    float *cW1F[2] = {nullptr, nullptr}, *cW2F[2] = {nullptr, nullptr};  // MFMA operand order (critic_pack)
     float *c_om = nullptr, *c_os = nullptr;
     // workspace
     long long R = 0;
@@ -1695,6 +1696,8 @@ int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states,
             c.b2[i] = h->cb2[i];
             c.W3[i] = h->cW3[i];
             c.b3[i] = h->cb3[i];
+            c.W1F[i] = h->cW1F[i];
+            c.W2F[i] = h->cW2F[i];
         }
         c.q = h->qv;
         launch_critic(c, st);
@@ -1852,6 +1855,10 @@ int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out) {
             CHK(dmalloc(&h->cb2[i], Hd));
             CHK(dmalloc(&h->cW3[i], Hd));
             CHK(dmalloc(&h->cb3[i], 4));
+            if (critic_mfma_covers(h->S, h->A, Hd)) {
+                CHK(dmalloc(&h->cW1F[i], critic_w1f_floats(Hd)));
+                CHK(dmalloc(&h->cW2F[i], critic_w2f_floats(Hd)));
+            }
         }
         CHK(dmalloc(&h->c_om, 32));
         CHK(dmalloc(&h->c_os, 32));
@@ -1900,7 +1907,7 @@ int m3pc_destroy(m3pc_handle* h) {
     for (void* b : bufs)
         if (b) hipFree(b);
     for (int i = 0; i < 2; ++i) {
-        void* cb[] = {h->cW1T[i], h->cb1[i], h->cW2T[i], h->cb2[i], h->cW3[i], h->cb3[i]};
+        void* cb[] = {h->cW1T[i], h->cb1[i], h->cW2T[i], h->cb2[i], h->cW3[i], h->cb3[i], h->cW1F[i], h->cW2F[i]};
         for (void* b : cb)
             if (b) hipFree(b);
     }
@@ -2090,6 +2097,12 @@ int m3pc_set_critic(m3pc_handle* h, const m3pc_named_tensor* tensors, int n, con
         HIPCHK(hipMemcpy(h->cb2[qn], b2.data(), b2.size() * sizeof(float), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->cW3[qn], w3.data(), w3.size() * sizeof(float), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->cb3[qn], b3.data(), sizeof(float), hipMemcpyHostToDevice));
+        if (h->cW1F[qn]) {
+            std::vector<float> w1f(critic_w1f_floats(Hd)), w2f(critic_w2f_floats(Hd));
+            critic_pack(w1.data(), w2.data(), SA, Hd, w1f.data(), w2f.data());
+            HIPCHK(hipMemcpy(h->cW1F[qn], w1f.data(), w1f.size() * sizeof(float), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(h->cW2F[qn], w2f.data(), w2f.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     HIPCHK(hipMemcpy(h->c_om, obs_mean, h->S * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->c_os, obs_std, h->S * sizeof(float), hipMemcpyHostToDevice));
