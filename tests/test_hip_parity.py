@@ -304,6 +304,34 @@ def test_odd_shapes_match_oracle(T, H, N, mode):
     h.close()
 
 
+@pytest.mark.parametrize("hidden", [64, 128, 96])
+def test_critic_widths_match_oracle(hidden):
+    """TwinQ at other hidden widths (finetune_omtm/model.py:146-171): 64 / 128 run the fp32 matrix-core kernel (256 is every
+    other critic test), 96 the scalar one; 130 rows = four whole 32-row tiles and a ragged one."""
+    T, H, N = 8, 4, 130
+    dims = synth.Dims(11, 3, T)
+    h = capi.Handle(dims.state_dim, dims.action_dim, dims.traj_length, dims.n_embd, dims.n_head, dims.n_enc_layer,
+                    dims.n_dec_layer, max_candidates=N, max_batch=1, critic_hidden=hidden)
+    sd = synth.make_state_dict(dims, 0)
+    h.load_weights(sd)
+    tstats = synth.make_tokenizer_stats(dims, 0)
+    for k, name in enumerate(synth.KEYS):
+        h.set_tokenizer(k, tstats[name]["mean"], tstats[name]["std"], normalize=(name != "actions"))
+    critic = synth.make_critic(dims, 0, hidden=hidden)
+    h.set_critic(*critic)
+    cfg = O.PlanCfg(T, H, N, 0.99, 1.0, 0.6)
+    win, hh = O.assemble_window(cfg, synth.make_history(dims, 3), 300, 2.0)
+    eps = synth.make_eps(N, dims, 9)
+    ref = O.guiding(sd, O.make_stats(tstats), cfg, win, H, 0.6, eps, "critic", critic=critic)
+    s, a, r = window_dev(win)
+    res = h.plan_step(MODES["critic"], s, a, r, eps[:, 0, :, 0, :].cuda(), H, 2.0, 0.6, 0.99, N)
+    scale = max(float(ref["expect_return"].abs().max()), 1.0)
+    assert float((res["expect_return"].cpu() - ref["expect_return"]).abs().max()) <= 5e-5 * scale
+    p_, ev, am = h.select(res["expect_return"], res["sample_actions"][:, 0], cfg.temperature)
+    assert int(am.item()) == ref["argmax"]
+    h.close()
+
+
 @pytest.mark.parametrize("T,H,N,mode", [(8, 4, 625, "rtg"), (8, 4, 320, "critic"), (16, 8, 300, "rtg")])
 def test_few_tile_bf16_passes_match_oracle(T, H, N, mode):
     """bf16 candidate passes of 16..96 fused-tail tiles (the reference's shipped N=625 / H=4 / T=8 config among them) take the
