@@ -132,14 +132,14 @@ __global__ __launch_bounds__(256) void pack_block_stream_kernel(const bf16_t* __
     for (int j = 0; j < 8; ++j) o[j] = v[j];
 }
 
-// fragments FR_TOTAL.. of a layer's stream: the NEXT layer's in_proj rows (Q, K, V: 512 fragments each, phase sb = k-steps
-// 2 sb, 2 sb + 1 of the 16 feature tiles, permuted k -- the other operand is the LayerNorm of an accumulator)
+// fragments FR_TOTAL.. of a layer's stream: the NEXT layer's in_proj rows (Q | K | V: 48 feature tiles, one phase of 32 k-steps
+// each, permuted k -- the other operand is the LayerNorm of an accumulator)
 __global__ __launch_bounds__(256) void pack_block_qkv_kernel(const bf16_t* __restrict__ Wqkv, bf16_t* __restrict__ out) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     if (gid >= QKV_FR * 64) return;
     const int f = gid >> 6, lane = gid & 63, r = lane & 31, h = lane >> 5;
-    const int hf = f / FR_OUT, g = f % FR_OUT, sb = g / 32, kk = (g % 32) / 16, jn = g % 16, ks = 2 * sb + kk;
-    const size_t row = (size_t)(BD * hf + 32 * jn + r) * BD;
+    const int jt = f / KS, ks = f % KS;  // phase jt = the 32 k-steps of feature tile jt (of the 48 of Q | K | V)
+    const size_t row = (size_t)(32 * jt + r) * BD;
     bf16_t* o = out + (size_t)(FR_TOTAL * 64 + gid) * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = Wqkv[row + 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3)];
@@ -190,6 +190,9 @@ __device__ __forceinline__ void mfma_a(f32x16& c, u32x4 a, u32x4 b) {
 }
 __device__ __forceinline__ void mfma_v(f32x16& c, u32x4 a, u32x4 b) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_v_ab(f32x16& c, u32x4 a, u32x4 b) {  // B operand from the accumulator half of the file
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
 }
 __device__ __forceinline__ void mfma_v0(f32x16& c, u32x4 a, u32x4 b) {  // c = a b (no accumulator input)
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
@@ -656,18 +659,47 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
         }
     }
     acc_touch(acc);
-    if (p.Xout && valid) {  // (SPLIT: this quarter's slab of M rows)
-        float* xrow = p.Xout + ((SPLIT ? (size_t)blockIdx.y * p.M : 0) + (size_t)rtok) * p.ldx;
+    if constexpr (!HEADS) if (p.Xout) {  // (SPLIT: this quarter's slab of M rows; the head variant never stores X'')
+        // Through the wave's staging buffers (idle since the FFN's last FFN1 phase) so that a store instruction writes 8 rows x
+        // one whole 128-byte line: a lane owns 16 bytes of each of its row's lines, and stored from the registers every
+        // instruction touched 32 lines for 1 KiB -- 8192 line touches per wave, which is what the X'' store took (23 k clocks
+        // per tile, the texture path's one line per clock; staged: 512).  Same swizzle as the residual tiles' way in.
+        const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)p.Xout, 0, (unsigned)((unsigned long long)(SPLIT ? SPLIT_N : 1) * p.M * p.ldx * 4), 0x00020000);
+        (void)x_rs;
+        const int r8 = lane >> 3, cc = lane & 7;
+        unsigned xoff[4];
 #pragma unroll
-        for (int jn = 0; jn < NT; ++jn)
+        for (int pp = 0; pp < 4; ++pp) {
+            const int rr = row0 + 32 * wu + 8 * pp + r8;
+            xoff[pp] = rr < p.M ? (unsigned)(((SPLIT ? (size_t)blockIdx.y * p.M : 0) + (size_t)rr) * p.ldx * 4 + ((cc ^ r8) << 4)) : 0x80000000u;
+        }
+        typedef char __attribute__((address_space(3))) * lds_c_t;
+        lds_c_t xwr = (lds_c_t)(rstage + l31 * 128);
+        lds_c_t xrd = (lds_c_t)(rstage + r8 * 128 + cc * 16);
+        asm volatile("" : "+v"(xwr), "+v"(xrd));
+        u32x4 xs[2][4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 x;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x[i] = acc[jn][4 * q + i];
-                *(f32x4*)(xrow + 32 * jn + 8 * q + 4 * lh) = x;
-                if (q == 3) __builtin_amdgcn_sched_barrier(0);
+                *(f32x4 __attribute__((address_space(3)))*)(xwr + (jn & 1) * 4096 + (((2 * q + lh) ^ (l31 & 7)) << 4)) = x;
             }
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) xs[jn & 1][pp] = *(const u32x4 __attribute__((address_space(3)))*)(xrd + (jn & 1) * 4096 + pp * 1024);
+            if (jn > 0) {
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) __builtin_amdgcn_raw_buffer_store_b128(xs[(jn - 1) & 1][pp], x_rs, xoff[pp], (jn - 1) * 128, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) __builtin_amdgcn_raw_buffer_store_b128(xs[(NT - 1) & 1][pp], x_rs, xoff[pp], (NT - 1) * 128, 0);
+#endif
     }
     stamps[5] = __builtin_readcyclecounter();
     acc_touch(acc);
@@ -715,72 +747,102 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) w[j] = (bf16_t)y[j];
             qa[s] = __builtin_bit_cast(u32x4, w);
-            asm volatile("" : "+v"(qa[s]));
+            asm volatile("" : "+a"(qa[s]));  // (the 32 fragments live where the feature accumulators were: B operands may)
         }
         const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.QKVout, 0, p.qkv_bytes, 0x00020000);
         (void)q_rs;
-        unsigned rowoff[16];  // byte offsets of the 16 token rows this lane stores (rows past the end: out of the buffer's range, dropped)
+        // Feature tile by feature tile (phase j = the 32 k-steps of tile j of the 48: one accumulator chain, as the out-proj),
+        // two hidden-style accumulators in turn: while tile j accumulates, tile j - 1 is rounded to bf16 and written to this
+        // wave's staging buffers (its 8 KiB of the LayerNorm-2 fragment region, idle since the FFN: 2 x {32 rows x 128 B},
+        // 16-byte chunks swizzled by row & 7), the accumulator it leaves takes the bias of tile j + 1, and every second phase a
+        // finished pair of tiles leaves as four 1-KiB stores -- 8 rows x one whole 128-byte line each -- issued right behind
+        // the stage sync, so that they have two phases to complete before a sync has to wait for them (vector-memory
+        // operations complete in issue order: the sync of the following phase counts them, vmcnt(11)).  Round 3 ran three
+        // times 16 phases over all 16 tiles of Q, of K, of V with the operands swapped, stored each third with 256 two-byte
+        // stores per lane and drained them (vmcnt(0)) before the next: 95-104 k clocks per tile for 1536 MFMAs.
+        for (int i = tid; i < 3 * BD / 4; i += 256) *(f32x4*)(tab + T_B1 + 4 * i) = *(const f32x4*)(p.bqkv + 4 * i);  // (the linear1 bias table is dead)
+        unsigned srow[4];  // store pp: byte offset of row 8 pp + (lane >> 3) of the wave's 32 + this lane's (un-swizzled) chunk
+        {
+            const int r8 = lane >> 3, cc = lane & 7;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int rr = row0 + 32 * wu + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            rowoff[e] = rr < p.M ? (unsigned)rr * (unsigned)(p.ldq * 2) + (unsigned)(l31 * 2) : 0x80000000u;
+            for (int pp = 0; pp < 4; ++pp) {
+                const int rr = row0 + 32 * wu + 8 * pp + r8;
+                srow[pp] = rr < p.M ? (unsigned)rr * (unsigned)(p.ldq * 2) + (unsigned)((cc ^ r8) * 16) : 0x80000000u;
+            }
         }
-        auto bias_init = [&](int hf) {
-            float bq[NT];
+        typedef char __attribute__((address_space(3))) * lds_c_t;
+        lds_c_t const swr = (lds_c_t)(rstage + l31 * 128 + lh * 8);                     // + buffer * 4096 + swizzled chunk * 16
+        lds_c_t srd = (lds_c_t)(rstage + (lane >> 3) * 128 + (lane & 7) * 16);          // + buffer * 4096 + pp * 1024
+        asm volatile("" : "+v"(srd));
+        f32x16 hA, hB;
+        u32x4 sreg[4];
+        auto bias_q = [&](f32x16& hh, int j, int q) {  // registers 4 q.. := in_proj bias of features 32 j + 8 q + 4 lh ..
+            const f32x4 bb = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_B1 + 32 * j + 8 * q);
 #pragma unroll
-            for (int jn = 0; jn < NT; ++jn) bq[jn] = p.bqkv[BD * hf + 32 * jn + l31];
-#pragma unroll
-            for (int jn = 0; jn < NT; ++jn) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[jn][e] = bq[jn];
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int i = 0; i < 4; ++i) hh[4 * q + i] = bb[i];
         };
-        auto store_third = [&](int hf) {
-            acc_touch(acc);
-#if defined(__HIP_DEVICE_COMPILE__)
+        auto stage_q = [&](const f32x16& hh, int t, int q) {  // quarter q of finished tile t -> bf16 -> staging
+            typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            bf16x4v w;
 #pragma unroll
-            for (int jn = 0; jn < NT; ++jn) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const bf16_t w = (bf16_t)acc[jn][e];
-                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, w), q_rs, rowoff[e] + (BD * hf + 32 * jn) * 2, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#endif
+            for (int i = 0; i < 4; ++i) w[i] = (bf16_t)hh[4 * q + i];
+            const int c = (t & 1) * 4 + q;
+            *(u32x2 __attribute__((address_space(3)))*)(swr + ((t >> 1) & 1) * 4096 + ((c ^ (l31 & 7)) << 4)) = __builtin_bit_cast(u32x2, w);
         };
-        // the X'' stores are out (they share vmcnt with the DMA pieces and complete out of order with respect to them); the
-        // stages 144, 145 landed before the FFN ended.  Fragment groups 0, 1 of stage 144 (slot 0):
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the X'' stores are out (they share vmcnt with the DMA pieces); the stages 144, 145 landed before the FFN ended.
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (+ the bias table)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             R[0][k] = frag(0, k);
             R[1][k] = frag(0, 4 + k);
         }
-#define QKV_PH(base, sb, SL) phase((base) + (sb), SL{}, no_extra, [&](int i, u32x4 a, int) { mfma_a(acc[i % 16], qa[2 * (sb) + i / 16], a); }, no_valu);
-        bias_init(0);  // Q: phases 144..159 (phase 144 = slot 0)
-        QKV_PH(144, 0, S0) QKV_PH(144, 1, S1) QKV_PH(144, 2, S2) QKV_PH(144, 3, S0) QKV_PH(144, 4, S1) QKV_PH(144, 5, S2)
-        QKV_PH(144, 6, S0) QKV_PH(144, 7, S1) QKV_PH(144, 8, S2) QKV_PH(144, 9, S0) QKV_PH(144, 10, S1) QKV_PH(144, 11, S2)
-        QKV_PH(144, 12, S0) QKV_PH(144, 13, S1) QKV_PH(144, 14, S2) QKV_PH(144, 15, S0)
-        mfma_done_a(acc);
-        store_third(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        bias_init(1);  // K: phases 160..175 (slot 1)
-        QKV_PH(160, 0, S1) QKV_PH(160, 1, S2) QKV_PH(160, 2, S0) QKV_PH(160, 3, S1) QKV_PH(160, 4, S2) QKV_PH(160, 5, S0)
-        QKV_PH(160, 6, S1) QKV_PH(160, 7, S2) QKV_PH(160, 8, S0) QKV_PH(160, 9, S1) QKV_PH(160, 10, S2) QKV_PH(160, 11, S0)
-        QKV_PH(160, 12, S1) QKV_PH(160, 13, S2) QKV_PH(160, 14, S0) QKV_PH(160, 15, S1)
-        mfma_done_a(acc);
-        store_third(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        bias_init(2);  // V: phases 176..191 (slot 2)
-        QKV_PH(176, 0, S2) QKV_PH(176, 1, S0) QKV_PH(176, 2, S1) QKV_PH(176, 3, S2) QKV_PH(176, 4, S0) QKV_PH(176, 5, S1)
-        QKV_PH(176, 6, S2) QKV_PH(176, 7, S0) QKV_PH(176, 8, S1) QKV_PH(176, 9, S2) QKV_PH(176, 10, S0) QKV_PH(176, 11, S1)
-        QKV_PH(176, 12, S2) QKV_PH(176, 13, S0) QKV_PH(176, 14, S1) QKV_PH(176, 15, S2)
-#undef QKV_PH
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bias_q(hA, 0, q);
+            bias_q(hB, 0, q);  // (phase 0 stages "tile -1" from it: into the half of a buffer that tile 3 overwrites before it is read)
+        }
+        // phase j: HC accumulates tile j; HP (tile j - 1) is staged and re-initialised; STORE: the pair (j - 2, j - 1) leaves
+        auto qkv_phase = [&](int j, auto sl_c, auto nres_c, f32x16& HC, f32x16& HP, auto store_c) {
+            constexpr bool STORE = decltype(store_c)::value;
+            phase_n(144 + j, sl_c, nres_c, no_extra, [&](int i, u32x4 a, int) { mfma_v_ab(HC, a, qa[i]); },
+                    [&](int g, int k) {
+                        if (g == 0) stage_q(HP, j - 1, k);
+                        if (g == 1) bias_q(HP, j + 1, k);
+                        if (STORE && g == 3) sreg[k] = *(const u32x4 __attribute__((address_space(3)))*)(srd + (((j - 2) >> 1) & 1) * 4096 + k * 1024);
+#if defined(__HIP_DEVICE_COMPILE__)
+                        // (behind the sync and stage ph + 2's last piece -- slot (6, 0) shares a scheduling region with that piece,
+                        // so the stores start one slot later; j = 0: nothing is staged yet, the stores go out of the buffer's range)
+                        if (STORE && ((g == 6 && k > 0) || (g == 7 && k == 0))) {
+                            const int pp = g == 6 ? k - 1 : 3;
+                            __builtin_amdgcn_raw_buffer_store_b128(sreg[pp], q_rs, j >= 2 ? srow[pp] : 0x80000000u, ((j - 2) >> 1) * 128, 0);
+                        }
+#endif
+                    });
+            mfma_done_v(HC);
+        };
+        using NR0 = std::integral_constant<int, 0>;
+        using NR4 = std::integral_constant<int, 4>;
+        psum[0] = __builtin_readcyclecounter();
+        for (int j = 0; j < 3 * NT; j += 6) {  // (even phases store; the phase behind a storing one counts its four stores)
+            qkv_phase(j, S0{}, NR0{}, hA, hB, std::true_type{});
+            qkv_phase(j + 1, S1{}, NR4{}, hB, hA, std::false_type{});
+            qkv_phase(j + 2, S2{}, NR0{}, hA, hB, std::true_type{});
+            qkv_phase(j + 3, S0{}, NR4{}, hB, hA, std::false_type{});
+            qkv_phase(j + 4, S1{}, NR0{}, hA, hB, std::true_type{});
+            qkv_phase(j + 5, S2{}, NR4{}, hB, hA, std::false_type{});
+        }
+        psum[1] = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the pieces issued past the end of the stream
-        mfma_done_a(acc);
-        store_third(2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stage_q(hB, 3 * NT - 1, q);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u32x4 v = *(const u32x4 __attribute__((address_space(3)))*)(srd + (((3 * NT - 2) >> 1) & 1) * 4096 + k * 1024);
+            __builtin_amdgcn_raw_buffer_store_b128(v, q_rs, srow[k], ((3 * NT - 2) >> 1) * 128, 0);
+        }
+#endif
     } else if constexpr (HEADS) {
         // ---- the output head of this workgroup's key: y = w2 . gelu(W1 LN_head(LN_A(X'')) + b1) + b2, de-tokenised.
         // W1 runs like an FFN1: 16 phases of one hidden tile (32 units over the 32 k-steps), accumulators h0 / h1 in turn;
@@ -943,7 +1005,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     if (p.stamps && (int)blockIdx.x == p.stamp_block && lane == 0) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) p.stamps[wu * 16 + k] = stamps[k];
-        if (DBG == 3)
+        if (DBG == 3 || QKV)  // (QKV: psum[0], [1] = the clock at the first and behind the last Q|K|V phase)
 #pragma unroll
             for (int k = 0; k < 4; ++k) p.stamps[wu * 16 + 8 + k] = psum[k];
     }
@@ -1299,14 +1361,14 @@ bool launch_block_fused(const BlockP& p, hipStream_t st) {
     if (p.M <= 0) return true;
     if (((uintptr_t)p.O & 15) || (p.ldo % 8) || ((uintptr_t)p.wstream & 1023)) return false;
     if (!p.rowtab && (((uintptr_t)p.res & 15) || (p.ldr % 4) || (unsigned long long)p.M * p.ldr * 4 >= 0xfffffff0ull)) return false;  // (32-bit buffer offsets)
-    if (p.Xout && (((uintptr_t)p.Xout & 15) || (p.ldx % 4))) return false;
+    if (p.Xout && (((uintptr_t)p.Xout & 15) || (p.ldx % 4) || (unsigned long long)(p.split ? SPLIT_N : 1) * p.M * p.ldx * 4 >= 0x80000000ull)) return false;  // (32-bit buffer offsets; a row past M is addressed out of range)
     if (p.res_L > 0 && (p.rowtab || p.Xout == p.res || p.res_nshared > p.res_L)) return false;
     if (p.res_nu < 0 || (p.res_nu > 0 && (!p.rowtab || p.res_nu > p.rt_mod || p.split))) return false;
     if (p.rowtab && (unsigned long long)(p.rt_mod + (p.res_nu > 0 ? (unsigned long long)((p.M + p.rt_mod - 1) / p.rt_mod) * p.res_nu : 0)) * BD * 4 >= 0xfffffff0ull) return false;  // (in place, the shared rows would be overwritten while read)
     if (p.Hout && (((uintptr_t)p.Hout & 7) || (p.ldh % 4))) return false;
     if (p.out_mod > 0 && (p.M % p.out_mod != 0 || p.out_mod != 2 * p.out_grp)) return false;
     if (p.QKVout) {  // the next layer's Q|K|V rows instead of its norm1 rows
-        if (p.Hout || p.lnB_g[0] || !p.lnA_g || !p.bqkv || ((uintptr_t)p.QKVout & 3) || p.ldq < 3 * BD) return false;
+        if (p.Hout || p.lnB_g[0] || !p.lnA_g || !p.bqkv || ((uintptr_t)p.QKVout & 15) || p.ldq < 3 * BD || (p.ldq % 8)) return false;  // (16-byte pieces of whole lines)
         if (p.qkv_bytes == 0 || p.qkv_bytes >= 0x80000000u || (unsigned long long)p.M * p.ldq * 2 > p.qkv_bytes) return false;
     }
     if (p.head_out[0]) {  // the two scalar output heads instead of their LayerNorm rows

@@ -53,7 +53,8 @@ def main():
             names = ["prologue", "out-proj", "LN2", "FFN", "X store", "LN + H store | qkv"]
             for w in (0, 3):
                 dl = [int(s[w, k + 1] - s[w, k]) for k in range(6)]
-                print(f"{name} rows {M} wave {w} clocks: " + "  ".join(f"{n} {v}" for n, v in zip(names, dl)) + f"  total {int(s[w, 6] - s[w, 0])}")
+                extra = f"  [fragments {int(s[w, 8] - s[w, 5])}  48 phases {int(s[w, 9] - s[w, 8])}  last pair {int(s[w, 6] - s[w, 9])}]" if name == "tail+qkv" else ""
+                print(f"{name} rows {M} wave {w} clocks: " + "  ".join(f"{n} {v}" for n, v in zip(names, dl)) + f"  total {int(s[w, 6] - s[w, 0])}" + extra)
             ts = []
             for _ in range(12):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
