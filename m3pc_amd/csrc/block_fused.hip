@@ -1025,8 +1025,10 @@ namespace {
 constexpr int KV_FR = FR_OUT + 2 * FR_OUT;   // 1536
 constexpr int KV_NRS = KV_FR / RS_FR;        // 48
 constexpr int KT_G = 0, KT_B = KT_G + BD, KT_BKV = KT_B + BD, KT_END = KT_BKV + 2 * BD;
-constexpr int KV_TAB_OFF = NSLOT * RS_B;
+constexpr int KV_STAGE_OFF = NSLOT * RS_B;           // 4 waves x two 4-KiB staging buffers (table rows in, K|V tiles out)
+constexpr int KV_TAB_OFF = KV_STAGE_OFF + 4 * 8192;
 constexpr int KV_LDS_BYTES = KV_TAB_OFF + KT_END * 4;
+static_assert(KV_LDS_BYTES <= 160 * 1024, "LDS");
 }  // namespace
 
 __global__ __launch_bounds__(256) void pack_kv_stream_kernel(const bf16_t* __restrict__ We, const bf16_t* __restrict__ Wkv,
@@ -1035,13 +1037,12 @@ __global__ __launch_bounds__(256) void pack_kv_stream_kernel(const bf16_t* __res
     if (gid >= KV_FR * 64) return;
     const int f = gid >> 6, lane = gid & 63, r = lane & 31, h = lane >> 5;
     bf16_t v[8];
-    const int g = f % FR_OUT, sb = g / 32, kk = (g % 32) / 16, jn = g % 16, s = 2 * sb + kk;
+    const int jt = f / KS, s = f % KS;  // phase jt = the 32 k-steps of one feature tile: 16 of the embedding, then the 32 of K | V
     if (f < FR_OUT) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = We[(size_t)(32 * jn + r) * BD + 16 * s + 8 * h + j];
+        for (int j = 0; j < 8; ++j) v[j] = We[(size_t)(32 * jt + r) * BD + 16 * s + 8 * h + j];
     } else {
-        const int hf = f / FR_OUT - 1;
-        const size_t row = (size_t)(BD * hf + 32 * jn + r) * BD;
+        const size_t row = (size_t)(32 * (jt - NT) + r) * BD;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = Wkv[row + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
     }
@@ -1088,6 +1089,9 @@ __global__ __launch_bounds__(256, 1) void kv_fused_kernel(KvFusedP p) {
     const char* const lbase2 = smem + 2 * RS_B + lane16;
     auto frag = [&](int slot, int f) -> u32x4 { return *(const u32x4*)((slot == 2 ? lbase2 : lbase0 + slot * RS_B) + f * 1024); };
     float* const tab = (float*)(smem + KV_TAB_OFF);
+    typedef const float __attribute__((address_space(3))) * lds_cf32_t;
+    lds_cf32_t tabl = (lds_cf32_t)(tab + 4 * lh);
+    asm volatile("" : "+v"(tabl));
 
     // ---- prologue
 #pragma unroll
@@ -1102,67 +1106,108 @@ __global__ __launch_bounds__(256, 1) void kv_fused_kernel(KvFusedP p) {
         *(f32x4*)(tab + KT_BKV + i) = *(const f32x4*)(p.bkv + i);
         *(f32x4*)(tab + KT_BKV + BD + i) = *(const f32x4*)(p.bkv + BD + i);
     }
-    // Z fragments (B operand of the embedding; the LayerNorm fragments take their place) first: they come from HBM, the
-    // position-table rows (L2) follow in four batches behind them
+    // Z fragments (B operand of the embedding; dead after it)
     u32x4 ofr[KS];
     {
         const bf16_t* const zrow = p.Z + (size_t)mrow * p.ldz + 8 * lh;
 #pragma unroll
         for (int s = 0; s < KS; ++s) ofr[s] = *(const u32x4*)(zrow + 16 * s);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 acc[NT];
+    // The position-table rows arrive like the residual of the fused layer tail: the embedding runs feature tile by feature
+    // tile, tile jn's accumulator starts at the table values of its 32 features, and those come by LDS-DMA in whole-line
+    // pieces (8 rows x 128 B, source-side swizzle) into this wave's two 4-KiB staging buffers, two phases ahead.  (Round 3
+    // read them per lane from L2 in the prologue: 16 bytes of 32 different lines per instruction, 13 k of the tile's 115 k clocks.)
+    char* const rstage = smem + KV_STAGE_OFF + wu * 8192;
+    unsigned rsrc[4];
     {
-        const float* rrow = p.rowtab[grp] + (size_t)(rld % p.rt_mod[grp]) * BD;
-        f32x4 xb[16];
+        const int rr8 = lane >> 3, cc = lane & 7;
 #pragma unroll
-        for (int bt = 0; bt < 4; ++bt) {
-#pragma unroll
-            for (int u = 0; u < 16; ++u) xb[u] = *(const f32x4*)(rrow + 32 * (4 * bt + u / 4) + 8 * (u % 4) + 4 * lh);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[4 * bt + u / 4][4 * (u % 4) + i] = xb[u][i];
-            __builtin_amdgcn_sched_barrier(0);
+        for (int pp = 0; pp < 4; ++pp) {
+            const int rt = tile * 128 + 32 * wu + 8 * pp + rr8;
+            const int rs = rt < Mg ? rt : Mg - 1;
+            rsrc[pp] = (unsigned)(((size_t)(rs % p.rt_mod[grp]) * BD + 4 * (cc ^ rr8)) * 4);
         }
     }
+    const __amdgpu_buffer_rsrc_t r_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.rowtab[grp], 0, (unsigned)((size_t)p.rt_mod[grp] * BD * 4), 0x00020000);
+    (void)r_rs;
+    auto rdma = [&](int t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rs, (lptr_t)(rstage + (t & 1) * 4096 + pp * 1024), 16, rsrc[pp], 128 * t, 0, 0);
+#endif
+    };
+    rdma(0);
+    rdma(1);
+    typedef const char __attribute__((address_space(3))) * lds_cc_t;
+    lds_cc_t rback = (lds_cc_t)(rstage + (l31 >> 3) * 1024 + (l31 & 7) * 128);
+    asm volatile("" : "+v"(rback));
+    f32x16 acc[NT];
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     stamps[1] = __builtin_readcyclecounter();
 
-    u32x4 R[2][4];
+    // weight fragment groups read two groups ahead, one phase = one ring stage: see block_fused_kernel
+    u32x4 R[3][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) R[0][k] = frag(0, k);
-    // one phase = one ring stage (see block_fused_kernel): 8 groups of {reads of the next group, one DMA piece, 4 MFMAs}
-    auto phase = [&](int ph, auto sl_c, auto&& mma) {
+    for (int k = 0; k < 4; ++k) {
+        R[0][k] = frag(0, k);
+        R[1][k] = frag(0, 4 + k);
+    }
+    auto phase_n = [&](int ph, auto sl_c, auto nres_c, auto&& mma, auto&& valu) {
         constexpr int SL = decltype(sl_c)::value;
+        constexpr int RB = (2 * SL) % 3;
+        constexpr int NRES = decltype(nres_c)::value;
+        static_assert(NRES == 0 || NRES == 4, "sync counts");
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            if (g == 7) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (g == 6) {
+                if (NRES == 4) asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) R[(g + 1) & 1][k] = g < 7 ? frag(SL, 4 * (g + 1) + k) : frag((SL + 1) % 3, k);
+            for (int k = 0; k < 4; ++k)
+                R[(RB + g + 2) % 3][k] = g < 6 ? frag(SL, 4 * (g + 2) + k) : frag((SL + 1) % 3, 4 * (g - 6) + k);
             if (g < 7) piece(ph + 2, (SL + 2) % 3, 1 + g);
             else piece(ph + 3, SL, 0);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                mma(4 * g + k, R[g & 1][k]);
+                mma(4 * g + k, R[(RB + g) % 3][k], g);
+                valu(g, k);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
+    auto no_valu = [](int, int) {};
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     using S2 = std::integral_constant<int, 2>;
+    using NR0 = std::integral_constant<int, 0>;
+    using NR4 = std::integral_constant<int, 4>;
 
-    // ---- embedding: phase sb = k-steps 2 sb, 2 sb + 1 of all 16 feature tiles
-#define KV_PH(base, sb, SL, opnd) phase((base) + (sb), SL{}, [&](int i, u32x4 a) { mfma_a(acc[i % 16], a, opnd[2 * (sb) + i / 16]); });
-    KV_PH(0, 0, S0, ofr) KV_PH(0, 1, S1, ofr) KV_PH(0, 2, S2, ofr) KV_PH(0, 3, S0, ofr) KV_PH(0, 4, S1, ofr) KV_PH(0, 5, S2, ofr)
-    KV_PH(0, 6, S0, ofr) KV_PH(0, 7, S1, ofr) KV_PH(0, 8, S2, ofr) KV_PH(0, 9, S0, ofr) KV_PH(0, 10, S1, ofr) KV_PH(0, 11, S2, ofr)
-    KV_PH(0, 12, S0, ofr) KV_PH(0, 13, S1, ofr) KV_PH(0, 14, S2, ofr) KV_PH(0, 15, S0, ofr)
+    // ---- embedding: phase jn = the 32 k-steps of feature tile jn (vmcnt bookkeeping as the out-proj of block_fused_kernel)
+    auto acc_init = [&](int jn) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 x = *(const f32x4 __attribute__((address_space(3)))*)(rback + (jn & 1) * 4096 + (((2 * q + lh) ^ (l31 & 7)) << 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[jn][4 * q + i] = x[i];
+        }
+    };
+#define KV_EMB(jn, SL, NR, WAIT)                                                                                             \
+    asm volatile("s_waitcnt vmcnt(" #WAIT ")" ::: "memory");                                                                 \
+    acc_init(jn);                                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                                       \
+    if ((jn) + 2 < NT) rdma((jn) + 2);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                       \
+    phase_n(jn, SL{}, std::integral_constant<int, NR>{}, [&](int i, u32x4 a, int) { mfma_a(acc[jn], a, ofr[i]); }, no_valu);
+    KV_EMB(0, S0, 4, 0) KV_EMB(1, S1, 4, 20) KV_EMB(2, S2, 4, 20) KV_EMB(3, S0, 4, 20) KV_EMB(4, S1, 4, 20) KV_EMB(5, S2, 4, 20)
+    KV_EMB(6, S0, 4, 20) KV_EMB(7, S1, 4, 20) KV_EMB(8, S2, 4, 20) KV_EMB(9, S0, 4, 20) KV_EMB(10, S1, 4, 20) KV_EMB(11, S2, 4, 20)
+    KV_EMB(12, S0, 4, 20) KV_EMB(13, S1, 4, 20) KV_EMB(14, S2, 0, 20) KV_EMB(15, S0, 0, 16)
+#undef KV_EMB
     mfma_done_a(acc);
     stamps[2] = __builtin_readcyclecounter();
 
-    // ---- norm1 of the embedded rows -> act (bf16 B-operand fragments)
+    // ---- norm1 of the embedded rows -> act (bf16 B-operand fragments, kept where the accumulators were)
     u32x4 act[KS];
     {
         float s1 = 0.f, s2 = 0.f;
@@ -1191,9 +1236,9 @@ __global__ __launch_bounds__(256, 1) void kv_fused_kernel(KvFusedP p) {
             float y[8];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const int q = 2 * (s & 1) + k, n = 32 * jn + 8 * q + 4 * lh;
-                const f32x4 g = *(const f32x4*)(tab + KT_G + n);
-                const f32x4 b = *(const f32x4*)(tab + KT_B + n);
+                const int q = 2 * (s & 1) + k, n = 32 * jn + 8 * q;
+                const f32x4 g = *(const f32x4 __attribute__((address_space(3)))*)(tabl + KT_G + n);
+                const f32x4 b = *(const f32x4 __attribute__((address_space(3)))*)(tabl + KT_B + n);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) y[4 * k + i] = fmaf(fmaf(acc[jn][4 * q + i], rstd, nmr), g[i], b[i]);
             }
@@ -1201,73 +1246,89 @@ __global__ __launch_bounds__(256, 1) void kv_fused_kernel(KvFusedP p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) w[j] = (bf16_t)y[j];
             act[s] = __builtin_bit_cast(u32x4, w);
-            asm volatile("" : "+v"(act[s]));
+            asm volatile("" : "+a"(act[s]));
         }
     }
     stamps[3] = __builtin_readcyclecounter();
 
-    // The K|V products run with the operands SWAPPED (activations = A operand, weights = B operand: the register images
-    // are the same), so an accumulator holds  lane & 31 = feature, registers = token rows: one store instruction then
-    // writes 64 contiguous bytes of two rows, where the transposed form would scatter 8 bytes into each of 32 rows.
-    // Row byte offsets of the 16 token rows this lane stores (rows past the group's end: out of the buffer's range, dropped)
+    // ---- K | V: 32 feature tiles, one phase each (the next layer's Q|K|V part of block_fused_kernel: two accumulators in turn,
+    // the finished tile staged as bf16 through the wave's buffers, a pair of tiles stored as whole 128-byte lines behind the
+    // stage sync of every second phase).  Round 3 ran K and V as 16 phases over 16 accumulators each with the operands
+    // swapped, stored 256 two-byte values per lane and half, and drained the stream between the halves.
     const __amdgpu_buffer_rsrc_t kv_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.KV, 0, p.kv_bytes, 0x00020000);
-    unsigned rowoff[16];
-    const float inv_rpg = 1.0f / (float)(map.rpg ? map.rpg : 1);
+    (void)kv_rs;
+    unsigned srow[4];
+    {
+        const int r8 = lane >> 3, cc = lane & 7;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int rr = tile * 128 + 32 * wu + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        long long mr = rr;
-        if (map.rpg) {  // rr / rpg through the reciprocal (rr < 2^22), corrected by one either way
-            int qd = (int)((float)rr * inv_rpg), rm = rr - qd * map.rpg;
-            if (rm < 0) { --qd; rm += map.rpg; }
-            if (rm >= map.rpg) { ++qd; rm -= map.rpg; }
-            mr = (long long)qd * map.gstride + rm + map.off;
+        for (int pp = 0; pp < 4; ++pp) {
+            const int rr = tile * 128 + 32 * wu + 8 * pp + r8;
+            const long long mr = map.rpg ? (long long)(rr / map.rpg) * map.gstride + rr % map.rpg + map.off : rr;
+            srow[pp] = rr < Mg ? (unsigned)(mr * p.ldkv * 2 + ((cc ^ r8) << 4)) : 0x80000000u;
         }
-        rowoff[e] = rr < Mg ? (unsigned)(mr * p.ldkv * 2 + l31 * 2) : 0x80000000u;
     }
-    auto bias_init = [&](int hf) {
+    typedef char __attribute__((address_space(3))) * lds_c_t;
+    lds_c_t const swr = (lds_c_t)(rstage + l31 * 128 + lh * 8);
+    lds_c_t srd = (lds_c_t)(rstage + (lane >> 3) * 128 + (lane & 7) * 16);
+    asm volatile("" : "+v"(srd));
+    f32x16 hA, hB;
+    u32x4 sreg[4];
+    auto bias_q = [&](f32x16& hh, int j, int q) {
+        const f32x4 bb = *(const f32x4 __attribute__((address_space(3)))*)(tabl + KT_BKV + 32 * j + 8 * q);
 #pragma unroll
-        for (int jn = 0; jn < NT; ++jn) {
-            const float b = tab[KT_BKV + BD * hf + 32 * jn + l31];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[jn][e] = b;
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int i = 0; i < 4; ++i) hh[4 * q + i] = bb[i];
     };
-    auto store_half = [&](int hf) {
-        acc_touch(acc);
+    auto stage_q = [&](const f32x16& hh, int t, int q) {
+        typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        bf16x4v w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (bf16_t)hh[4 * q + i];
+        const int c = (t & 1) * 4 + q;
+        *(u32x2 __attribute__((address_space(3)))*)(swr + ((t >> 1) & 1) * 4096 + ((c ^ (l31 & 7)) << 4)) = __builtin_bit_cast(u32x2, w);
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bias_q(hA, 0, q);
+        bias_q(hB, 0, q);  // (phase 0 stages "tile -1" from it: into the half of a buffer that tile 3 overwrites before it is read)
+    }
+    auto kv_phase = [&](int j, auto sl_c, auto nres_c, f32x16& HC, f32x16& HP, auto store_c) {
+        constexpr bool STORE = decltype(store_c)::value;
+        phase_n(16 + j, sl_c, nres_c, [&](int i, u32x4 a, int) { mfma_v_ab(HC, a, act[i]); },
+                [&](int g, int k) {
+                    if (g == 0) stage_q(HP, j - 1, k);
+                    if (g == 1) bias_q(HP, j + 1 < 2 * NT ? j + 1 : j, k);
+                    if (STORE && g == 3) sreg[k] = *(const u32x4 __attribute__((address_space(3)))*)(srd + (((j - 2) >> 1) & 1) * 4096 + k * 1024);
+#if defined(__HIP_DEVICE_COMPILE__)
+                    if (STORE && ((g == 6 && k > 0) || (g == 7 && k == 0))) {  // (behind the sync and stage ph + 2's last piece)
+                        const int pp = g == 6 ? k - 1 : 3;
+                        __builtin_amdgcn_raw_buffer_store_b128(sreg[pp], kv_rs, j >= 2 ? srow[pp] : 0x80000000u, ((j - 2) >> 1) * 128, 0);
+                    }
+#endif
+                });
+        mfma_done_v(HC);
+    };
+    for (int j = 0; j < 2 * NT - 2; j += 6) {  // tiles 0..29 (phase 16 = slot 1); even phases store, the one behind counts the stores
+        kv_phase(j, S1{}, NR0{}, hA, hB, std::true_type{});
+        kv_phase(j + 1, S2{}, NR4{}, hB, hA, std::false_type{});
+        kv_phase(j + 2, S0{}, NR0{}, hA, hB, std::true_type{});
+        kv_phase(j + 3, S1{}, NR4{}, hB, hA, std::false_type{});
+        kv_phase(j + 4, S2{}, NR0{}, hA, hB, std::true_type{});
+        kv_phase(j + 5, S0{}, NR4{}, hB, hA, std::false_type{});
+        if (j == 12) stamps[4] = __builtin_readcyclecounter();
+    }
+    kv_phase(2 * NT - 2, S1{}, NR0{}, hA, hB, std::true_type{});
+    kv_phase(2 * NT - 1, S2{}, NR4{}, hB, hA, std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the pieces issued past the end of the stream
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stage_q(hB, 2 * NT - 1, q);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-        for (int jn = 0; jn < NT; ++jn) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const bf16_t w = (bf16_t)acc[jn][e];
-                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, w), kv_rs, rowoff[e] + (BD * hf + 32 * jn) * 2, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    for (int k = 0; k < 4; ++k) {
+        const u32x4 v = *(const u32x4 __attribute__((address_space(3)))*)(srd + (((2 * NT - 2) >> 1) & 1) * 4096 + k * 1024);
+        __builtin_amdgcn_raw_buffer_store_b128(v, kv_rs, srow[k], ((2 * NT - 2) >> 1) * 128, 0);
+    }
 #endif
-    };
-#define KV_PHS(base, sb, SL) phase((base) + (sb), SL{}, [&](int i, u32x4 a) { mfma_a(acc[i % 16], act[2 * (sb) + i / 16], a); });
-    // ---- K: phases 16..31 (phase 16 = slot 1)
-    bias_init(0);
-    KV_PHS(16, 0, S1) KV_PHS(16, 1, S2) KV_PHS(16, 2, S0) KV_PHS(16, 3, S1) KV_PHS(16, 4, S2) KV_PHS(16, 5, S0)
-    KV_PHS(16, 6, S1) KV_PHS(16, 7, S2) KV_PHS(16, 8, S0) KV_PHS(16, 9, S1) KV_PHS(16, 10, S2) KV_PHS(16, 11, S0)
-    KV_PHS(16, 12, S1) KV_PHS(16, 13, S2) KV_PHS(16, 14, S0) KV_PHS(16, 15, S1)
-    mfma_done_a(acc);
-    stamps[4] = __builtin_readcyclecounter();
-    store_half(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see the header: stores and DMA pieces share the counter)
-    // ---- V: phases 32..47 (phase 32 = slot 2)
-    bias_init(1);
-    KV_PHS(32, 0, S2) KV_PHS(32, 1, S0) KV_PHS(32, 2, S1) KV_PHS(32, 3, S2) KV_PHS(32, 4, S0) KV_PHS(32, 5, S1)
-    KV_PHS(32, 6, S2) KV_PHS(32, 7, S0) KV_PHS(32, 8, S1) KV_PHS(32, 9, S2) KV_PHS(32, 10, S0) KV_PHS(32, 11, S1)
-    KV_PHS(32, 12, S2) KV_PHS(32, 13, S0) KV_PHS(32, 14, S1) KV_PHS(32, 15, S2)
-#undef KV_PHS
-#undef KV_PH
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the pieces issued past the end of the stream
-    mfma_done_a(acc);
-    store_half(1);
     stamps[5] = __builtin_readcyclecounter();
     if (p.stamps && (int)blockIdx.x == p.stamp_block && lane == 0) {
 #pragma unroll
@@ -1342,7 +1403,7 @@ void launch_block_split_reduce(const SplitReduceP& p, hipStream_t st) {
 int block_split_n() { return SPLIT_N; }
 
 bool launch_kv_fused(const KvFusedP& p, hipStream_t st) {
-    if (((uintptr_t)p.Z & 15) || (p.ldz % 8) || ((uintptr_t)p.KV & 7) || (p.ldkv % 4)) return false;
+    if (((uintptr_t)p.Z & 15) || (p.ldz % 8) || ((uintptr_t)p.KV & 15) || (p.ldkv % 8)) return false;  // (16-byte pieces of whole lines)
     if (p.kv_bytes == 0 || p.kv_bytes >= 0x80000000u) return false;
     int tiles = 0;
     for (int g = 0; g < 2; ++g) {
