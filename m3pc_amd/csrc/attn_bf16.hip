@@ -392,6 +392,250 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_direct_kernel(AttnP p) {
         }
     }
 }
+// Lk <= 52, at most 52 query slots, head dim 128 (the encoder attentions of the T = 32 plan step): the same arithmetic as
+// attn_bf16_direct_kernel<4, 2, 2>, software-pipelined over (batch element, head) items.  The direct kernel is one
+// short-lived workgroup per item: load -> compute -> store with nothing in flight during the last two, all workgroups of a
+// round in the same stage at the same time (31.5 us for 100 MB where the loads alone take 17.5).  Here a workgroup is
+// persistent, two per CU, and has THREE waves: two compute an item (32 query slots each) while the third, the loader,
+// keeps the next two items' Q, K, V rows in flight -- LDS-DMA in whole-line pieces (4 rows x 256 B, 16-byte chunks
+// swizzled by row & 7 on the source side so that the fragment reads are conflict-free) into two LDS buffers.  The split
+// is about the counter: vector-memory operations complete in issue order, so a wave that both loads and stores waits for
+// its old stores' acknowledgements whenever it waits for a load (measured: 42 us with the loads and stores on the same
+// waves); the loader's vmcnt sees loads only, and the compute waves never wait for their stores.
+// O leaves through the Q image of the item's buffer (a wave's Q rows are in registers by then; P V runs with the
+// operands swapped -- the register images are identical -- so a lane owns its query row and writes 8 bytes per quarter
+// of a 32-dim tile): whole 256-byte rows out, 4 rows per store instruction.
+// Images per buffer: V | K | Q, 52 rows each.  Fragment rows past an image (keys or queries 52..63) read the image behind
+// it: finite values that are masked (scores of keys >= Lk), multiplied by an exact zero (V rows of keys >= Lk: rows
+// Lk..51 are never written and stay zero) or never stored (queries).
+// NQ1, NQ2, NK1, NK2: 4-row pieces of the per-item and the batch-shared query / key segments.
+namespace {
+constexpr int APIPE_NR = 52, APIPE_IMG = APIPE_NR * 256, APIPE_BUF = 3 * APIPE_IMG;
+}
+template <int NQ1, int NQ2, int NK1, int NK2>
+__global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_items) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int HD = 128, NS = 8, HDT = 4;
+    constexpr int NDMA = NQ1 + NQ2 + 2 * (NK1 + NK2);  // pieces per item (the loader's)
+    constexpr int NST = (APIPE_NR / 4 + 1) / 2;        // stores per compute wave and item (4 rows each)
+    static_assert(NDMA <= 63, "vmcnt");
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // 2 * APIPE_BUF bytes (dynamic: two workgroups per CU must fit to the byte)
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0, 1: compute; 2: loader
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int Lk = p.L1 + p.L2;
+    const int Lq1p = NQ2 ? 32 : 0;  // (launcher: a second query segment starts at slot 32)
+
+    {   // zero the images once: rows no piece ever writes must stay zero (V rows of keys >= Lk)
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int i = tid; i < 2 * APIPE_BUF / 16; i += 192) *(u32x4*)(lds + i * 16) = z;
+    }
+    const int r4 = lane >> 4, c16 = lane & 15;  // a piece: row r4 of its 4, 16-byte chunk c16
+    const int n_mine = ((int)blockIdx.x < n_items) ? (n_items - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int stride = gridDim.x;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the zeros are in before a piece lands on them)
+
+    if (wid == 2) {
+        // ---------------------------------------------------------------- loader
+        // this lane's source offsets inside a piece (swizzled by the image row & 7 = 4 (piece & 1) + r4) for the four row strides
+        auto voff = [&](int ld, int odd) { return (unsigned)(r4 * ld * 2 + ((c16 ^ (4 * odd + r4)) << 4)); };
+        const unsigned vq[2] = {voff(p.ldq, 0), voff(p.ldq, 1)}, vq2[2] = {voff(p.ldq2, 0), voff(p.ldq2, 1)};
+        const unsigned vk[2] = {voff(p.ldkv1, 0), voff(p.ldkv1, 1)}, vk2[2] = {voff(p.ldkv2, 0), voff(p.ldkv2, 1)};
+        // N pieces of one segment (rows [0, L) of `base`, row stride ld elements; rows >= L are out of the resource's range)
+        // -> image rows row0.. of `img` (row0 a multiple of 8: the swizzle is that of the image row)
+        auto seg_dma = [&](const bf16_t* base, int L, int ld, const unsigned (&v)[2], char* img, int row0, auto n_c) {
+            constexpr int N = decltype(n_c)::value;
+            if (N == 0) return;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (unsigned)(L * ld * 2), 0x00020000);
+#pragma unroll
+            for (int pc = 0; pc < N; ++pc)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(img + (row0 / 4 + pc) * 1024), 16, v[pc & 1], pc * 4 * ld * 2, 0, 0);
+        };
+        auto issue = [&](int it, int buf) {
+            if (p.no_pipe == 3) return;  // (lab timing: no loads)
+            const int b = it / p.n_head, head = it % p.n_head;
+            char* const B = lds + buf * APIPE_BUF;
+            seg_dma((const bf16_t*)p.K1 + b * p.kv1_bstride + head * HD, p.L1, p.ldkv1, vk, B + APIPE_IMG, 0, std::integral_constant<int, NK1>{});
+            seg_dma((const bf16_t*)p.K2 + head * HD, p.L2, p.ldkv2, vk2, B + APIPE_IMG, 4 * NK1, std::integral_constant<int, NK2>{});
+            seg_dma((const bf16_t*)p.Q + b * p.q_bstride + head * HD, p.Lq, p.ldq, vq, B + 2 * APIPE_IMG, 0, std::integral_constant<int, NQ1>{});
+            seg_dma((const bf16_t*)p.Q2 + head * HD, p.Lq2, p.ldq2, vq2, B + 2 * APIPE_IMG, Lq1p, std::integral_constant<int, NQ2>{});
+            seg_dma((const bf16_t*)p.V1 + b * p.kv1_bstride + head * HD, p.L1, p.ldkv1, vk, B, 0, std::integral_constant<int, NK1>{});
+            seg_dma((const bf16_t*)p.V2 + head * HD, p.L2, p.ldkv2, vk2, B, 4 * NK1, std::integral_constant<int, NK2>{});
+        };
+        if (n_mine > 0) issue(blockIdx.x, 0);
+        if (n_mine > 1) issue(blockIdx.x + stride, 1);
+        for (int k = 0; k < n_mine; ++k) {
+            if (k + 1 < n_mine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");  // item k is in, item k + 1 may be on its way
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");  // A: the compute waves start on item k
+            asm volatile("s_barrier" ::: "memory");  // C: (their O rows are in the Q image)
+            asm volatile("s_barrier" ::: "memory");  // B: they are done with the buffer
+            if (k + 2 < n_mine) issue(blockIdx.x + (k + 2) * stride, k & 1);
+        }
+        return;
+    }
+    // -------------------------------------------------------------------- compute waves
+    const int qi = wid * 32 + l31;  // this lane's query slot
+    const int sw = l31 & 7;         // fragment addresses: chunk ^ (row & 7)
+    const int gi = lane & 15;
+    for (int k = 0; k < n_mine; ++k) {
+        const int it = blockIdx.x + k * stride;
+        const char* const B = lds + (k & 1) * APIPE_BUF;
+        asm volatile("s_barrier" ::: "memory");  // A
+        if (p.no_pipe == 2) {  // (lab timing: no arithmetic)
+            asm volatile("s_barrier\n\ts_barrier" ::: "memory");
+            continue;
+        }
+        // ---- S^T = K Q^T
+        const unsigned vbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)B;  // (the V image: first in the buffer)
+        const char* const Ki = B + APIPE_IMG;
+        const char* const Qi = B + 2 * APIPE_IMG;
+        u32x4 qf[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) qf[s] = *(const u32x4*)(Qi + qi * 256 + (((2 * s + lh) ^ sw) << 4));
+        f32x16 sacc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[t][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const u32x4 kf = *(const u32x4*)(Ki + (32 * t + l31) * 256 + (((2 * s + lh) ^ sw) << 4));
+                sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[s]), sacc[t], 0, 0, 0);
+            }
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int j = jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const float v = (j < Lk) ? sacc[jt][e] * p.scale : -INFINITY;
+                sacc[jt][e] = v;
+                m = fmaxf(m, v);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float v = __builtin_amdgcn_exp2f((sacc[jt][e] - m) * 1.44269504088896340736f);
+                sacc[jt][e] = v;
+                l += v;
+            }
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        // ---- O^T = V^T P^T (lane = query, registers = dims)
+        f32x16 oacc[HDT];
+#pragma unroll
+        for (int d = 0; d < HDT; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pa;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pa[e] = (bf16_t)(sacc[jt][8 * s2 + e] * inv);
+                // transposing reads: lane -> key row kr (and kr + 8), 8 bytes at dim d * 32 + ((lane >> 4) & 1) * 16 + (gi & 3) * 4.
+                // As asm statements: the builtin carries no memory operand, and hipcc would order it behind every LDS-DMA it
+                // has seen with a full vmcnt(0).
+                const int kr = jt * 32 + 16 * s2 + 4 * lh + (gi >> 2);
+                s16x4 v0[HDT], v1[HDT];
+#pragma unroll
+                for (int d = 0; d < HDT; ++d) {
+                    const int bo = d * 64 + ((lane >> 4) & 1) * 32 + (gi & 3) * 8;  // byte offset in the row
+                    const unsigned a0 = vbase + kr * 256 + ((((bo >> 4) ^ (kr & 7)) << 4) | (bo & 15));
+                    const unsigned a1 = vbase + (kr + 8) * 256 + ((((bo >> 4) ^ ((kr + 8) & 7)) << 4) | (bo & 15));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v0[d]) : "v"(a0));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v1[d]) : "v"(a1));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0[0]), "+v"(v0[1]), "+v"(v0[2]), "+v"(v0[3]), "+v"(v1[0]), "+v"(v1[1]), "+v"(v1[2]), "+v"(v1[3]));
+#pragma unroll
+                for (int d = 0; d < HDT; ++d) {
+                    const s16x8 vb = __builtin_shufflevector(v0[d], v1[d], 0, 1, 2, 3, 4, 5, 6, 7);
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vb), pa, oacc[d], 0, 0, 0);
+                }
+            }
+        }
+        // ---- O through the Q image (this wave writes the rows it read)
+        {
+            char* const Oi = (char*)Qi;
+            if (qi < APIPE_NR) {
+#pragma unroll
+                for (int d = 0; d < HDT; ++d)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        bf16x4 w;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) w[i] = (bf16_t)oacc[d][4 * q + i];
+                        *(bf16x4*)(Oi + qi * 256 + (((4 * d + q) ^ sw) << 4) + 8 * lh) = w;
+                    }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // C
+        u32x4 ov[NST];
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            int pc = 2 * j + wid;
+            pc = pc < APIPE_NR / 4 ? pc : APIPE_NR / 4 - 1;
+            ov[j] = *(const u32x4*)(Qi + (4 * pc + r4) * 256 + c16 * 16);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B: the pieces of the item after next may land
+        // ---- stores (never waited for; rows that do not exist are addressed out of the buffer's range)
+        {
+            const int b = it / p.n_head, head = it % p.n_head;
+            const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((bf16_t*)p.O + b * p.o_bstride + head * HD), 0, 0x7fffffffu, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < NST; ++j) {
+                int pc = 2 * j + wid;
+                pc = pc < APIPE_NR / 4 ? pc : APIPE_NR / 4 - 1;
+                const int row = 4 * pc + r4;
+                unsigned off = 0x80000000u;
+                if (row < p.Lq) off = (unsigned)((p.orow1 + row) * p.ldo * 2);
+                else if (NQ2 && row >= Lq1p && row - Lq1p < p.Lq2) off = (unsigned)((p.orow2 + row - Lq1p) * p.ldo * 2);
+                __builtin_amdgcn_raw_buffer_store_b128(ov[j], o_rs, off + ((c16 ^ (row & 7)) << 4), 0, 0);
+            }
+        }
+    }
+#endif
+}
+template <int NQ1, int NQ2, int NK1, int NK2>
+static void launch_pipe(const AttnP& p, hipStream_t st) {
+    const int n_items = p.batch * p.n_head;
+    int cap = 512;  // two workgroups per CU
+#ifdef M3PC_LAB
+    static const int env_cap = M3PC_ENV("M3PC_ATTN_PIPE_GRID") ? atoi(M3PC_ENV("M3PC_ATTN_PIPE_GRID")) : 0;
+    if (env_cap > 0) cap = env_cap;
+#endif
+    const int grid = n_items < cap ? n_items : cap;
+    static const bool attr_ok = hipFuncSetAttribute((const void*)attn_bf16_pipe_kernel<NQ1, NQ2, NK1, NK2>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * APIPE_BUF) == hipSuccess;
+    (void)attr_ok;
+    hipLaunchKernelGGL((attn_bf16_pipe_kernel<NQ1, NQ2, NK1, NK2>), dim3(grid), dim3(192), 2 * APIPE_BUF, st, p, n_items);
+}
+// the shapes the pipelined kernel is built for; everything else takes the kernels below
+static bool try_pipe(const AttnP& p, hipStream_t st) {
+    if (p.hd != 128 || p.pre_m || p.no_pipe == 1 || p.batch * p.n_head < 1024) return false;
+    if (((uintptr_t)p.Q | (uintptr_t)p.K1 | (uintptr_t)p.V1 | (uintptr_t)p.O) & 15) return false;
+    if ((p.ldq | p.ldkv1 | p.ldo) % 8 || (p.q_bstride | p.kv1_bstride | p.o_bstride) % 8) return false;
+    if ((long long)p.Lq * p.ldq * 2 >= 0x7fffffffLL || (long long)p.L1 * p.ldkv1 * 2 >= 0x7fffffffLL) return false;
+    if (!p.Q2 && !p.K2 && p.Lq == 49 && p.L1 == 49 && p.L2 == 0) {
+        launch_pipe<13, 0, 13, 0>(p, st);
+        return true;
+    }
+    if (p.Q2 && p.K2 && p.Lq == 32 && p.Lq2 == 17 && p.L1 == 32 && p.L2 == 17 && !(((uintptr_t)p.Q2 | (uintptr_t)p.K2 | (uintptr_t)p.V2) & 15) &&
+        (p.ldq2 | p.ldkv2) % 8 == 0) {
+        launch_pipe<8, 5, 8, 5>(p, st);
+        return true;
+    }
+    return false;
+}
+
 template <int HDT, int NW, int NKT>
 static void launch_direct(const AttnP& p, int slots, hipStream_t st) {
     const size_t smem = (size_t)NKT * 32 * (HDT * 64 + 16) + NW * 32 * sizeof(float);
@@ -414,6 +658,8 @@ static void launch_hd(const AttnP& p, hipStream_t st) {
     const size_t smem = (size_t)rows * (HDT * 64 + 16) + 512;  // + per-query weights of the pre-reduced block
     dim3 grid(p.batch, p.n_head, qgroups), block(nw * 64);
     static const bool no_direct = M3PC_ENV("M3PC_NO_ATTN_DIRECT") != nullptr;  // A/B switch
+    static const bool no_pipe = M3PC_ENV("M3PC_NO_ATTN_PIPE") != nullptr;      // A/B switch
+    if (HDT == 4 && !no_pipe && !no_direct && try_pipe(p, st)) return;
     if (Lk <= 64 && !no_direct) {
         if (slots <= 32)
             launch_direct<HDT, 1, 2>(p, slots, st);

@@ -2981,6 +2981,44 @@ int m3pc_debug_block_fused_heads(const void* O, int M, const float* rowtab, int 
 // the kept[g] rows at offset off[g] of every candidate, embedded with We[g] (512, 512) bf16 + rowtab[g] (kept[g], 512);
 // stream_buf: 2 * m3pc_debug_kv_stream_bytes() bytes; KV (n*Le, 1024) bf16
 long long m3pc_debug_kv_stream_bytes(void) { return (long long)kv_stream_bytes(); }
+int m3pc_debug_attention_bf16(const void* QKV, const void* QKVs, void* O, int batch, int n_own, int n_sh, int kernel, void* stream) {
+    const int d = 512, L = n_own + n_sh;
+    AttnP a;
+    memset(&a, 0, sizeof(a));
+    const char* q = (const char*)QKV;
+    const char* qs = (const char*)QKVs;
+    a.Q = q;
+    a.q_bstride = (long long)n_own * 3 * d;
+    a.ldq = 3 * d;
+    a.Lq = n_own;
+    a.K1 = q + (size_t)d * 2;
+    a.V1 = q + (size_t)2 * d * 2;
+    a.kv1_bstride = (long long)n_own * 3 * d;
+    a.ldkv1 = 3 * d;
+    a.L1 = n_own;
+    if (n_sh > 0) {  // (run_block: own rows first in the slots, shared rows first in the output)
+        a.orow1 = n_sh;
+        a.Q2 = qs;
+        a.ldq2 = 3 * d;
+        a.Lq2 = n_sh;
+        a.orow2 = 0;
+        a.K2 = qs + (size_t)d * 2;
+        a.V2 = qs + (size_t)2 * d * 2;
+        a.ldkv2 = 3 * d;
+        a.L2 = n_sh;
+    }
+    a.O = O;
+    a.o_bstride = (long long)L * d;
+    a.ldo = d;
+    a.batch = batch;
+    a.n_head = 4;
+    a.hd = 128;
+    a.scale = 1.0f / sqrtf(128.0f);
+    a.no_pipe = kernel;  // (2, 3: timing variants of the pipelined kernel that compute nothing / load nothing)
+    launch_attention(a, DT_BF16, (hipStream_t)stream);
+    return check_launch("debug_attention_bf16");
+}
+
 int m3pc_debug_kv_fused(const void* Z, int n, int Le, int kept0, int off0, int kept1, int off1, const void* We0, const void* We1,
                         const void* Wkv, void* stream_buf, const float* rowtab0, const float* rowtab1, const float* ln_g,
                         const float* ln_b, const float* bkv, void* KV, void* stream, long long* stamps) {

@@ -290,3 +290,35 @@ def test_kv_fused_rows_independent_of_batch():
     full = _kv_call(lib, Z, n, Le, kept, off, We, Wkv, rowtab, g, b, bkv)
     part = _kv_call(lib, Z[37 * Le:(37 + 101) * Le].contiguous(), 101, Le, kept, off, We, Wkv, rowtab, g, b, bkv)
     assert torch.equal(full[37 * Le:(37 + 101) * Le], part)
+
+
+# ------------------------------------------------------------------------------------------------ bf16 attention (attn_bf16.hip)
+@pytest.mark.parametrize("batch,n_own,n_sh", [(512, 49, 0), (512, 32, 17), (300, 49, 0), (257, 32, 17)])
+def test_pipelined_attention_is_the_direct_kernel_bit_for_bit(batch, n_own, n_sh):
+    """attn_bf16_pipe_kernel (persistent workgroups, rows by LDS-DMA, two items in flight) against attn_bf16_direct_kernel on the two
+    encoder-layer shapes of the candidate pass: same products, same order -- equal bits -- and both against a float64 softmax.
+    Item counts that are / are not multiples of the grid, so that workgroups end on different iterations."""
+    lib = lab_library()
+    fn = lib.m3pc_debug_attention_bf16
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]
+    g = torch.Generator(device="cuda").manual_seed(batch + n_sh)
+    qkv = torch.randn(batch, n_own, 1536, device="cuda", generator=g).to(torch.bfloat16)
+    qkvs = torch.randn(max(n_sh, 1), 1536, device="cuda", generator=g).to(torch.bfloat16)
+    L = n_own + n_sh
+    outs = []
+    for kernel in (0, 1):
+        O = torch.full((batch, L, 512), float("nan"), device="cuda", dtype=torch.bfloat16)
+        rc = fn(qkv.data_ptr(), qkvs.data_ptr() if n_sh else None, O.data_ptr(), batch, n_own, n_sh, kernel,
+                C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, lib.m3pc_last_error()
+        torch.cuda.synchronize()
+        outs.append(O)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    # float64 reference on a few batch elements
+    for b in (0, batch // 2, batch - 1):
+        rows = torch.cat([qkvs[:n_sh], qkv[b]], 0).double() if n_sh else qkv[b].double()  # output order: shared rows first
+        q, k, v = rows[:, :512], rows[:, 512:1024], rows[:, 1024:]
+        ref = torch.cat([torch.softmax(q[:, 128 * h:128 * h + 128] @ k[:, 128 * h:128 * h + 128].T / 128 ** 0.5, -1)
+                         @ v[:, 128 * h:128 * h + 128] for h in range(4)], 1)
+        assert float((outs[0][b].double() - ref).abs().max()) < 3e-2

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""The bf16 attention of an encoder layer alone (lab build): the pipelined kernel against the direct one, cache-cold (buffer sets
+rotated so that nothing is served from the 256-MiB MALL).   M3PC_LIB=m3pc_amd/libm3pc_hip_lab.so python tools/attn_bench.py [batch]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from m3pc_amd import capi  # noqa: E402
+
+
+def main():
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    lib = capi.load_library()
+    fn = lib.m3pc_debug_attention_bf16
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]
+    nset = 10
+    for n_own, n_sh in ((49, 0), (32, 17)):
+        L = n_own + n_sh
+        sets = [(torch.randn(batch, n_own, 1536, device="cuda").to(torch.bfloat16), torch.randn(max(n_sh, 1), 1536, device="cuda").to(torch.bfloat16),
+                 torch.empty(batch, L, 512, device="cuda", dtype=torch.bfloat16)) for _ in range(nset)]
+        mb = batch * (n_own * 3072 + L * 1024) / 1e6
+        for kernel, name in ((0, "pipelined"), (1, "direct"), (2, "pipe:loads"), (3, "pipe:math")):
+            s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            ts = []
+            for rep in range(4):
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(nset + 1)]
+                ev[0].record()
+                for i, (q, qs, o) in enumerate(sets):
+                    assert fn(q.data_ptr(), qs.data_ptr() if n_sh else None, o.data_ptr(), batch, n_own, n_sh, kernel, s) == 0
+                    ev[i + 1].record()
+                torch.cuda.synchronize()
+                if rep:
+                    ts += [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(nset)]
+            ts.sort()
+            print(f"batch {batch} own {n_own} shared {n_sh} {name:9s}: min {ts[0]:6.1f} us  med {ts[len(ts) // 2]:6.1f} us  "
+                  f"{mb / ts[len(ts) // 2]:.2f} TB/s algorithmic ({mb:.0f} MB)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
