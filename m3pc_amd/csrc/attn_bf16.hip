@@ -466,12 +466,14 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
         if (n_mine > 0) issue(blockIdx.x, 0);
         if (n_mine > 1) issue(blockIdx.x + stride, 1);
         for (int k = 0; k < n_mine; ++k) {
-            if (k + 1 < n_mine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");  // item k is in, item k + 1 may be on its way
+            // item k is in (item k + 1 may be on its way: only at k = 0 -- later its pieces are issued behind barrier A, while the
+            // compute waves work: issued in front of it, the 39 pieces' issue time sat between two items' arithmetic)
+            if (k == 0 && n_mine > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");  // A: the compute waves start on item k
+            if (k >= 1 && k + 1 < n_mine) issue(blockIdx.x + (k + 1) * stride, (k + 1) & 1);  // (its buffer is free since barrier B of item k - 1)
             asm volatile("s_barrier" ::: "memory");  // C: (their O rows are in the Q image)
             asm volatile("s_barrier" ::: "memory");  // B: they are done with the buffer
-            if (k + 2 < n_mine) issue(blockIdx.x + (k + 2) * stride, k & 1);
         }
         return;
     }
