@@ -47,8 +47,11 @@ int m3pc_debug_kv_fused(const void* Z, int n, int Le, int kept0, int off0, int k
                         const float* ln_b, const float* bkv, void* KV, void* stream, long long* stamps);
 /* the bf16 attention of an encoder layer of the candidate pass on caller tensors: QKV (batch, n_own, 1536) per-candidate rows
  * [Q | K | V] and, when n_sh > 0, QKVs (n_sh, 1536) rows shared by the batch (first layer: history tokens); O (batch, n_own + n_sh, 512),
- * shared rows first.  4 heads of 128.  kernel: 0 = what the library picks, 1 = never the pipelined kernel */
-int m3pc_debug_attention_bf16(const void* QKV, const void* QKVs, void* O, int batch, int n_own, int n_sh, int kernel, void* stream);
+ * shared rows first.  4 heads of 128.  kernel: 0 = what the library picks, 1 = never the pipelined kernel, 2 / 3 = the pipelined kernel
+ * without its arithmetic / without its loads (timing only).
+ * stamps: optional 16 int64 (device): shader-clock stamps of one workgroup's third item in the pipelined kernel */
+int m3pc_debug_attention_bf16(const void* QKV, const void* QKVs, void* O, int batch, int n_own, int n_sh, int kernel, void* stream,
+                              long long* stamps);
 /* in-kernel phase stamps of workgroup 37 of every fused-tail launch as the step runs: cap > 0 starts a ring of cap entries
  * (64 int64 each), cap == 0 copies it to `out` (host), reports the number of launches logged and stops */
 int m3pc_debug_stamp_log(m3pc_handle* h, int cap, long long* out, int* n_logged);

@@ -481,10 +481,12 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
     const int qi = wid * 32 + l31;  // this lane's query slot
     const int sw = l31 & 7;         // fragment addresses: chunk ^ (row & 7)
     const int gi = lane & 15;
+    long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (lab: shader-clock stamps of this workgroup's third item)
     for (int k = 0; k < n_mine; ++k) {
         const int it = blockIdx.x + k * stride;
         const char* const B = lds + (k & 1) * APIPE_BUF;
         asm volatile("s_barrier" ::: "memory");  // A
+        if (p.stamps && k == 2) st_[0] = __builtin_readcyclecounter();
         if (p.no_pipe == 2) {  // (lab timing: no arithmetic)
             asm volatile("s_barrier\n\ts_barrier" ::: "memory");
             continue;
@@ -507,6 +509,8 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
                 sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[s]), sacc[t], 0, 0, 0);
             }
         }
+        asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]));
+        if (p.stamps && k == 2) st_[1] = __builtin_readcyclecounter();
         float m = -INFINITY;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
@@ -530,6 +534,8 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
         l += __shfl_xor(l, 32);
         const float inv = 1.0f / l;
         // ---- O^T = V^T P^T (lane = query, registers = dims)
+        asm volatile("" : "+v"(l));
+        if (p.stamps && k == 2) st_[2] = __builtin_readcyclecounter();
         f32x16 oacc[HDT];
 #pragma unroll
         for (int d = 0; d < HDT; ++d)
@@ -564,6 +570,8 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
             }
         }
         // ---- O through the Q image (this wave writes the rows it read)
+        asm volatile("" : "+v"(oacc[0]), "+v"(oacc[1]), "+v"(oacc[2]), "+v"(oacc[3]));
+        if (p.stamps && k == 2) st_[3] = __builtin_readcyclecounter();
         {
             char* const Oi = (char*)Qi;
             if (qi < APIPE_NR) {
@@ -579,6 +587,7 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // C
+        if (p.stamps && k == 2) st_[4] = __builtin_readcyclecounter();
         u32x4 ov[NST];
 #pragma unroll
         for (int j = 0; j < NST; ++j) {
@@ -587,6 +596,7 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
             ov[j] = *(const u32x4*)(Qi + (4 * pc + r4) * 256 + c16 * 16);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B: the pieces of the item after next may land
+        if (p.stamps && k == 2) st_[5] = __builtin_readcyclecounter();
         // ---- stores (never waited for; rows that do not exist are addressed out of the buffer's range)
         {
             const int b = it / p.n_head, head = it % p.n_head;
@@ -603,7 +613,10 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
                 __builtin_amdgcn_raw_buffer_store_b128(ov[j], o_rs, off + ((c16 ^ (row & 7)) << 4), 0, 0);
             }
         }
+        if (p.stamps && k == 2) st_[6] = __builtin_readcyclecounter();
     }
+    if (p.stamps && (int)blockIdx.x == 37 && lane == 0)
+        for (int i = 0; i < 7; ++i) p.stamps[wid * 8 + i] = st_[i];
 #endif
 }
 template <int NQ1, int NQ2, int NK1, int NK2>

@@ -225,6 +225,7 @@ struct AttnP {
     const float* pre_m;  // (n_head, Lq)
     const float* pre_l;  // (n_head, Lq)
     const float* pre_O;  // (n_head, Lq, hd)
+    long long* stamps;   // optional (lab): 2 x 8 shader-clock stamps of workgroup 37's third item in attn_bf16_pipe_kernel
     int no_pipe;         // 1: never the pipelined kernel (attn_bf16_pipe_kernel) -- kernel-level A/B and bit-identity tests
 };
 // pre_m / pre_l / pre_O of queries Q (Lq rows) against keys K2/V2 (L2 rows); uses Q, ldq, K2, V2, ldkv2, L2, Lq,

@@ -2981,7 +2981,8 @@ int m3pc_debug_block_fused_heads(const void* O, int M, const float* rowtab, int 
 // the kept[g] rows at offset off[g] of every candidate, embedded with We[g] (512, 512) bf16 + rowtab[g] (kept[g], 512);
 // stream_buf: 2 * m3pc_debug_kv_stream_bytes() bytes; KV (n*Le, 1024) bf16
 long long m3pc_debug_kv_stream_bytes(void) { return (long long)kv_stream_bytes(); }
-int m3pc_debug_attention_bf16(const void* QKV, const void* QKVs, void* O, int batch, int n_own, int n_sh, int kernel, void* stream) {
+int m3pc_debug_attention_bf16(const void* QKV, const void* QKVs, void* O, int batch, int n_own, int n_sh, int kernel, void* stream,
+                              long long* stamps) {
     const int d = 512, L = n_own + n_sh;
     AttnP a;
     memset(&a, 0, sizeof(a));
@@ -3014,6 +3015,7 @@ int m3pc_debug_attention_bf16(const void* QKV, const void* QKVs, void* O, int ba
     a.n_head = 4;
     a.hd = 128;
     a.scale = 1.0f / sqrtf(128.0f);
+    a.stamps = stamps;
     a.no_pipe = kernel;  // (2, 3: timing variants of the pipelined kernel that compute nothing / load nothing)
     launch_attention(a, DT_BF16, (hipStream_t)stream);
     return check_launch("debug_attention_bf16");

@@ -301,7 +301,7 @@ def test_pipelined_attention_is_the_direct_kernel_bit_for_bit(batch, n_own, n_sh
     lib = lab_library()
     fn = lib.m3pc_debug_attention_bf16
     fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]
+    fn.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p] * 2
     g = torch.Generator(device="cuda").manual_seed(batch + n_sh)
     qkv = torch.randn(batch, n_own, 1536, device="cuda", generator=g).to(torch.bfloat16)
     qkvs = torch.randn(max(n_sh, 1), 1536, device="cuda", generator=g).to(torch.bfloat16)
@@ -310,7 +310,7 @@ def test_pipelined_attention_is_the_direct_kernel_bit_for_bit(batch, n_own, n_sh
     for kernel in (0, 1):
         O = torch.full((batch, L, 512), float("nan"), device="cuda", dtype=torch.bfloat16)
         rc = fn(qkv.data_ptr(), qkvs.data_ptr() if n_sh else None, O.data_ptr(), batch, n_own, n_sh, kernel,
-                C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                C.c_void_p(torch.cuda.current_stream().cuda_stream), None)
         assert rc == 0, lib.m3pc_last_error()
         torch.cuda.synchronize()
         outs.append(O)

@@ -16,7 +16,7 @@ def main():
     lib = capi.load_library()
     fn = lib.m3pc_debug_attention_bf16
     fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]
+    fn.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p] * 2
     nset = 10
     for n_own, n_sh in ((49, 0), (32, 17)):
         L = n_own + n_sh
@@ -30,12 +30,23 @@ def main():
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(nset + 1)]
                 ev[0].record()
                 for i, (q, qs, o) in enumerate(sets):
-                    assert fn(q.data_ptr(), qs.data_ptr() if n_sh else None, o.data_ptr(), batch, n_own, n_sh, kernel, s) == 0
+                    assert fn(q.data_ptr(), qs.data_ptr() if n_sh else None, o.data_ptr(), batch, n_own, n_sh, kernel, s, None) == 0
                     ev[i + 1].record()
                 torch.cuda.synchronize()
                 if rep:
                     ts += [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(nset)]
             ts.sort()
+            if kernel == 0:
+                stamps = torch.zeros(16, dtype=torch.int64, device="cuda")
+                q, qs, o = sets[0]
+                for _ in range(2):
+                    fn(q.data_ptr(), qs.data_ptr() if n_sh else None, o.data_ptr(), batch, n_own, n_sh, 0, s, stamps.data_ptr())
+                torch.cuda.synchronize()
+                st = stamps.cpu().tolist()
+                names = ["scores", "softmax", "P V", "O -> LDS + barrier", "read back + barrier", "stores"]
+                for w in (0, 1):
+                    print(f"   wave {w} item 3 clocks: " + "  ".join(f"{n} {st[8 * w + i + 1] - st[8 * w + i]}" for i, n in enumerate(names))
+                          + f"  total {st[8 * w + 6] - st[8 * w]}")
             print(f"batch {batch} own {n_own} shared {n_sh} {name:9s}: min {ts[0]:6.1f} us  med {ts[len(ts) // 2]:6.1f} us  "
                   f"{mb / ts[len(ts) // 2]:.2f} TB/s algorithmic ({mb:.0f} MB)", flush=True)
 
