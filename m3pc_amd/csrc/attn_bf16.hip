@@ -412,20 +412,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_direct_kernel(AttnP p) {
 namespace {
 constexpr int APIPE_NR = 52, APIPE_IMG = APIPE_NR * 256, APIPE_BUF = 3 * APIPE_IMG;
 }
-template <int NQ1, int NQ2, int NK1, int NK2>
+template <int N1, int SH>
 __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_items) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int HD = 128, NS = 8, HDT = 4;
-    constexpr int NDMA = NQ1 + NQ2 + 2 * (NK1 + NK2);  // pieces per item (the loader's)
-    constexpr int NST = (APIPE_NR / 4 + 1) / 2;        // stores per compute wave and item (4 rows each)
-    static_assert(NDMA <= 63, "vmcnt");
+    constexpr int Lk = N1 + SH;                                  // keys: the item's own N1 rows, then SH rows shared by the batch
+    constexpr int NP_OWN = (N1 + 3) / 4, NP_SH = SH ? (Lk + 3) / 4 - N1 / 4 : 0;  // 4-row pieces of the two key segments (the one at the seam twice)
+    constexpr int NDMA = NP_OWN + 2 * (NP_OWN + NP_SH);          // pieces per item (the loader's): Q, K, V
+    constexpr int NST = (APIPE_NR / 4 + 1) / 2;                  // stores per compute wave and item (4 rows each)
+    static_assert(NDMA <= 63 && Lk <= APIPE_NR && (SH == 0 || (SH == 32 && N1 <= APIPE_NR - 32)), "shapes");
     extern __shared__ __attribute__((aligned(16))) char lds[];  // 2 * APIPE_BUF bytes (dynamic: two workgroups per CU must fit to the byte)
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0, 1: compute; 2: loader
     const int l31 = lane & 31, lh = lane >> 5;
-    const int Lk = p.L1 + p.L2;
-    const int Lq1p = NQ2 ? 32 : 0;  // (launcher: a second query segment starts at slot 32)
+    // query slots: SH == 0: slot i = the item's query i.  SH == 32 (first layer): slots 0..N1-1 = the item's queries (wave 0),
+    // slots 32..63 = the 32 shared ones (wave 1: the same rows for every item of a head, and a workgroup's items share the head)
+    constexpr int QROW0 = SH ? 32 : 0;  // image row of the item's first query = its output row (run_block: shared rows first)
 
     {   // zero the images once: rows no piece ever writes must stay zero (V rows of keys >= Lk)
         const u32x4 z = {0u, 0u, 0u, 0u};
@@ -438,30 +441,33 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
 
     if (wid == 2) {
         // ---------------------------------------------------------------- loader
-        // this lane's source offsets inside a piece (swizzled by the image row & 7 = 4 (piece & 1) + r4) for the four row strides
+        // this lane's source offset inside image piece pc (rows 4 pc .. 4 pc + 3, swizzled by the image row & 7 = 4 (pc & 1) + r4)
         auto voff = [&](int ld, int odd) { return (unsigned)(r4 * ld * 2 + ((c16 ^ (4 * odd + r4)) << 4)); };
-        const unsigned vq[2] = {voff(p.ldq, 0), voff(p.ldq, 1)}, vq2[2] = {voff(p.ldq2, 0), voff(p.ldq2, 1)};
+        const unsigned vq[2] = {voff(p.ldq, 0), voff(p.ldq, 1)};
         const unsigned vk[2] = {voff(p.ldkv1, 0), voff(p.ldkv1, 1)}, vk2[2] = {voff(p.ldkv2, 0), voff(p.ldkv2, 1)};
-        // N pieces of one segment (rows [0, L) of `base`, row stride ld elements; rows >= L are out of the resource's range)
-        // -> image rows row0.. of `img` (row0 a multiple of 8: the swizzle is that of the image row)
-        auto seg_dma = [&](const bf16_t* base, int L, int ld, const unsigned (&v)[2], char* img, int row0, auto n_c) {
-            constexpr int N = decltype(n_c)::value;
-            if (N == 0) return;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (unsigned)(L * ld * 2), 0x00020000);
+        // source rows [0, L) of `src` (row stride ld elements) -> image rows R0 .. R0 + L - 1: the image pieces that hold them, lanes
+        // of other rows switched off (a piece at the seam of two segments is issued once for each)
+        auto seg_dma = [&](const bf16_t* src, int ld, const unsigned (&v)[2], char* img, auto r0_c, auto l_c) {
+            constexpr int R0 = decltype(r0_c)::value, L = decltype(l_c)::value;
+            if (L == 0) return;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src - (long long)R0 * ld), 0, (unsigned)((R0 + L) * ld * 2), 0x00020000);
 #pragma unroll
-            for (int pc = 0; pc < N; ++pc)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(img + (row0 / 4 + pc) * 1024), 16, v[pc & 1], pc * 4 * ld * 2, 0, 0);
+            for (int pc = R0 / 4; pc <= (R0 + L - 1) / 4; ++pc) {
+                const bool lo = 4 * pc >= R0 ? true : 4 * pc + r4 >= R0;
+                const bool hi = 4 * pc + 3 < R0 + L ? true : 4 * pc + r4 < R0 + L;
+                if (lo && hi) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(img + pc * 1024), 16, v[pc & 1], pc * 4 * ld * 2, 0, 0);
+            }
         };
+        using I0 = std::integral_constant<int, 0>;
         auto issue = [&](int it, int buf) {
             if (p.no_pipe == 3) return;  // (lab timing: no loads)
             const int b = it / p.n_head, head = it % p.n_head;
             char* const B = lds + buf * APIPE_BUF;
-            seg_dma((const bf16_t*)p.K1 + b * p.kv1_bstride + head * HD, p.L1, p.ldkv1, vk, B + APIPE_IMG, 0, std::integral_constant<int, NK1>{});
-            seg_dma((const bf16_t*)p.K2 + head * HD, p.L2, p.ldkv2, vk2, B + APIPE_IMG, 4 * NK1, std::integral_constant<int, NK2>{});
-            seg_dma((const bf16_t*)p.Q + b * p.q_bstride + head * HD, p.Lq, p.ldq, vq, B + 2 * APIPE_IMG, 0, std::integral_constant<int, NQ1>{});
-            seg_dma((const bf16_t*)p.Q2 + head * HD, p.Lq2, p.ldq2, vq2, B + 2 * APIPE_IMG, Lq1p, std::integral_constant<int, NQ2>{});
-            seg_dma((const bf16_t*)p.V1 + b * p.kv1_bstride + head * HD, p.L1, p.ldkv1, vk, B, 0, std::integral_constant<int, NK1>{});
-            seg_dma((const bf16_t*)p.V2 + head * HD, p.L2, p.ldkv2, vk2, B, 4 * NK1, std::integral_constant<int, NK2>{});
+            seg_dma((const bf16_t*)p.K1 + b * p.kv1_bstride + head * HD, p.ldkv1, vk, B + APIPE_IMG, I0{}, std::integral_constant<int, N1>{});
+            seg_dma((const bf16_t*)p.K2 + head * HD, p.ldkv2, vk2, B + APIPE_IMG, std::integral_constant<int, N1>{}, std::integral_constant<int, SH>{});
+            seg_dma((const bf16_t*)p.Q + b * p.q_bstride + head * HD, p.ldq, vq, B + 2 * APIPE_IMG, std::integral_constant<int, QROW0>{}, std::integral_constant<int, N1>{});
+            seg_dma((const bf16_t*)p.V1 + b * p.kv1_bstride + head * HD, p.ldkv1, vk, B, I0{}, std::integral_constant<int, N1>{});
+            seg_dma((const bf16_t*)p.V2 + head * HD, p.ldkv2, vk2, B, std::integral_constant<int, N1>{}, std::integral_constant<int, SH>{});
         };
         if (n_mine > 0) issue(blockIdx.x, 0);
         if (n_mine > 1) issue(blockIdx.x + stride, 1);
@@ -482,6 +488,12 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
     const int sw = l31 & 7;         // fragment addresses: chunk ^ (row & 7)
     const int gi = lane & 15;
     long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (lab: shader-clock stamps of this workgroup's third item)
+    u32x4 qf[NS];
+    if (SH && wid == 1) {  // the shared queries of this workgroup's head, once
+        const bf16_t* qrow = (const bf16_t*)p.Q2 + (blockIdx.x % p.n_head) * HD + (long long)l31 * p.ldq2 + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) qf[s] = *(const u32x4*)(qrow + 16 * s);
+    }
     for (int k = 0; k < n_mine; ++k) {
         const int it = blockIdx.x + k * stride;
         const char* const B = lds + (k & 1) * APIPE_BUF;
@@ -495,9 +507,10 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
         const unsigned vbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)B;  // (the V image: first in the buffer)
         const char* const Ki = B + APIPE_IMG;
         const char* const Qi = B + 2 * APIPE_IMG;
-        u32x4 qf[NS];
+        if (SH == 0 || wid == 0) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) qf[s] = *(const u32x4*)(Qi + qi * 256 + (((2 * s + lh) ^ sw) << 4));
+            for (int s = 0; s < NS; ++s) qf[s] = *(const u32x4*)(Qi + (QROW0 + qi) * 256 + (((2 * s + lh) ^ sw) << 4));
+        }
         f32x16 sacc[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -574,7 +587,9 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
         if (p.stamps && k == 2) st_[3] = __builtin_readcyclecounter();
         {
             char* const Oi = (char*)Qi;
-            if (qi < APIPE_NR) {
+            // (output row = image row: SH == 0: the query's slot; first layer: the shared queries' rows 0..31, then the item's own)
+            const int orow_i = SH == 0 ? qi : (wid == 0 ? 32 + qi : qi - 32);
+            if (SH == 0 ? qi < APIPE_NR : (wid == 1 || qi < N1)) {
 #pragma unroll
                 for (int d = 0; d < HDT; ++d)
 #pragma unroll
@@ -582,7 +597,7 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
                         bf16x4 w;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) w[i] = (bf16_t)oacc[d][4 * q + i];
-                        *(bf16x4*)(Oi + qi * 256 + (((4 * d + q) ^ sw) << 4) + 8 * lh) = w;
+                        *(bf16x4*)(Oi + orow_i * 256 + (((4 * d + q) ^ (orow_i & 7)) << 4) + 8 * lh) = w;
                     }
             }
         }
@@ -607,9 +622,7 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
                 int pc = 2 * j + wid;
                 pc = pc < APIPE_NR / 4 ? pc : APIPE_NR / 4 - 1;
                 const int row = 4 * pc + r4;
-                unsigned off = 0x80000000u;
-                if (row < p.Lq) off = (unsigned)((p.orow1 + row) * p.ldo * 2);
-                else if (NQ2 && row >= Lq1p && row - Lq1p < p.Lq2) off = (unsigned)((p.orow2 + row - Lq1p) * p.ldo * 2);
+                const unsigned off = row < Lk ? (unsigned)((SH ? row : p.orow1 + row) * p.ldo * 2) : 0x80000000u;
                 __builtin_amdgcn_raw_buffer_store_b128(ov[j], o_rs, off + ((c16 ^ (row & 7)) << 4), 0, 0);
             }
         }
@@ -619,33 +632,35 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
         for (int i = 0; i < 7; ++i) p.stamps[wid * 8 + i] = st_[i];
 #endif
 }
-template <int NQ1, int NQ2, int NK1, int NK2>
+template <int N1, int SH>
 static void launch_pipe(const AttnP& p, hipStream_t st) {
     const int n_items = p.batch * p.n_head;
-    int cap = 512;  // two workgroups per CU
+    int cap = 512;  // two workgroups per CU; a multiple of the head count (a workgroup's items share the head)
 #ifdef M3PC_LAB
     static const int env_cap = M3PC_ENV("M3PC_ATTN_PIPE_GRID") ? atoi(M3PC_ENV("M3PC_ATTN_PIPE_GRID")) : 0;
     if (env_cap > 0) cap = env_cap;
 #endif
+    cap -= cap % p.n_head;
     const int grid = n_items < cap ? n_items : cap;
-    static const bool attr_ok = hipFuncSetAttribute((const void*)attn_bf16_pipe_kernel<NQ1, NQ2, NK1, NK2>,
+    static const bool attr_ok = hipFuncSetAttribute((const void*)attn_bf16_pipe_kernel<N1, SH>,
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * APIPE_BUF) == hipSuccess;
     (void)attr_ok;
-    hipLaunchKernelGGL((attn_bf16_pipe_kernel<NQ1, NQ2, NK1, NK2>), dim3(grid), dim3(192), 2 * APIPE_BUF, st, p, n_items);
+    hipLaunchKernelGGL((attn_bf16_pipe_kernel<N1, SH>), dim3(grid), dim3(192), 2 * APIPE_BUF, st, p, n_items);
 }
-// the shapes the pipelined kernel is built for; everything else takes the kernels below
+// the shapes the pipelined kernel is built for (the two encoder layers of the T = 32 candidate pass); everything else takes the kernels below
 static bool try_pipe(const AttnP& p, hipStream_t st) {
-    if (p.hd != 128 || p.pre_m || p.no_pipe == 1 || p.batch * p.n_head < 1024) return false;
+    if (p.hd != 128 || p.n_head != 4 || p.pre_m || p.no_pipe == 1 || p.batch * p.n_head < 1024) return false;
     if (((uintptr_t)p.Q | (uintptr_t)p.K1 | (uintptr_t)p.V1 | (uintptr_t)p.O) & 15) return false;
     if ((p.ldq | p.ldkv1 | p.ldo) % 8 || (p.q_bstride | p.kv1_bstride | p.o_bstride) % 8) return false;
-    if ((long long)p.Lq * p.ldq * 2 >= 0x7fffffffLL || (long long)p.L1 * p.ldkv1 * 2 >= 0x7fffffffLL) return false;
-    if (!p.Q2 && !p.K2 && p.Lq == 49 && p.L1 == 49 && p.L2 == 0) {
-        launch_pipe<13, 0, 13, 0>(p, st);
+    if ((long long)64 * p.ldq * 2 >= 0x7fffffffLL || (long long)64 * p.ldkv1 * 2 >= 0x7fffffffLL || (long long)64 * p.ldo * 2 >= 0x7fffffffLL) return false;
+    if (!p.Q2 && !p.K2 && p.Lq == 49 && p.L1 == 49 && p.L2 == 0 && p.orow1 >= 0) {
+        launch_pipe<49, 0>(p, st);
         return true;
     }
-    if (p.Q2 && p.K2 && p.Lq == 32 && p.Lq2 == 17 && p.L1 == 32 && p.L2 == 17 && !(((uintptr_t)p.Q2 | (uintptr_t)p.K2 | (uintptr_t)p.V2) & 15) &&
-        (p.ldq2 | p.ldkv2) % 8 == 0) {
-        launch_pipe<8, 5, 8, 5>(p, st);
+    // first layer: the history tokens' rows are shared by the batch (run_block: 17 own + 32 shared rows, shared rows first in the output)
+    if (p.Q2 && p.K2 && p.V2 && p.Lq == 17 && p.L1 == 17 && p.Lq2 == 32 && p.L2 == 32 && p.orow1 == 32 && p.orow2 == 0 &&
+        !(((uintptr_t)p.Q2 | (uintptr_t)p.K2 | (uintptr_t)p.V2) & 15) && (p.ldq2 | p.ldkv2) % 8 == 0 && (long long)64 * p.ldkv2 * 2 < 0x7fffffffLL) {
+        launch_pipe<17, 32>(p, st);
         return true;
     }
     return false;

@@ -293,10 +293,11 @@ def test_kv_fused_rows_independent_of_batch():
 
 
 # ------------------------------------------------------------------------------------------------ bf16 attention (attn_bf16.hip)
-@pytest.mark.parametrize("batch,n_own,n_sh", [(512, 49, 0), (512, 32, 17), (300, 49, 0), (257, 32, 17)])
+@pytest.mark.parametrize("batch,n_own,n_sh", [(512, 49, 0), (512, 17, 32), (300, 49, 0), (257, 17, 32), (256, 20, 29)])
 def test_pipelined_attention_is_the_direct_kernel_bit_for_bit(batch, n_own, n_sh):
     """attn_bf16_pipe_kernel (persistent workgroups, rows by LDS-DMA, two items in flight) against attn_bf16_direct_kernel on the two
-    encoder-layer shapes of the candidate pass: same products, same order -- equal bits -- and both against a float64 softmax.
+    encoder-layer shapes of the candidate pass (second layer: 49 own rows; first: 17 own + 32 history rows shared by the batch): same
+    products, same order -- equal bits -- and both against a float64 softmax.  (20 + 29: a split only the direct kernel takes.)
     Item counts that are / are not multiples of the grid, so that workgroups end on different iterations."""
     lib = lab_library()
     fn = lib.m3pc_debug_attention_bf16

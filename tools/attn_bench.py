@@ -18,7 +18,7 @@ def main():
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p] * 2
     nset = 10
-    for n_own, n_sh in ((49, 0), (32, 17)):
+    for n_own, n_sh in ((49, 0), (17, 32)):
         L = n_own + n_sh
         sets = [(torch.randn(batch, n_own, 1536, device="cuda").to(torch.bfloat16), torch.randn(max(n_sh, 1), 1536, device="cuda").to(torch.bfloat16),
                  torch.empty(batch, L, 512, device="cuda", dtype=torch.bfloat16)) for _ in range(nset)]
