@@ -407,7 +407,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_direct_kernel(AttnP p) {
 // of a 32-dim tile): whole 256-byte rows out, 4 rows per store instruction.
 // Images per buffer: V | K | Q, 52 rows each.  Fragment rows past an image (keys or queries 52..63) read the image behind
 // it: finite values that are masked (scores of keys >= Lk), multiplied by an exact zero (V rows of keys >= Lk: rows
-// Lk..51 are never written and stay zero) or never stored (queries).
+// Lk..51 are never written and are zeroed once) or never stored (queries).
 // NQ1, NQ2, NK1, NK2: 4-row pieces of the per-item and the batch-shared query / key segments.
 namespace {
 constexpr int APIPE_NR = 52, APIPE_IMG = APIPE_NR * 256, APIPE_BUF = 3 * APIPE_IMG;
@@ -419,7 +419,6 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
     constexpr int Lk = N1 + SH;                                  // keys: the item's own N1 rows, then SH rows shared by the batch
     constexpr int NP_OWN = (N1 + 3) / 4, NP_SH = SH ? (Lk + 3) / 4 - N1 / 4 : 0;  // 4-row pieces of the two key segments (the one at the seam twice)
     constexpr int NDMA = NP_OWN + 2 * (NP_OWN + NP_SH);          // pieces per item (the loader's): Q, K, V
-    constexpr int NST = (APIPE_NR / 4 + 1) / 2;                  // stores per compute wave and item (4 rows each)
     static_assert(NDMA <= 63 && Lk <= APIPE_NR && (SH == 0 || (SH == 32 && N1 <= APIPE_NR - 32)), "shapes");
     extern __shared__ __attribute__((aligned(16))) char lds[];  // 2 * APIPE_BUF bytes (dynamic: two workgroups per CU must fit to the byte)
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -430,9 +429,10 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
     // slots 32..63 = the 32 shared ones (wave 1: the same rows for every item of a head, and a workgroup's items share the head)
     constexpr int QROW0 = SH ? 32 : 0;  // image row of the item's first query = its output row (run_block: shared rows first)
 
-    {   // zero the images once: rows no piece ever writes must stay zero (V rows of keys >= Lk)
+    {   // the V rows of keys >= Lk are never written and must be zero: P is exactly zero there, and 0 x (what LDS held) must not be a NaN
         const u32x4 z = {0u, 0u, 0u, 0u};
-        for (int i = tid; i < 2 * APIPE_BUF / 16; i += 192) *(u32x4*)(lds + i * 16) = z;
+        constexpr int NZ = (APIPE_NR - Lk) * 16;  // 16-byte chunks per buffer
+        for (int i = tid; i < 2 * NZ; i += 192) *(u32x4*)(lds + (i / NZ) * APIPE_BUF + Lk * 256 + (i % NZ) * 16) = z;
     }
     const int r4 = lane >> 4, c16 = lane & 15;  // a piece: row r4 of its 4, 16-byte chunk c16
     const int n_mine = ((int)blockIdx.x < n_items) ? (n_items - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
         using I0 = std::integral_constant<int, 0>;
         auto issue = [&](int it, int buf) {
             if (p.no_pipe == 3) return;  // (lab timing: no loads)
-            const int b = it / p.n_head, head = it % p.n_head;
+            const int b = it >> 2, head = it & 3;  // (4 heads: try_pipe)
             char* const B = lds + buf * APIPE_BUF;
             seg_dma((const bf16_t*)p.K1 + b * p.kv1_bstride + head * HD, p.ldkv1, vk, B + APIPE_IMG, I0{}, std::integral_constant<int, N1>{});
             seg_dma((const bf16_t*)p.K2 + head * HD, p.ldkv2, vk2, B + APIPE_IMG, std::integral_constant<int, N1>{}, std::integral_constant<int, SH>{});
@@ -478,7 +478,6 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");  // A: the compute waves start on item k
             if (k >= 1 && k + 1 < n_mine) issue(blockIdx.x + (k + 1) * stride, (k + 1) & 1);  // (its buffer is free since barrier B of item k - 1)
-            asm volatile("s_barrier" ::: "memory");  // C: (their O rows are in the Q image)
             asm volatile("s_barrier" ::: "memory");  // B: they are done with the buffer
         }
         return;
@@ -500,7 +499,7 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
         asm volatile("s_barrier" ::: "memory");  // A
         if (p.stamps && k == 2) st_[0] = __builtin_readcyclecounter();
         if (p.no_pipe == 2) {  // (lab timing: no arithmetic)
-            asm volatile("s_barrier\n\ts_barrier" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
             continue;
         }
         // ---- S^T = K Q^T
@@ -513,15 +512,16 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
         }
         f32x16 sacc[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) sacc[t][e] = 0.f;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
+        for (int s = 0; s < NS; ++s)  // (the two key tiles' accumulator chains side by side)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
                 const u32x4 kf = *(const u32x4*)(Ki + (32 * t + l31) * 256 + (((2 * s + lh) ^ sw) << 4));
                 sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[s]), sacc[t], 0, 0, 0);
             }
-        }
         asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]));
         if (p.stamps && k == 2) st_[1] = __builtin_readcyclecounter();
         float m = -INFINITY;
@@ -554,35 +554,42 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
         for (int d = 0; d < HDT; ++d)
 #pragma unroll
             for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+        // transposing reads of 16-key step n = 2 jt + s2: lane -> key row kr (and kr + 8), 8 bytes at dim d * 32 + ((lane >> 4) & 1) * 16 +
+        // (gi & 3) * 4.  As asm statements (the builtin carries no memory operand, and hipcc would order it behind every LDS-DMA
+        // it has seen with a full vmcnt(0)), one step ahead of the MFMAs that use them: LDS operations return in order, so
+        // lgkmcnt(8) = "all but the 8 reads of the next step".
+        s16x4 tv[2][2 * HDT];
+        auto tr_reads = [&](int n, s16x4 (&v)[2 * HDT]) {
+            const int kr = 16 * n + 4 * lh + (gi >> 2);
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
+            for (int d = 0; d < HDT; ++d) {
+                const int bo = d * 64 + ((lane >> 4) & 1) * 32 + (gi & 3) * 8;  // byte offset in the row
+                const unsigned a0 = vbase + kr * 256 + ((((bo >> 4) ^ (kr & 7)) << 4) | (bo & 15));
+                const unsigned a1 = vbase + (kr + 8) * 256 + ((((bo >> 4) ^ ((kr + 8) & 7)) << 4) | (bo & 15));
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v[2 * d]) : "v"(a0));
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v[2 * d + 1]) : "v"(a1));
+            }
+        };
+        tr_reads(0, tv[0]);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 pa;
+        for (int n = 0; n < 4; ++n) {
+            const int jt = n >> 1, s2 = n & 1;
+            bf16x8 pa;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pa[e] = (bf16_t)(sacc[jt][8 * s2 + e] * inv);
-                // transposing reads: lane -> key row kr (and kr + 8), 8 bytes at dim d * 32 + ((lane >> 4) & 1) * 16 + (gi & 3) * 4.
-                // As asm statements: the builtin carries no memory operand, and hipcc would order it behind every LDS-DMA it
-                // has seen with a full vmcnt(0).
-                const int kr = jt * 32 + 16 * s2 + 4 * lh + (gi >> 2);
-                s16x4 v0[HDT], v1[HDT];
+            for (int e = 0; e < 8; ++e) pa[e] = (bf16_t)(sacc[jt][8 * s2 + e] * inv);
+            s16x4(&cur)[2 * HDT] = tv[n & 1];
+            if (n < 3) {
+                tr_reads(n + 1, tv[(n + 1) & 1]);
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
+            }
 #pragma unroll
-                for (int d = 0; d < HDT; ++d) {
-                    const int bo = d * 64 + ((lane >> 4) & 1) * 32 + (gi & 3) * 8;  // byte offset in the row
-                    const unsigned a0 = vbase + kr * 256 + ((((bo >> 4) ^ (kr & 7)) << 4) | (bo & 15));
-                    const unsigned a1 = vbase + (kr + 8) * 256 + ((((bo >> 4) ^ ((kr + 8) & 7)) << 4) | (bo & 15));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v0[d]) : "v"(a0));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v1[d]) : "v"(a1));
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0[0]), "+v"(v0[1]), "+v"(v0[2]), "+v"(v0[3]), "+v"(v1[0]), "+v"(v1[1]), "+v"(v1[2]), "+v"(v1[3]));
-#pragma unroll
-                for (int d = 0; d < HDT; ++d) {
-                    const s16x8 vb = __builtin_shufflevector(v0[d], v1[d], 0, 1, 2, 3, 4, 5, 6, 7);
-                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vb), pa, oacc[d], 0, 0, 0);
-                }
+            for (int d = 0; d < HDT; ++d) {
+                const s16x8 vb = __builtin_shufflevector(cur[2 * d], cur[2 * d + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vb), pa, oacc[d], 0, 0, 0);
             }
         }
-        // ---- O through the Q image (this wave writes the rows it read)
         asm volatile("" : "+v"(oacc[0]), "+v"(oacc[1]), "+v"(oacc[2]), "+v"(oacc[3]));
         if (p.stamps && k == 2) st_[3] = __builtin_readcyclecounter();
         {
@@ -601,26 +608,27 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
                     }
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // C
         if (p.stamps && k == 2) st_[4] = __builtin_readcyclecounter();
-        u32x4 ov[NST];
+        // read back the rows this wave wrote (same wave: LDS operations execute in order, no barrier): 4 rows per piece and store
+        constexpr int NPC_LO = 8, NPC_HI = APIPE_NR / 4 - 8;  // pieces of image rows 0..31 / 32..51
+        const bool low_rows = SH == 0 ? wid == 0 : wid == 1;    // (first layer: wave 1 owns the shared queries = rows 0..31)
+        u32x4 ov[NPC_LO];
 #pragma unroll
-        for (int j = 0; j < NST; ++j) {
-            int pc = 2 * j + wid;
-            pc = pc < APIPE_NR / 4 ? pc : APIPE_NR / 4 - 1;
+        for (int j = 0; j < NPC_LO; ++j) {
+            const int pc = low_rows ? j : (j < NPC_HI ? 8 + j : 8 + NPC_HI - 1);
             ov[j] = *(const u32x4*)(Qi + (4 * pc + r4) * 256 + c16 * 16);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B: the pieces of the item after next may land
         if (p.stamps && k == 2) st_[5] = __builtin_readcyclecounter();
-        // ---- stores (never waited for; rows that do not exist are addressed out of the buffer's range)
+        // ---- stores (never waited for; rows that do not exist are addressed out of the buffer's range; the wave of the upper
+        // rows repeats its last piece so that both issue the same number)
         {
-            const int b = it / p.n_head, head = it % p.n_head;
+            const int b = it >> 2, head = it & 3;  // (4 heads: try_pipe)
             const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)((bf16_t*)p.O + b * p.o_bstride + head * HD), 0, 0x7fffffffu, 0x00020000);
 #pragma unroll
-            for (int j = 0; j < NST; ++j) {
-                int pc = 2 * j + wid;
-                pc = pc < APIPE_NR / 4 ? pc : APIPE_NR / 4 - 1;
+            for (int j = 0; j < NPC_LO; ++j) {
+                const int pc = low_rows ? j : (j < NPC_HI ? 8 + j : 8 + NPC_HI - 1);
                 const int row = 4 * pc + r4;
                 const unsigned off = row < Lk ? (unsigned)((SH ? row : p.orow1 + row) * p.ldo * 2) : 0x80000000u;
                 __builtin_amdgcn_raw_buffer_store_b128(ov[j], o_rs, off + ((c16 ^ (row & 7)) << 4), 0, 0);
@@ -645,7 +653,12 @@ static void launch_pipe(const AttnP& p, hipStream_t st) {
     static const bool attr_ok = hipFuncSetAttribute((const void*)attn_bf16_pipe_kernel<N1, SH>,
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * APIPE_BUF) == hipSuccess;
     (void)attr_ok;
-    hipLaunchKernelGGL((attn_bf16_pipe_kernel<N1, SH>), dim3(grid), dim3(192), 2 * APIPE_BUF, st, p, n_items);
+    size_t lds_bytes = 2 * APIPE_BUF;
+#ifdef M3PC_LAB  // (occupancy experiment: a smaller allocation than the kernel uses -- out-of-range LDS accesses are dropped -- timing only)
+    static const int env_lds = M3PC_ENV("M3PC_ATTN_PIPE_LDS") ? atoi(M3PC_ENV("M3PC_ATTN_PIPE_LDS")) : 0;
+    if (env_lds > 0) lds_bytes = env_lds;
+#endif
+    hipLaunchKernelGGL((attn_bf16_pipe_kernel<N1, SH>), dim3(grid), dim3(192), lds_bytes, st, p, n_items);
 }
 // the shapes the pipelined kernel is built for (the two encoder layers of the T = 32 candidate pass); everything else takes the kernels below
 static bool try_pipe(const AttnP& p, hipStream_t st) {

@@ -43,7 +43,7 @@ def main():
                     fn(q.data_ptr(), qs.data_ptr() if n_sh else None, o.data_ptr(), batch, n_own, n_sh, 0, s, stamps.data_ptr())
                 torch.cuda.synchronize()
                 st = stamps.cpu().tolist()
-                names = ["scores", "softmax", "P V", "O -> LDS + barrier", "read back + barrier", "stores"]
+                names = ["scores", "softmax", "P V", "O -> LDS", "read back + barrier", "stores"]
                 for w in (0, 1):
                     print(f"   wave {w} item 3 clocks: " + "  ".join(f"{n} {st[8 * w + i + 1] - st[8 * w + i]}" for i, n in enumerate(names))
                           + f"  total {st[8 * w + 6] - st[8 * w]}")
