@@ -8,6 +8,8 @@
 //   * the matching B operand V[key][dim] needs, per lane (fixed dim), 4 consecutive keys: exactly what
 //     ds_read_b64_tr_b16 delivers from the row-major V image -- two transposed reads per fragment,
 //     no transposing stores.
+#include <cstdio>
+
 #include "kernels.h"
 
 namespace m3pc {
@@ -756,6 +758,12 @@ void launch_attention_prestats(const AttnP& p, float* pre_m, float* pre_l, float
 }
 
 void launch_attention_bf16(const AttnP& p, hipStream_t st) {
+#ifdef M3PC_LAB
+    static const bool log_shapes = M3PC_ENV("M3PC_ATTN_LOG") != nullptr;  // (which shapes a workload launches)
+    if (log_shapes)
+        fprintf(stderr, "attn bf16: batch %d heads %d hd %d  Lq %d Lq2 %d  L1 %d L2 %d  pre %d  orow %d %d  q_bstride %lld ldq %d ldkv1 %d\n", p.batch,
+                p.n_head, p.hd, p.Lq, p.Lq2, p.L1, p.L2, p.pre_m != nullptr, p.orow1, p.orow2, p.q_bstride, p.ldq, p.ldkv1);
+#endif
     switch (p.hd) {
         case 32: launch_hd<1>(p, st); break;
         case 64: launch_hd<2>(p, st); break;
