@@ -61,5 +61,11 @@ for kind in range(6):
     d = d[(d > 0).all(axis=1)]
     if len(d) == 0:
         continue
+    extra = ""
+    if kind < 2:  # layer-1 tail: the Q|K|V part's own stamps (clock at its first phase / behind its last)
+        ok = (rows[:, 0, 8] > rows[:, 0, 5]) & (rows[:, 0, 9] > rows[:, 0, 8])
+        if ok.any():
+            extra = (f"  [fragments + X'' drain {int(np.median((rows[:, 0, 8] - rows[:, 0, 5])[ok]))}  48 phases "
+                     f"{int(np.median((rows[:, 0, 9] - rows[:, 0, 8])[ok]))}]")
     print(f"{kinds[kind]:6s} n={len(d):3d}  " + "  ".join(f"{nm} {int(np.median(d[:, i]))}" for i, nm in enumerate(names))
-          + f"  total {int(np.median(d.sum(axis=1)))}")
+          + f"  total {int(np.median(d.sum(axis=1)))}" + extra)
