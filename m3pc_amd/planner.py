@@ -497,13 +497,14 @@ class HipPlanner:
                 chain.wait_event(sl.ev_done)  # (see _Slot.ready: the slot's buffers are free once its previous owner is done)
                 if self._ev_main is not None:
                     chain.wait_event(self._ev_main)  # (_mark_main: the caller's stream was in the policy workspace)
+            # the policy pass consumes no variate: its ~30 launches go out first, the draws are enqueued while the device runs them
+            hd.policy_pass(mode, states, actions, rewards, h, tk.rtg, slot=sl.i, returns=returns)
             if eps is None:
                 eps = self._draw_eps(mode, h, sl.eps_buf if chain is not None else None)
             tk.eps = eps = eps.reshape(N, -1, A)
             if expo is None:
                 expo = sl.expo_buf.exponential_(1, generator=self.generator) if chain is not None else self._draw_expo()
             tk.expo = expo
-            hd.policy_pass(mode, states, actions, rewards, h, tk.rtg, slot=sl.i, returns=returns)
             if chain is not None:
                 sl.ev_pol.record(chain)
         if chain is not None:
@@ -1184,13 +1185,8 @@ class HipPlanner:
         if plan:
             guidance = self.cfg.plan_guidance
             assert guidance in _MODES, guidance
-            # the step's variates do not depend on the window: their kernels are enqueued first and run while the host copies
-            # the window (same draws in the same order as without this: eps, then the multinomial's exponentials)
-            h, end_idx = int(self.cfg.horizon), int(sequence_history["path_length"])
-            if end_idx + h < self.T:
-                h = self.T - end_idx  # (learner.py:342-345, as _window_host)
+            # (the step's variates are drawn behind the policy pass's launches: _issue)
             self._drain()
-            self._predrawn = (_MODES[guidance], h, self._draw_eps(_MODES[guidance], h), self._draw_expo())
         states, actions, rewards, h, return_to_go = self.assemble_window(sequence_history, rtg, percentage)
         traj = {"states": states[None], "actions": actions[None], "rewards": rewards[None], "_rtg": return_to_go}
         if plan:
