@@ -526,13 +526,16 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
             }
         asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]));
         if (p.stamps && k == 2) st_[1] = __builtin_readcyclecounter();
+        // (a key slot that is past Lk in both lane halves is dead at compile time: its exp is an exact 0 in the sum and in P -- the
+        // same bits as the direct kernel's exp2(-inf) -- and costs nothing)
         float m = -INFINITY;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
+                if (jt * 32 + (e & 3) + 8 * (e >> 2) >= Lk) continue;
                 const int j = jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const float v = (j < Lk) ? sacc[jt][e] * p.scale : -INFINITY;
+                const float v = (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 < Lk || j < Lk) ? sacc[jt][e] * p.scale : -INFINITY;
                 sacc[jt][e] = v;
                 m = fmaxf(m, v);
             }
@@ -542,6 +545,10 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
+                if (jt * 32 + (e & 3) + 8 * (e >> 2) >= Lk) {
+                    sacc[jt][e] = 0.f;
+                    continue;
+                }
                 const float v = __builtin_amdgcn_exp2f((sacc[jt][e] - m) * 1.44269504088896340736f);
                 sacc[jt][e] = v;
                 l += v;
