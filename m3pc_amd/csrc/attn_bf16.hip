@@ -650,7 +650,7 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
 #endif
 }
 template <int N1, int SH>
-static void launch_pipe(const AttnP& p, hipStream_t st) {
+static bool launch_pipe(const AttnP& p, hipStream_t st) {
     const int n_items = p.batch * p.n_head;
     int cap = 512;  // two workgroups per CU; a multiple of the head count (a workgroup's items share the head)
 #ifdef M3PC_LAB
@@ -661,13 +661,14 @@ static void launch_pipe(const AttnP& p, hipStream_t st) {
     const int grid = n_items < cap ? n_items : cap;
     static const bool attr_ok = hipFuncSetAttribute((const void*)attn_bf16_pipe_kernel<N1, SH>,
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * APIPE_BUF) == hipSuccess;
-    (void)attr_ok;
+    if (!attr_ok) return false;  // (78 KB of dynamic LDS refused: the direct kernel takes the launch)
     size_t lds_bytes = 2 * APIPE_BUF;
 #ifdef M3PC_LAB  // (occupancy experiment: a smaller allocation than the kernel uses -- out-of-range LDS accesses are dropped -- timing only)
     static const int env_lds = M3PC_ENV("M3PC_ATTN_PIPE_LDS") ? atoi(M3PC_ENV("M3PC_ATTN_PIPE_LDS")) : 0;
     if (env_lds > 0) lds_bytes = env_lds;
 #endif
     hipLaunchKernelGGL((attn_bf16_pipe_kernel<N1, SH>), dim3(grid), dim3(192), lds_bytes, st, p, n_items);
+    return true;
 }
 // the shapes the pipelined kernel is built for (the two encoder layers of the T = 32 candidate pass); everything else takes the kernels below
 static bool try_pipe(const AttnP& p, hipStream_t st) {
@@ -676,14 +677,12 @@ static bool try_pipe(const AttnP& p, hipStream_t st) {
     if ((p.ldq | p.ldkv1 | p.ldo) % 8 || (p.q_bstride | p.kv1_bstride | p.o_bstride) % 8) return false;
     if ((long long)64 * p.ldq * 2 >= 0x7fffffffLL || (long long)64 * p.ldkv1 * 2 >= 0x7fffffffLL || (long long)64 * p.ldo * 2 >= 0x7fffffffLL) return false;
     if (!p.Q2 && !p.K2 && p.Lq == 49 && p.L1 == 49 && p.L2 == 0 && p.orow1 >= 0) {
-        launch_pipe<49, 0>(p, st);
-        return true;
+        return launch_pipe<49, 0>(p, st);
     }
     // first layer: the history tokens' rows are shared by the batch (run_block: 17 own + 32 shared rows, shared rows first in the output)
     if (p.Q2 && p.K2 && p.V2 && p.Lq == 17 && p.L1 == 17 && p.Lq2 == 32 && p.L2 == 32 && p.orow1 == 32 && p.orow2 == 0 &&
         !(((uintptr_t)p.Q2 | (uintptr_t)p.K2 | (uintptr_t)p.V2) & 15) && (p.ldq2 | p.ldkv2) % 8 == 0 && (long long)64 * p.ldkv2 * 2 < 0x7fffffffLL) {
-        launch_pipe<17, 32>(p, st);
-        return true;
+        return launch_pipe<17, 32>(p, st);
     }
     return false;
 }
