@@ -52,6 +52,11 @@ int m3pc_debug_kv_fused(const void* Z, int n, int Le, int kept0, int off0, int k
  * stamps: optional 16 int64 (device): shader-clock stamps of one workgroup's third item in the pipelined kernel */
 int m3pc_debug_attention_bf16(const void* QKV, const void* QKVs, void* O, int batch, int n_own, int n_sh, int kernel, void* stream,
                               long long* stamps);
+/* the decoder's bf16 attention of an rtg_guiding candidate pass: Qtab (nq <= 32, 1536) the batch-shared query rows [Q | . | .], QKVm (Lm, 1536)
+ * the masked tokens' rows [. | K | V] (their block of the softmax is pre-reduced into `pre`: 4 * nq * (2 + 128) floats of scratch), KV (n, 49, 1024)
+ * the candidates' own [K | V] rows; O (n, nq, 512).  kernel as m3pc_debug_attention_bf16 */
+int m3pc_debug_attention_dec_bf16(const void* Qtab, const void* QKVm, const void* KV, void* O, float* pre, int n, int nq, int Lm, int kernel,
+                                  void* stream);
 /* in-kernel phase stamps of workgroup 37 of every fused-tail launch as the step runs: cap > 0 starts a ring of cap entries
  * (64 int64 each), cap == 0 copies it to `out` (host), reports the number of launches logged and stops */
 int m3pc_debug_stamp_log(m3pc_handle* h, int cap, long long* out, int* n_logged);

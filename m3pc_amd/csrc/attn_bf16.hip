@@ -20,6 +20,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 template <int HDT, int NCH>
 __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnP p) {
@@ -649,6 +650,234 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
         for (int i = 0; i < 7; ++i) p.stamps[wid * 8 + i] = st_[i];
 #endif
 }
+// The decoder's attention of an rtg_guiding candidate pass in the same pipelined form: 32 queries that are the SAME rows for every
+// candidate (the masked scored tokens' query table) against the candidate's own N1 K|V rows, merged with the pre-reduced block of
+// the masked tokens' keys (AttnP::pre_m / pre_l / pre_O) exactly as attn_bf16_direct_kernel<4, 1, 2> merges it.  One 32-query tile
+// per item = one wave, so the workgroup's two compute waves work on two DIFFERENT items at a time (each with its own pair of
+// K|V buffers: 4 x 26 KB, one workgroup per CU); a workgroup's items share the head, so the Q fragments, the pre-block's
+// statistics and its pre_O rows are loaded once and stay in registers.  O leaves through the wave's own K image.
+template <int N1>
+__global__ __launch_bounds__(192, 1) void attn_bf16_pipe_dec_kernel(AttnP p, int n_items) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int HD = 128, NS = 8, HDT = 4;
+    constexpr int Lk = N1;
+    constexpr int NPC = (N1 + 3) / 4;       // 4-row pieces of one image
+    constexpr int NDMA = 2 * 2 * NPC;       // pieces per round (two items' K and V), the loader's
+    constexpr int DBUF = 2 * APIPE_IMG;     // one buffer: V | K
+    static_assert(NDMA <= 63 && Lk <= APIPE_NR, "shapes");
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // 4 * DBUF bytes: wave w's buffers at (2 w + r % 2) * DBUF
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0, 1: compute; 2: loader
+    const int l31 = lane & 31, lh = lane >> 5;
+    {   // the V rows of keys >= Lk are never written and must be zero (P is exactly zero there)
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        constexpr int NZ = (APIPE_NR - Lk) * 16;
+        for (int i = tid; i < 4 * NZ; i += 192) *(u32x4*)(lds + (i / NZ) * DBUF + Lk * 256 + (i % NZ) * 16) = z;
+    }
+    const int r4 = lane >> 4, c16 = lane & 15;
+    const int stride = gridDim.x;
+    // this workgroup's items: blockIdx.x + stride * j; compute wave w takes j = 2 r + w in round r
+    const int n_mine = ((int)blockIdx.x < n_items) ? (n_items - 1 - (int)blockIdx.x) / stride + 1 : 0;
+    const int n_rounds = (n_mine + 1) / 2;
+    const int head = blockIdx.x & 3;  // (4 heads, grid a multiple of 4: try_pipe)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    if (wid == 2) {
+        // ---------------------------------------------------------------- loader
+        const unsigned v[2] = {(unsigned)(r4 * p.ldkv1 * 2 + ((c16 ^ r4) << 4)), (unsigned)(r4 * p.ldkv1 * 2 + ((c16 ^ (4 + r4)) << 4))};
+        auto issue = [&](int r) {
+            if (p.no_pipe == 3) return;  // (lab timing: no loads)
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                int j = 2 * r + w;
+                j = j < n_mine ? j : n_mine - 1;  // (a wave without an item in the last round: its neighbour's rows again, never used)
+                const int it = blockIdx.x + stride * j;
+                char* const B = lds + (2 * w + (r & 1)) * DBUF;
+                const bf16_t* kb = (const bf16_t*)p.K1 + (long long)(it >> 2) * p.kv1_bstride + head * HD;
+                const bf16_t* vb = (const bf16_t*)p.V1 + (long long)(it >> 2) * p.kv1_bstride + head * HD;
+                const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, (unsigned)(N1 * p.ldkv1 * 2), 0x00020000);
+                const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (unsigned)(N1 * p.ldkv1 * 2), 0x00020000);
+#pragma unroll
+                for (int pc = 0; pc < NPC; ++pc) {
+                    const bool ok = 4 * pc + 3 < N1 ? true : 4 * pc + r4 < N1;
+                    if (ok) {
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lptr_t)(B + APIPE_IMG + pc * 1024), 16, v[pc & 1], pc * 4 * p.ldkv1 * 2, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lptr_t)(B + pc * 1024), 16, v[pc & 1], pc * 4 * p.ldkv1 * 2, 0, 0);
+                    }
+                }
+            }
+        };
+        if (n_rounds > 0) issue(0);
+        if (n_rounds > 1) issue(1);
+        for (int r = 0; r < n_rounds; ++r) {
+            if (r == 0 && n_rounds > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");  // A
+            if (r >= 1 && r + 1 < n_rounds) issue(r + 1);
+            asm volatile("s_barrier" ::: "memory");  // B
+        }
+        return;
+    }
+    // -------------------------------------------------------------------- compute waves
+    const int qi = l31;  // this lane's query
+    const int sw = l31 & 7;
+    const int gi = lane & 15;
+    // per workgroup constants: the Q fragments of this head's 32 shared queries, the pre-reduced block's statistics and pre_O rows
+    u32x4 qf[NS];
+    {
+        const bf16_t* qrow = (const bf16_t*)p.Q + head * HD + (long long)(qi < p.Lq ? qi : 0) * p.ldq + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) qf[s] = *(const u32x4*)(qrow + 16 * s);
+    }
+    float mp = -INFINITY, lp = 0.f;
+    f32x4v po[HDT][4];  // pre_O of this lane's query at the dims it owns: d * 32 + 8 q + 4 lh ..
+    if (qi < p.Lq) {
+        mp = p.pre_m[head * p.Lq + qi];
+        lp = p.pre_l[head * p.Lq + qi];
+    }
+    {
+        const float* prow = p.pre_O + ((long long)head * p.Lq + (qi < p.Lq ? qi : 0)) * HD + 4 * lh;
+#pragma unroll
+        for (int d = 0; d < HDT; ++d)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) po[d][q] = *(const f32x4v*)(prow + d * 32 + 8 * q);
+    }
+    const unsigned ooff_base = qi < p.Lq ? 0u : 0x80000000u;
+    (void)ooff_base;
+    for (int r = 0; r < n_rounds; ++r) {
+        const int j = 2 * r + wid;
+        const bool have = j < n_mine;
+        const int it = blockIdx.x + stride * (have ? j : 0);
+        const char* const B = lds + (2 * wid + (r & 1)) * DBUF;
+        asm volatile("s_barrier" ::: "memory");  // A
+        if (have && p.no_pipe != 2) {
+            const unsigned vbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)B;
+            const char* const Ki = B + APIPE_IMG;
+            f32x16 sacc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sacc[t][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const u32x4 kf = *(const u32x4*)(Ki + (32 * t + l31) * 256 + (((2 * s + lh) ^ sw) << 4));
+                    sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[s]), sacc[t], 0, 0, 0);
+                }
+            float m = -INFINITY;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (jt * 32 + (e & 3) + 8 * (e >> 2) >= Lk) continue;
+                    const int jj = jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const float v = (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 < Lk || jj < Lk) ? sacc[jt][e] * p.scale : -INFINITY;
+                    sacc[jt][e] = v;
+                    m = fmaxf(m, v);
+                }
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float l = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (jt * 32 + (e & 3) + 8 * (e >> 2) >= Lk) {
+                        sacc[jt][e] = 0.f;
+                        continue;
+                    }
+                    const float v = __builtin_amdgcn_exp2f((sacc[jt][e] - m) * 1.44269504088896340736f);
+                    sacc[jt][e] = v;
+                    l += v;
+                }
+            l += __shfl_xor(l, 32);
+            // the pre-reduced block: two blocks of a streaming softmax (attn_bf16_direct_kernel)
+            const float mt = fmaxf(m, mp);
+            const float a = __builtin_amdgcn_exp2f((m - mt) * 1.44269504088896340736f);
+            const float bs = __builtin_amdgcn_exp2f((mp - mt) * 1.44269504088896340736f);
+            const float lt = l * a + lp * bs;
+            const float inv = a / lt;
+            const float fpre = bs / lt;
+            f32x16 oacc[HDT];
+#pragma unroll
+            for (int d = 0; d < HDT; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+            s16x4 tv[2][2 * HDT];
+            auto tr_reads = [&](int n, s16x4 (&v)[2 * HDT]) {
+                const int kr = 16 * n + 4 * lh + (gi >> 2);
+#pragma unroll
+                for (int d = 0; d < HDT; ++d) {
+                    const int bo = d * 64 + ((lane >> 4) & 1) * 32 + (gi & 3) * 8;
+                    const unsigned a0 = vbase + kr * 256 + ((((bo >> 4) ^ (kr & 7)) << 4) | (bo & 15));
+                    const unsigned a1 = vbase + (kr + 8) * 256 + ((((bo >> 4) ^ ((kr + 8) & 7)) << 4) | (bo & 15));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v[2 * d]) : "v"(a0));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v[2 * d + 1]) : "v"(a1));
+                }
+            };
+            tr_reads(0, tv[0]);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int jt = n >> 1, s2 = n & 1;
+                bf16x8 pa;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pa[e] = (bf16_t)(sacc[jt][8 * s2 + e] * inv);
+                s16x4(&cur)[2 * HDT] = tv[n & 1];
+                if (n < 3) {
+                    tr_reads(n + 1, tv[(n + 1) & 1]);
+                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
+                }
+#pragma unroll
+                for (int d = 0; d < HDT; ++d) {
+                    const s16x8 vb = __builtin_shufflevector(cur[2 * d], cur[2 * d + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vb), pa, oacc[d], 0, 0, 0);
+                }
+            }
+            // ---- + the pre-reduced block, bf16, through this wave's K image (its scores are done), whole rows out
+            {
+                char* const Oi = (char*)Ki;
+#pragma unroll
+                for (int d = 0; d < HDT; ++d)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        bf16x4 w;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) w[i] = (bf16_t)fmaf(fpre, po[d][q][i], oacc[d][4 * q + i]);
+                        *(bf16x4*)(Oi + qi * 256 + (((4 * d + q) ^ sw) << 4) + 8 * lh) = w;
+                    }
+            }
+            u32x4 ov[8];
+#pragma unroll
+            for (int pc = 0; pc < 8; ++pc) ov[pc] = *(const u32x4*)(Ki + (4 * pc + r4) * 256 + c16 * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            {
+                const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)((bf16_t*)p.O + (long long)(it >> 2) * p.o_bstride + head * HD), 0, 0x7fffffffu, 0x00020000);
+#pragma unroll
+                for (int pc = 0; pc < 8; ++pc) {
+                    const int row = 4 * pc + r4;
+                    const unsigned off = row < p.Lq ? (unsigned)((p.orow1 + row) * p.ldo * 2) : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(ov[pc], o_rs, off + ((c16 ^ (row & 7)) << 4), 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B
+    }
+#endif
+}
+template <int N1>
+static bool launch_pipe_dec(const AttnP& p, hipStream_t st) {
+    const int n_items = p.batch * p.n_head;
+    const int grid = n_items < 256 ? n_items : 256;  // one workgroup per CU (4 x 26 KB of K|V buffers); a multiple of the 4 heads
+    static const bool attr_ok = hipFuncSetAttribute((const void*)attn_bf16_pipe_dec_kernel<N1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    8 * APIPE_IMG) == hipSuccess;
+    if (!attr_ok) return false;
+    hipLaunchKernelGGL((attn_bf16_pipe_dec_kernel<N1>), dim3(grid), dim3(192), 8 * APIPE_IMG, st, p, n_items);
+    return true;
+}
 template <int N1, int SH>
 static bool launch_pipe(const AttnP& p, hipStream_t st) {
     const int n_items = p.batch * p.n_head;
@@ -672,7 +901,14 @@ static bool launch_pipe(const AttnP& p, hipStream_t st) {
 }
 // the shapes the pipelined kernel is built for (the two encoder layers of the T = 32 candidate pass); everything else takes the kernels below
 static bool try_pipe(const AttnP& p, hipStream_t st) {
-    if (p.hd != 128 || p.n_head != 4 || p.pre_m || p.no_pipe == 1 || p.batch * p.n_head < 1024) return false;
+    if (p.hd != 128 || p.n_head != 4 || p.no_pipe == 1 || p.batch * p.n_head < 1024) return false;
+    if (p.pre_m) {  // the decoder of an rtg_guiding candidate pass: 32 batch-shared queries, the candidate's own 49 K|V rows, pre-reduced block
+        if (p.q_bstride != 0 || p.Q2 || p.K2 || p.Lq < 1 || p.Lq > 32 || p.L1 != 49 || p.L2 != 0 || !p.pre_l || !p.pre_O) return false;
+        if (((uintptr_t)p.Q | (uintptr_t)p.K1 | (uintptr_t)p.V1 | (uintptr_t)p.O | (uintptr_t)p.pre_O) & 15) return false;
+        if ((p.ldq | p.ldkv1 | p.ldo) % 8 || (p.kv1_bstride | p.o_bstride) % 8) return false;
+        if ((long long)64 * p.ldkv1 * 2 >= 0x7fffffffLL || (long long)64 * p.ldo * 2 >= 0x7fffffffLL) return false;
+        return launch_pipe_dec<49>(p, st);
+    }
     if (((uintptr_t)p.Q | (uintptr_t)p.K1 | (uintptr_t)p.V1 | (uintptr_t)p.O) & 15) return false;
     if ((p.ldq | p.ldkv1 | p.ldo) % 8 || (p.q_bstride | p.kv1_bstride | p.o_bstride) % 8) return false;
     if ((long long)64 * p.ldq * 2 >= 0x7fffffffLL || (long long)64 * p.ldkv1 * 2 >= 0x7fffffffLL || (long long)64 * p.ldo * 2 >= 0x7fffffffLL) return false;

@@ -3021,6 +3021,46 @@ int m3pc_debug_attention_bf16(const void* QKV, const void* QKVs, void* O, int ba
     return check_launch("debug_attention_bf16");
 }
 
+int m3pc_debug_attention_dec_bf16(const void* Qtab, const void* QKVm, const void* KV, void* O, float* pre, int n, int nq, int Lm, int kernel,
+                                  void* stream) {
+    const int d = 512, nh = 4, hd = 128, Le = 49;
+    hipStream_t st = (hipStream_t)stream;
+    float* pre_m = pre;
+    float* pre_l = pre + nh * nq;
+    float* pre_O = pre + 2 * nh * nq;
+    AttnP at;
+    memset(&at, 0, sizeof(at));
+    at.Q = Qtab;
+    at.ldq = 3 * d;
+    at.Lq = nq;
+    at.K2 = (const char*)QKVm + (size_t)d * 2;
+    at.V2 = (const char*)QKVm + (size_t)2 * d * 2;
+    at.ldkv2 = 3 * d;
+    at.L2 = Lm;
+    at.n_head = nh;
+    at.hd = hd;
+    at.scale = 1.0f / sqrtf((float)hd);
+    launch_attention_prestats(at, pre_m, pre_l, pre_O, st);
+    at.K2 = at.V2 = nullptr;
+    at.L2 = 0;
+    at.q_bstride = 0;
+    at.K1 = KV;
+    at.V1 = (const char*)KV + (size_t)d * 2;
+    at.kv1_bstride = (long long)Le * 2 * d;
+    at.ldkv1 = 2 * d;
+    at.L1 = Le;
+    at.O = O;
+    at.o_bstride = (long long)nq * d;
+    at.ldo = d;
+    at.batch = n;
+    at.pre_m = pre_m;
+    at.pre_l = pre_l;
+    at.pre_O = pre_O;
+    at.no_pipe = kernel;
+    launch_attention(at, DT_BF16, st);
+    return check_launch("debug_attention_dec_bf16");
+}
+
 int m3pc_debug_kv_fused(const void* Z, int n, int Le, int kept0, int off0, int kept1, int off1, const void* We0, const void* We1,
                         const void* Wkv, void* stream_buf, const float* rowtab0, const float* rowtab1, const float* ln_g,
                         const float* ln_b, const float* bkv, void* KV, void* stream, long long* stamps) {

@@ -323,3 +323,34 @@ def test_pipelined_attention_is_the_direct_kernel_bit_for_bit(batch, n_own, n_sh
         ref = torch.cat([torch.softmax(q[:, 128 * h:128 * h + 128] @ k[:, 128 * h:128 * h + 128].T / 128 ** 0.5, -1)
                          @ v[:, 128 * h:128 * h + 128] for h in range(4)], 1)
         assert float((outs[0][b].double() - ref).abs().max()) < 3e-2
+
+
+@pytest.mark.parametrize("n,nq,Lm", [(512, 32, 47), (300, 32, 47), (257, 20, 30)])
+def test_pipelined_decoder_attention_is_the_direct_kernel_bit_for_bit(n, nq, Lm):
+    """attn_bf16_pipe_dec_kernel (two compute waves on two different items, K|V rows by LDS-DMA, the pre-reduced block of the masked tokens'
+    keys merged in registers) against attn_bf16_direct_kernel<4, 1, 2>: equal bits, and both against a float64 softmax over all keys."""
+    lib = lab_library()
+    fn = lib.m3pc_debug_attention_dec_bf16
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]
+    g = torch.Generator(device="cuda").manual_seed(n + Lm)
+    qtab = torch.randn(nq, 1536, device="cuda", generator=g).to(torch.bfloat16)
+    qkvm = torch.randn(Lm, 1536, device="cuda", generator=g).to(torch.bfloat16)
+    kv = torch.randn(n, 49, 1024, device="cuda", generator=g).to(torch.bfloat16)
+    pre = torch.zeros(4 * nq * 130, device="cuda")
+    outs = []
+    for kernel in (0, 1):
+        O = torch.full((n, nq, 512), float("nan"), device="cuda", dtype=torch.bfloat16)
+        rc = fn(qtab.data_ptr(), qkvm.data_ptr(), kv.data_ptr(), O.data_ptr(), pre.data_ptr(), n, nq, Lm, kernel,
+                C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, lib.m3pc_last_error()
+        torch.cuda.synchronize()
+        outs.append(O)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    for b in (0, n // 2, n - 1):
+        q = qtab[:, :512].double()
+        k = torch.cat([kv[b, :, :512], qkvm[:, 512:1024]], 0).double()
+        v = torch.cat([kv[b, :, 512:], qkvm[:, 1024:]], 0).double()
+        ref = torch.cat([torch.softmax(q[:, 128 * h:128 * h + 128] @ k[:, 128 * h:128 * h + 128].T / 128 ** 0.5, -1)
+                         @ v[:, 128 * h:128 * h + 128] for h in range(4)], 1)
+        assert float((outs[0][b].double() - ref).abs().max()) < 3e-2

@@ -51,5 +51,35 @@ def main():
                   f"{mb / ts[len(ts) // 2]:.2f} TB/s algorithmic ({mb:.0f} MB)", flush=True)
 
 
+def dec(batch):
+    lib = capi.load_library()
+    fn = lib.m3pc_debug_attention_dec_bf16
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]
+    nset, nq, Lm = 10, 32, 47
+    qtab = torch.randn(nq, 1536, device="cuda").to(torch.bfloat16)
+    qkvm = torch.randn(Lm, 1536, device="cuda").to(torch.bfloat16)
+    pre = torch.zeros(4 * nq * 130, device="cuda")
+    sets = [(torch.randn(batch, 49, 1024, device="cuda").to(torch.bfloat16), torch.empty(batch, nq, 512, device="cuda", dtype=torch.bfloat16))
+            for _ in range(nset)]
+    mb = batch * (49 * 2048 + nq * 1024) / 1e6
+    for kernel, name in ((0, "pipelined"), (1, "direct"), (2, "pipe:loads"), (3, "pipe:math")):
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        ts = []
+        for rep in range(4):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(nset + 1)]
+            ev[0].record()
+            for i, (kv, o) in enumerate(sets):
+                assert fn(qtab.data_ptr(), qkvm.data_ptr(), kv.data_ptr(), o.data_ptr(), pre.data_ptr(), batch, nq, Lm, kernel, s) == 0
+                ev[i + 1].record()
+            torch.cuda.synchronize()
+            if rep:
+                ts += [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(nset)]
+        ts.sort()
+        print(f"decoder batch {batch} {name:9s}: min {ts[0]:6.1f} us  med {ts[len(ts) // 2]:6.1f} us  {mb / ts[len(ts) // 2]:.2f} TB/s algorithmic "
+              f"({mb:.0f} MB; incl. the prestats launch)", flush=True)
+
+
 if __name__ == "__main__":
     main()
+    dec(int(sys.argv[1]) if len(sys.argv) > 1 else 512)
