@@ -923,6 +923,112 @@ static bool try_pipe(const AttnP& p, hipStream_t st) {
     return false;
 }
 
+// Windows of at most 16 tokens (the zero-shot passes of BASELINE config 5: 10 and 12 kept tokens): the direct kernel gives every
+// (window, head) a 32-query x 64-key tile that is 14 % full.  Here TWO windows share one tile -- queries and keys of window w
+// at slots 16 w .. 16 w + 15 -- behind a block-diagonal mask.  Bit-identical to the direct kernel: a score is a sum over the
+// head dimension only; a window's keys fill positions 0.. of their OWN 16-key step of P V exactly as they fill step 0 there, the
+// other window's step multiplies exact zeros; and the softmax's register order meets the same values in the same order,
+// preceded by exact -inf / 0 (the 16-slot shift is 8 accumulator registers).  One query / key segment, no pre-reduced block.
+template <int HDT>
+__global__ __launch_bounds__(64, 4) void attn_bf16_pack2_kernel(AttnP p) {
+    constexpr int HD = HDT * 32;
+    constexpr int ROWB = HD * 2 + 16;
+    constexpr int NS = HD / 16;
+    constexpr int CPR = HD / 8;
+    __shared__ __attribute__((aligned(16))) char lds[32 * ROWB];
+    const int lane = threadIdx.x, l31 = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.y, b0 = 2 * blockIdx.x;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    // slot l31: window b0 + (l31 >> 4), its token l31 & 15 (query row and key row alike)
+    const int wb = b0 + (l31 >> 4), tk = l31 & 15;
+    const bool wok = wb < p.batch;
+    const bf16_t* qrow = wok && tk < p.Lq ? (const bf16_t*)p.Q + (long long)wb * p.q_bstride + head * HD + (long long)tk * p.ldq : nullptr;
+    const bf16_t* krow = wok && tk < p.L1 ? (const bf16_t*)p.K1 + (long long)wb * p.kv1_bstride + head * HD + (long long)tk * p.ldkv1 : nullptr;
+    u32x4 qf[NS], kf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        qf[s] = zero4;
+        if (qrow) qf[s] = *(const u32x4*)(qrow + 16 * s + 8 * lh);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        kf[s] = zero4;
+        if (krow) kf[s] = *(const u32x4*)(krow + 16 * s + 8 * lh);
+    }
+    f32x16 sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[s]), __builtin_bit_cast(bf16x8, qf[s]), sacc, 0, 0, 0);
+    // V image: row r = slot r (zero rows for tokens that do not exist)
+    constexpr int VPT = 32 * CPR / 64;
+    u32x4 vv[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int x = lane + i * 64, r = x / CPR, kc = x % CPR;
+        const int vb = b0 + (r >> 4), vt = r & 15;
+        vv[i] = zero4;
+        if (vb < p.batch && vt < p.L1) vv[i] = *(const u32x4*)((const bf16_t*)p.V1 + (long long)vb * p.kv1_bstride + head * HD + (long long)vt * p.ldkv1 + kc * 8);
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int j = (e & 3) + 8 * (e >> 2) + 4 * lh;  // key slot
+        const float v = ((j >> 4) == (l31 >> 4) && (j & 15) < p.L1) ? sacc[e] * p.scale : -INFINITY;
+        sacc[e] = v;
+        m = fmaxf(m, v);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float v = __builtin_amdgcn_exp2f((sacc[e] - m) * 1.44269504088896340736f);
+        sacc[e] = v;
+        l += v;
+    }
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int x = lane + i * 64, r = x / CPR, kc = x % CPR;
+        *(u32x4*)(lds + r * ROWB + kc * 16) = vv[i];
+    }
+    __syncthreads();
+    f32x16 oacc[HDT];
+#pragma unroll
+    for (int d = 0; d < HDT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+    const int gi = lane & 15;
+    const int tr_off = (gi >> 2) * ROWB + (((lane >> 4) & 1) * 16 + (gi & 3) * 4) * 2;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pa;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pa[e] = (bf16_t)(sacc[8 * s2 + e] * inv);
+        const int kb = 16 * s2 + 4 * lh;
+#pragma unroll
+        for (int d = 0; d < HDT; ++d) {
+            const char* base = lds + kb * ROWB + d * 64 + tr_off;
+            const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base));
+            const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + 8 * ROWB));
+            const s16x8 vb = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8, vb), oacc[d], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = (e & 3) + 8 * (e >> 2) + 4 * lh;  // query slot
+        const int ob = b0 + (i >> 4), ot = i & 15;
+        if (ob < p.batch && ot < p.Lq) {
+            bf16_t* Ob = (bf16_t*)p.O + (long long)ob * p.o_bstride + head * HD + (long long)(p.orow1 + ot) * p.ldo;
+#pragma unroll
+            for (int d = 0; d < HDT; ++d) Ob[d * 32 + l31] = (bf16_t)oacc[d][e];
+        }
+    }
+}
+
 template <int HDT, int NW, int NKT>
 static void launch_direct(const AttnP& p, int slots, hipStream_t st) {
     const size_t smem = (size_t)NKT * 32 * (HDT * 64 + 16) + NW * 32 * sizeof(float);
@@ -947,6 +1053,12 @@ static void launch_hd(const AttnP& p, hipStream_t st) {
     static const bool no_direct = M3PC_ENV("M3PC_NO_ATTN_DIRECT") != nullptr;  // A/B switch
     static const bool no_pipe = M3PC_ENV("M3PC_NO_ATTN_PIPE") != nullptr;      // A/B switch
     if (HDT == 4 && !no_pipe && !no_direct && try_pipe(p, st)) return;
+    static const bool no_pack = M3PC_ENV("M3PC_NO_ATTN_PACK") != nullptr;  // A/B switch
+    if (!no_direct && !no_pack && p.no_pipe != 1 && !p.Q2 && !p.K2 && !p.pre_m && p.L2 == 0 && p.Lq >= 1 && p.Lq <= 16 && p.L1 >= 1 && p.L1 <= 16 &&
+        p.batch >= 64) {  // two windows per tile (the zero-shot passes)
+        hipLaunchKernelGGL((attn_bf16_pack2_kernel<HDT>), dim3((p.batch + 1) / 2, p.n_head), dim3(64), 0, st, p);
+        return;
+    }
     if (Lk <= 64 && !no_direct) {
         if (slots <= 32)
             launch_direct<HDT, 1, 2>(p, slots, st);

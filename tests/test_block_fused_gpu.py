@@ -354,3 +354,30 @@ def test_pipelined_decoder_attention_is_the_direct_kernel_bit_for_bit(n, nq, Lm)
         ref = torch.cat([torch.softmax(q[:, 128 * h:128 * h + 128] @ k[:, 128 * h:128 * h + 128].T / 128 ** 0.5, -1)
                          @ v[:, 128 * h:128 * h + 128] for h in range(4)], 1)
         assert float((outs[0][b].double() - ref).abs().max()) < 3e-2
+
+
+@pytest.mark.parametrize("batch,L", [(4096, 12), (4097, 10), (64, 16), (65, 1), (333, 7)])
+def test_packed_attention_of_short_windows_is_the_direct_kernel_bit_for_bit(batch, L):
+    """attn_bf16_pack2_kernel: two windows of <= 16 tokens per 32 x 32 tile behind a block-diagonal mask (the zero-shot passes of config 5)
+    against one window per tile: equal bits (16-slot alignment keeps every sum's order), odd batch sizes leave half a tile empty."""
+    lib = lab_library()
+    fn = lib.m3pc_debug_attention_bf16
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p] * 2
+    g = torch.Generator(device="cuda").manual_seed(batch + L)
+    qkv = torch.randn(batch, L, 1536, device="cuda", generator=g).to(torch.bfloat16)
+    outs = []
+    for kernel in (0, 1):
+        O = torch.full((batch, L, 512), float("nan"), device="cuda", dtype=torch.bfloat16)
+        rc = fn(qkv.data_ptr(), None, O.data_ptr(), batch, L, 0, kernel, C.c_void_p(torch.cuda.current_stream().cuda_stream), None)
+        assert rc == 0, lib.m3pc_last_error()
+        torch.cuda.synchronize()
+        outs.append(O)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    for b in (0, batch // 2, batch - 1):
+        rows = qkv[b].double()
+        q, k, v = rows[:, :512], rows[:, 512:1024], rows[:, 1024:]
+        ref = torch.cat([torch.softmax(q[:, 128 * h:128 * h + 128] @ k[:, 128 * h:128 * h + 128].T / 128 ** 0.5, -1)
+                         @ v[:, 128 * h:128 * h + 128] for h in range(4)], 1)
+        assert float((outs[0][b].double() - ref).abs().max()) < 3e-2
