@@ -57,6 +57,11 @@ int m3pc_debug_attention_bf16(const void* QKV, const void* QKVs, void* O, int ba
  * the candidates' own [K | V] rows; O (n, nq, 512).  kernel as m3pc_debug_attention_bf16 */
 int m3pc_debug_attention_dec_bf16(const void* Qtab, const void* QKVm, const void* KV, void* O, float* pre, int n, int nq, int Lm, int kernel,
                                   void* stream);
+/* the decoder's bf16 attention of a critic_lambda_guiding candidate pass: Qown (n, Lq <= 4, 512) the candidates' own query rows, Qsh (Lq2, 1536)
+ * the batch-shared query rows [Q | . | .], KV (n, 49, 1024) the candidates' own [K | V] rows, QKVm (79, 1536) the batch-shared rows [. | K | V];
+ * O (n, Lq + Lq2, 512), own rows first.  kernel as m3pc_debug_attention_bf16 */
+int m3pc_debug_attention_mix_bf16(const void* Qown, const void* Qsh, const void* KV, const void* QKVm, void* O, int n, int Lq, int Lq2, int kernel,
+                                  void* stream);
 /* in-kernel phase stamps of workgroup 37 of every fused-tail launch as the step runs: cap > 0 starts a ring of cap entries
  * (64 int64 each), cap == 0 copies it to `out` (host), reports the number of launches logged and stops */
 int m3pc_debug_stamp_log(m3pc_handle* h, int cap, long long* out, int* n_logged);

@@ -868,6 +868,256 @@ __global__ __launch_bounds__(192, 1) void attn_bf16_pipe_dec_kernel(AttnP p, int
     }
 #endif
 }
+// The decoder's attention of a critic_lambda_guiding candidate pass (pruned_decoder with a prefix of un-masked queries): NQ1 queries of
+// the candidate's own + the rest of a 32-query tile shared by the batch, against the candidate's own N1 K|V rows followed by N2 rows
+// shared by the batch (the masked tokens').  The direct kernel gives the NQ1 own queries a 32-query tile of their own and re-reads the
+// shared keys for every (candidate, head): 172 us per C3 half.  Here the own and the shared queries share ONE tile (a query's
+// arithmetic does not depend on its slot), the shared K|V rows are fetched once per workgroup and stay in LDS, and the rest is the
+// pipelined decoder kernel above: a loader wave, two compute waves on two different items.  Key order (own rows, then shared) and every
+// sum's order are the direct kernel's: bit-identical.
+template <int N1, int N2>
+__global__ __launch_bounds__(192, 1) void attn_bf16_pipe_mix_kernel(AttnP p, int n_items) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int HD = 128, NS = 8, HDT = 4;
+    constexpr int Lk = N1 + N2, NKT = (Lk + 31) / 32;
+    constexpr int NPC1 = (N1 + 3) / 4, NPC2 = (N2 + 3) / 4;
+    constexpr int NDMA = 2 * (2 * NPC1 + 1);          // pieces per round: two items' own K and V rows and own query rows
+    constexpr int SIMG = NPC2 * 1024;                 // one shared image (K or V rows of the batch-shared keys)
+    constexpr int OBUF = 2 * APIPE_IMG + 1024;        // one item buffer: V own | K own | Q own (one piece)
+    static_assert(NDMA <= 63 && N1 <= APIPE_NR && NKT <= 4 && N1 >= 32, "shapes");
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // 2 * SIMG + 4 * OBUF bytes
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    char* const Ks = lds;
+    char* const Vs = lds + SIMG;
+    char* const IB = lds + 2 * SIMG;
+    {   // the shared V rows past N2 (the last piece's tail) must be zero: P is exactly zero there
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int i = tid; i < (NPC2 * 4 - N2) * 16; i += 192) *(u32x4*)(Vs + N2 * 256 + i * 16) = z;
+    }
+    const int r4 = lane >> 4, c16 = lane & 15;
+    const int stride = gridDim.x;
+    const int n_mine = ((int)blockIdx.x < n_items) ? (n_items - 1 - (int)blockIdx.x) / stride + 1 : 0;
+    const int n_rounds = (n_mine + 1) / 2;
+    const int head = blockIdx.x & 3;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    if (wid == 2) {
+        // ---------------------------------------------------------------- loader
+        auto voff = [&](int ld, int odd) { return (unsigned)(r4 * ld * 2 + ((c16 ^ (4 * odd + r4)) << 4)); };
+        const unsigned v1[2] = {voff(p.ldkv1, 0), voff(p.ldkv1, 1)}, v2[2] = {voff(p.ldkv2, 0), voff(p.ldkv2, 1)};
+        const unsigned vq = (unsigned)(r4 * p.ldq * 2 + ((c16 ^ r4) << 4));
+        {   // the shared K|V rows, once
+            const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.K2 + head * HD), 0, (unsigned)(N2 * p.ldkv2 * 2), 0x00020000);
+            const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.V2 + head * HD), 0, (unsigned)(N2 * p.ldkv2 * 2), 0x00020000);
+#pragma unroll
+            for (int pc = 0; pc < NPC2; ++pc) {
+                const bool ok = 4 * pc + 3 < N2 ? true : 4 * pc + r4 < N2;
+                if (ok) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lptr_t)(Ks + pc * 1024), 16, v2[pc & 1], pc * 4 * p.ldkv2 * 2, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lptr_t)(Vs + pc * 1024), 16, v2[pc & 1], pc * 4 * p.ldkv2 * 2, 0, 0);
+                }
+            }
+        }
+        auto issue = [&](int r) {
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                int j = 2 * r + w;
+                j = j < n_mine ? j : n_mine - 1;
+                const int it = blockIdx.x + stride * j;
+                char* const B = IB + (2 * w + (r & 1)) * OBUF;
+                const bf16_t* kb = (const bf16_t*)p.K1 + (long long)(it >> 2) * p.kv1_bstride + head * HD;
+                const bf16_t* vb = (const bf16_t*)p.V1 + (long long)(it >> 2) * p.kv1_bstride + head * HD;
+                const bf16_t* qb = (const bf16_t*)p.Q + (long long)(it >> 2) * p.q_bstride + head * HD;
+                const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, (unsigned)(N1 * p.ldkv1 * 2), 0x00020000);
+                const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (unsigned)(N1 * p.ldkv1 * 2), 0x00020000);
+                const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, (unsigned)(p.Lq * p.ldq * 2), 0x00020000);
+#pragma unroll
+                for (int pc = 0; pc < NPC1; ++pc) {
+                    const bool ok = 4 * pc + 3 < N1 ? true : 4 * pc + r4 < N1;
+                    if (ok) {
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lptr_t)(B + APIPE_IMG + pc * 1024), 16, v1[pc & 1], pc * 4 * p.ldkv1 * 2, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lptr_t)(B + pc * 1024), 16, v1[pc & 1], pc * 4 * p.ldkv1 * 2, 0, 0);
+                    }
+                }
+                if (r4 < p.Lq) __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lptr_t)(B + 2 * APIPE_IMG), 16, vq, 0, 0, 0);  // (Lq <= 4: one piece)
+            }
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");  // P: the shared rows are in
+        if (n_rounds > 0) issue(0);
+        if (n_rounds > 1) issue(1);
+        for (int r = 0; r < n_rounds; ++r) {
+            if (r == 0 && n_rounds > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");  // A
+            if (r >= 1 && r + 1 < n_rounds) issue(r + 1);
+            asm volatile("s_barrier" ::: "memory");  // B
+        }
+        return;
+    }
+    // -------------------------------------------------------------------- compute waves
+    // query slots: 0 .. Lq-1 the item's own queries, Lq .. Lq + Lq2 - 1 the shared ones (their fragments: once)
+    const int qi = l31;
+    const int sw = l31 & 7;
+    const int gi = lane & 15;
+    const bool own_q = qi < p.Lq;
+    u32x4 qsh[NS];
+    {
+        const int sq = qi - p.Lq;
+        const bf16_t* qrow = (const bf16_t*)p.Q2 + head * HD + (long long)(sq >= 0 && sq < p.Lq2 ? sq : 0) * p.ldq2 + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) qsh[s] = *(const u32x4*)(qrow + 16 * s);
+    }
+    asm volatile("s_barrier" ::: "memory");  // P
+    const unsigned ks_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)Ks;
+    const unsigned vs_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)Vs;
+    for (int r = 0; r < n_rounds; ++r) {
+        const int j = 2 * r + wid;
+        const bool have = j < n_mine;
+        const int it = blockIdx.x + stride * (have ? j : 0);
+        const char* const B = IB + (2 * wid + (r & 1)) * OBUF;
+        asm volatile("s_barrier" ::: "memory");  // A
+        if (have) {
+            const unsigned vo_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)B;
+            const unsigned ko_base = vo_base + APIPE_IMG;
+            const char* const Qi = B + 2 * APIPE_IMG;
+            u32x4 qf[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const u32x4 own = *(const u32x4*)(Qi + (own_q ? qi : 0) * 256 + (((2 * s + lh) ^ (own_q ? sw : 0)) << 4));
+                qf[s] = own_q ? own : qsh[s];
+            }
+            f32x16 sacc[NKT];
+#pragma unroll
+            for (int t = 0; t < NKT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sacc[t][e] = 0.f;
+            // (attn_bf16_direct_kernel<4, 2, 4>: two key tiles at a time)
+#pragma unroll
+            for (int pr = 0; pr < (NKT + 1) / 2; ++pr)
+#pragma unroll
+                for (int t = 2 * pr; t < 2 * pr + 2 && t < NKT; ++t) {
+                    const int kj = 32 * t + l31;  // key: own row kj, or shared row kj - N1
+                    const unsigned ka = 32 * t + 31 < N1 ? ko_base + kj * 256
+                                        : (32 * t >= N1 ? ks_base + (kj - N1) * 256 : (kj < N1 ? ko_base + kj * 256 : ks_base + (kj - N1) * 256));
+                    const int krow = 32 * t + 31 < N1 ? kj : (32 * t >= N1 ? kj - N1 : (kj < N1 ? kj : kj - N1));
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const u32x4 kf = *(const u32x4 __attribute__((address_space(3)))*)(uintptr_t)(ka + (((2 * s + lh) ^ (krow & 7)) << 4));
+                        sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[s]), sacc[t], 0, 0, 0);
+                    }
+                }
+            float m = -INFINITY;
+#pragma unroll
+            for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int jj = jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const float v = (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 < Lk || jj < Lk) ? sacc[jt][e] * p.scale : -INFINITY;
+                    sacc[jt][e] = v;
+                    m = fmaxf(m, v);
+                }
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float l = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = __builtin_amdgcn_exp2f((sacc[jt][e] - m) * 1.44269504088896340736f);
+                    sacc[jt][e] = v;
+                    l += v;
+                }
+            l += __shfl_xor(l, 32);
+            const float inv = 1.0f / l;
+            f32x16 oacc[HDT];
+#pragma unroll
+            for (int d = 0; d < HDT; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+            s16x4 tv[2][2 * HDT];
+            auto tr_reads = [&](int n, s16x4 (&v)[2 * HDT]) {
+                const int kr = 16 * n + 4 * lh + (gi >> 2);  // key rows kr and kr + 8: own (< N1) or shared
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int k0 = kr + 8 * hf;
+                    const bool own = 16 * n + 15 < N1 ? true : (16 * n >= N1 ? false : k0 < N1);
+                    const int row = own ? k0 : k0 - N1;
+                    const unsigned base = (own ? vo_base : vs_base) + row * 256;
+#pragma unroll
+                    for (int d = 0; d < HDT; ++d) {
+                        const int bo = d * 64 + ((lane >> 4) & 1) * 32 + (gi & 3) * 8;
+                        const unsigned a = base + ((((bo >> 4) ^ (row & 7)) << 4) | (bo & 15));
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v[2 * d + hf]) : "v"(a));
+                    }
+                }
+            };
+            constexpr int NSTEP = 2 * NKT;
+            tr_reads(0, tv[0]);
+#pragma unroll
+            for (int n = 0; n < NSTEP; ++n) {
+                const int jt = n >> 1, s2 = n & 1;
+                bf16x8 pa;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pa[e] = (bf16_t)(sacc[jt][8 * s2 + e] * inv);
+                s16x4(&cur)[2 * HDT] = tv[n & 1];
+                if (n + 1 < NSTEP) {
+                    tr_reads(n + 1, tv[(n + 1) & 1]);
+                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
+                }
+#pragma unroll
+                for (int d = 0; d < HDT; ++d) {
+                    const s16x8 vb = __builtin_shufflevector(cur[2 * d], cur[2 * d + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vb), pa, oacc[d], 0, 0, 0);
+                }
+            }
+            // ---- bf16, through this wave's own K image (its scores are done), whole rows out: output row = query slot
+            {
+                char* const Oi = (char*)(B + APIPE_IMG);
+#pragma unroll
+                for (int d = 0; d < HDT; ++d)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        bf16x4 w;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) w[i] = (bf16_t)oacc[d][4 * q + i];
+                        *(bf16x4*)(Oi + qi * 256 + (((4 * d + q) ^ sw) << 4) + 8 * lh) = w;
+                    }
+            }
+            u32x4 ov[8];
+#pragma unroll
+            for (int pc = 0; pc < 8; ++pc) ov[pc] = *(const u32x4*)(B + APIPE_IMG + (4 * pc + r4) * 256 + c16 * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            {
+                const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)((bf16_t*)p.O + (long long)(it >> 2) * p.o_bstride + head * HD), 0, 0x7fffffffu, 0x00020000);
+#pragma unroll
+                for (int pc = 0; pc < 8; ++pc) {
+                    const int row = 4 * pc + r4;
+                    const unsigned off = row < p.Lq + p.Lq2 ? (unsigned)(row * p.ldo * 2) : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(ov[pc], o_rs, off + ((c16 ^ (row & 7)) << 4), 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B
+    }
+#endif
+}
+template <int N1, int N2>
+static bool launch_pipe_mix(const AttnP& p, hipStream_t st) {
+    const int n_items = p.batch * p.n_head;
+    const int grid = n_items < 256 ? n_items : 256;
+    constexpr int LDSB = 2 * ((N2 + 3) / 4) * 1024 + 4 * (2 * APIPE_IMG + 1024);
+    static_assert(LDSB <= 160 * 1024, "LDS");
+    static const bool attr_ok = hipFuncSetAttribute((const void*)attn_bf16_pipe_mix_kernel<N1, N2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess;
+    if (!attr_ok) return false;
+    hipLaunchKernelGGL((attn_bf16_pipe_mix_kernel<N1, N2>), dim3(grid), dim3(192), LDSB, st, p, n_items);
+    return true;
+}
 template <int N1>
 static bool launch_pipe_dec(const AttnP& p, hipStream_t st) {
     const int n_items = p.batch * p.n_head;
@@ -911,6 +1161,11 @@ static bool try_pipe(const AttnP& p, hipStream_t st) {
     }
     if (((uintptr_t)p.Q | (uintptr_t)p.K1 | (uintptr_t)p.V1 | (uintptr_t)p.O) & 15) return false;
     if ((p.ldq | p.ldkv1 | p.ldo) % 8 || (p.q_bstride | p.kv1_bstride | p.o_bstride) % 8) return false;
+    // the decoder of a critic_lambda_guiding candidate pass: 1..4 own queries + shared ones in one tile, own 49 + shared 79 keys
+    if (p.Q2 && p.K2 && p.V2 && p.Lq >= 1 && p.Lq <= 4 && p.Lq + p.Lq2 <= 32 && p.L1 == 49 && p.L2 == 79 && p.orow1 == 0 && p.orow2 == p.Lq &&
+        !(((uintptr_t)p.Q2 | (uintptr_t)p.K2 | (uintptr_t)p.V2) & 15) && (p.ldq2 | p.ldkv2) % 8 == 0 && (long long)128 * p.ldkv2 * 2 < 0x7fffffffLL &&
+        (long long)64 * p.ldkv1 * 2 < 0x7fffffffLL && (long long)64 * p.ldo * 2 < 0x7fffffffLL)
+        return launch_pipe_mix<49, 79>(p, st);
     if ((long long)64 * p.ldq * 2 >= 0x7fffffffLL || (long long)64 * p.ldkv1 * 2 >= 0x7fffffffLL || (long long)64 * p.ldo * 2 >= 0x7fffffffLL) return false;
     if (!p.Q2 && !p.K2 && p.Lq == 49 && p.L1 == 49 && p.L2 == 0 && p.orow1 >= 0) {
         return launch_pipe<49, 0>(p, st);

@@ -3061,6 +3061,41 @@ int m3pc_debug_attention_dec_bf16(const void* Qtab, const void* QKVm, const void
     return check_launch("debug_attention_dec_bf16");
 }
 
+int m3pc_debug_attention_mix_bf16(const void* Qown, const void* Qsh, const void* KV, const void* QKVm, void* O, int n, int Lq, int Lq2, int kernel,
+                                  void* stream) {
+    const int d = 512, Le = 49, Lm = 79;
+    AttnP at;
+    memset(&at, 0, sizeof(at));
+    at.Q = Qown;
+    at.q_bstride = (long long)Lq * d;
+    at.ldq = d;
+    at.Lq = Lq;
+    at.orow1 = 0;
+    at.Q2 = Qsh;
+    at.ldq2 = 3 * d;
+    at.Lq2 = Lq2;
+    at.orow2 = Lq;
+    at.K1 = KV;
+    at.V1 = (const char*)KV + (size_t)d * 2;
+    at.kv1_bstride = (long long)Le * 2 * d;
+    at.ldkv1 = 2 * d;
+    at.L1 = Le;
+    at.K2 = (const char*)QKVm + (size_t)d * 2;
+    at.V2 = (const char*)QKVm + (size_t)2 * d * 2;
+    at.ldkv2 = 3 * d;
+    at.L2 = Lm;
+    at.O = O;
+    at.o_bstride = (long long)(Lq + Lq2) * d;
+    at.ldo = d;
+    at.batch = n;
+    at.n_head = 4;
+    at.hd = 128;
+    at.scale = 1.0f / sqrtf(128.0f);
+    at.no_pipe = kernel;
+    launch_attention(at, DT_BF16, (hipStream_t)stream);
+    return check_launch("debug_attention_mix_bf16");
+}
+
 int m3pc_debug_kv_fused(const void* Z, int n, int Le, int kept0, int off0, int kept1, int off1, const void* We0, const void* We1,
                         const void* Wkv, void* stream_buf, const float* rowtab0, const float* rowtab1, const float* ln_g,
                         const float* ln_b, const float* bkv, void* KV, void* stream, long long* stamps) {

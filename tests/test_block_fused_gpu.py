@@ -381,3 +381,35 @@ def test_packed_attention_of_short_windows_is_the_direct_kernel_bit_for_bit(batc
         ref = torch.cat([torch.softmax(q[:, 128 * h:128 * h + 128] @ k[:, 128 * h:128 * h + 128].T / 128 ** 0.5, -1)
                          @ v[:, 128 * h:128 * h + 128] for h in range(4)], 1)
         assert float((outs[0][b].double() - ref).abs().max()) < 3e-2
+
+
+@pytest.mark.parametrize("n,Lq,Lq2", [(2048, 1, 31), (300, 1, 31), (257, 2, 30), (512, 1, 20)])
+def test_pipelined_mixed_query_attention_is_the_direct_kernel_bit_for_bit(n, Lq, Lq2):
+    """attn_bf16_pipe_mix_kernel (critic mode's decoder: own + shared queries in one tile, the 79 batch-shared K|V rows resident in LDS,
+    own rows by LDS-DMA) against attn_bf16_direct_kernel<4, 2, 4>: equal bits, and both against a float64 softmax."""
+    lib = lab_library()
+    fn = lib.m3pc_debug_attention_mix_bf16
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]
+    g = torch.Generator(device="cuda").manual_seed(n + Lq2)
+    qown = torch.randn(n, Lq, 512, device="cuda", generator=g).to(torch.bfloat16)
+    qsh = torch.randn(Lq2, 1536, device="cuda", generator=g).to(torch.bfloat16)
+    kv = torch.randn(n, 49, 1024, device="cuda", generator=g).to(torch.bfloat16)
+    qkvm = torch.randn(79, 1536, device="cuda", generator=g).to(torch.bfloat16)
+    outs = []
+    for kernel in (0, 1):
+        O = torch.full((n, Lq + Lq2, 512), float("nan"), device="cuda", dtype=torch.bfloat16)
+        rc = fn(qown.data_ptr(), qsh.data_ptr(), kv.data_ptr(), qkvm.data_ptr(), O.data_ptr(), n, Lq, Lq2, kernel,
+                C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, lib.m3pc_last_error()
+        torch.cuda.synchronize()
+        outs.append(O)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    for b in (0, n // 2, n - 1):
+        q = torch.cat([qown[b], qsh[:, :512]], 0).double()
+        k = torch.cat([kv[b, :, :512], qkvm[:, 512:1024]], 0).double()
+        v = torch.cat([kv[b, :, 512:], qkvm[:, 1024:]], 0).double()
+        ref = torch.cat([torch.softmax(q[:, 128 * h:128 * h + 128] @ k[:, 128 * h:128 * h + 128].T / 128 ** 0.5, -1)
+                         @ v[:, 128 * h:128 * h + 128] for h in range(4)], 1)
+        assert float((outs[0][b].double() - ref).abs().max()) < 3e-2
