@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define M3PC_ABI_VERSION 4
+#define M3PC_ABI_VERSION 5
 
 #define M3PC_OK 0
 #define M3PC_EINVAL (-1)   /* bad argument / shape mismatch            */
@@ -321,6 +321,34 @@ int m3pc_topk_window(m3pc_handle* h, const float* expect_return, int n_total, in
 int m3pc_rescore_merge(m3pc_handle* h, const float* scores, int n_total, const int* index, int n, const float* top_scores,
                        const float* top_rescored, float delta, float* merged, float* stats, float* host_stats, float seq,
                        void* stream);
+/* The SAMPLED action of a plan step (learner.py:324-325: sample_action = a0[torch.multinomial(p, 1)], the action every online
+ * rollout step executes, replay_buffer.py:206-216) must not depend on bf16 rounding either.  torch.multinomial(p, 1) is
+ * arg-max_j p_j / q_j with q ~ Exp(1) (m3pc_select), and with p = softmax(temperature (E - max E)) that is the race
+ * arg-max_j (temperature E_j - log q_j).  An un-re-scored candidate's key is off by at most temperature * delta, so only
+ * candidates whose bf16 key comes within 2 temperature delta of the best can win: ABI v5 lists them, re-scores them beside the
+ * best-by-score candidates and certifies the draw as m3pc_rescore_merge certifies the arg-max.
+ *
+ * m3pc_topk_race_window: m3pc_topk_window (window = 0) plus the rmax best candidates by race key, both in ONE list of
+ * rmax + kmax + 1 entries laid out for contiguous slices:
+ *   list[rmax + i]      the i-th best candidate by score (i <= kmax), best first
+ *   list[rmax - 1 - i]  the i-th best candidate by race key temperature * E_j - log expo_j (i < rmax)
+ * so "the r best racers and the n best scorers" is list[rmax - r .. rmax + n): one m3pc_rescore call, one merge.
+ *   expo         device (n_total,) the Exp(1) variates m3pc_select will draw with
+ *   list_scores  device out (rmax + kmax + 1,), optional: expect_return[list[i]]
+ *   stats / host_stats / seq as m3pc_topk_window (of the score part).  rmax <= min(64, n_total). */
+int m3pc_topk_race_window(m3pc_handle* h, const float* expect_return, const float* expo, float temperature, int n_total, int kmax,
+                          int kmin, int rmax, int* list, float* stats, float* list_scores, float* host_stats, float seq, void* stream);
+/* m3pc_rescore_merge over such a list: `list` = r race entries followed by n score entries (a slice of the list above),
+ * list_scores / list_rescored their bf16 scores and fp32 re-scores.  The shift c, the deviation, merged[] and the arg-max
+ * certificate (need) are m3pc_rescore_merge's over all r + n entries.  Race certificate: K* = max over the listed entries of
+ * (temperature * rescored_i - log expo_i); need_race = #{j : temperature * scores[j] - log expo[j] >= K* + temperature (c - delta)}
+ * over the whole vector: need_race <= r certifies that the draw arg-max_j merged-p_j / expo_j is the fp32 draw; otherwise re-score
+ * the race entries r .. need_race-1 and merge again.
+ *   stats device out float[8] = {c, deviation, need, margin, -, need_race, K*, K* + temperature (c - delta)}; the host copy
+ *   carries `seq` in slot 4 (host_stats must hold 8 floats).  r + n <= 1024. */
+int m3pc_rescore_merge_race(m3pc_handle* h, const float* scores, const float* expo, float temperature, int n_total, const int* list,
+                            int r, int n, const float* list_scores, const float* list_rescored, float delta, float* merged,
+                            float* stats, float* host_stats, float seq, void* stream);
 /* m3pc_rescore of the n listed candidates (device int32 ids), written back into the full score vector in place. */
 int m3pc_rescore_listed(m3pc_handle* h, const m3pc_plan_args* args, const float* states, const float* actions,
                         const float* rewards, const float* eps, const int* index, int n, float* expect_return,

@@ -21,7 +21,7 @@ KEYS = ("states", "actions", "rewards", "returns")
 MODE_RTG, MODE_CRITIC, MODE_NOISE = 0, 1, 2
 PREC_FP32, PREC_BF16 = 0, 1
 PROF_LAYER_TAIL = 16  # m3pc_profile_read: the fused layer-tail launches only
-ABI_VERSION = 4
+ABI_VERSION = 5
 GOAL_PIID, GOAL_ID = 0, 1  # m3pc_goal_step_batch goal_mode
 SLOTS = 4  # M3PC_SLOTS: plan steps in flight per handle
 
@@ -31,7 +31,7 @@ EXPORTS = (
     "m3pc_goal_step_batch",
     "m3pc_policy_pass", "m3pc_candidate_pass", "m3pc_candidate_join", "m3pc_policy_pass_batch",
     "m3pc_plan_step", "m3pc_plan_step_batch", "m3pc_score_actions", "m3pc_rescore", "m3pc_rescore_topk", "m3pc_topk_window",
-    "m3pc_rescore_listed", "m3pc_rescore_merge", "m3pc_select",
+    "m3pc_rescore_listed", "m3pc_rescore_merge", "m3pc_topk_race_window", "m3pc_rescore_merge_race", "m3pc_select",
     "m3pc_profile_enable",
     "m3pc_profile_read",
 )
@@ -101,6 +101,8 @@ def load_library(path: Optional[str] = None):
         "m3pc_rescore_topk": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, i, vp, vp],
         "m3pc_topk_window": [vp, vp, i, i, i, f, vp, vp, vp, vp, f, vp],
         "m3pc_rescore_merge": [vp, vp, i, vp, i, vp, vp, f, vp, vp, vp, f, vp],
+        "m3pc_topk_race_window": [vp, vp, vp, f, i, i, i, i, vp, vp, vp, vp, f, vp],
+        "m3pc_rescore_merge_race": [vp, vp, vp, f, i, vp, i, i, vp, vp, f, vp, vp, vp, f, vp],
         "m3pc_rescore_listed": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, i, vp, vp],
         "m3pc_select": [vp, vp, vp, ll, i, f, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_profile_enable": [vp, i],
@@ -160,8 +162,10 @@ class HostStats:
         return self.np[4] == seq
 
     def read(self):
+        """[0..3] the four statistics every kernel writes; [4..6] = slots 5..7 of the buffer (m3pc_rescore_merge_race: need_race,
+        the best listed race key, its threshold; zero for the kernels that write four)."""
         hs = self.np
-        return [float(hs[0]), float(hs[1]), float(hs[2]), float(hs[3])]
+        return [float(hs[0]), float(hs[1]), float(hs[2]), float(hs[3]), float(hs[5]), float(hs[6]), float(hs[7])]
 
     def wait(self, seq: float, fallback: Optional[torch.Tensor] = None, timeout: float = 10.0):
         import time as _t
@@ -175,7 +179,8 @@ class HostStats:
                     # the device copy of the statistics is written on another stream than the current one: order behind
                     # everything on the device before reading it (this path is taken when the mapped buffer misbehaved)
                     torch.cuda.synchronize(fallback.device)
-                    return [float(x) for x in fallback.cpu()]
+                    fb = [float(x) for x in fallback.cpu()]
+                    return fb[:4] + (fb[5:8] if len(fb) >= 8 else [0.0, 0.0, 0.0])
                 raise M3pcError("timed out waiting for kernel statistics in host-mapped memory")
         return self.read()
 
@@ -539,6 +544,41 @@ class Handle:
                                           _ptr(top_rescored), float(delta), _ptr(merged), _ptr(stats),
                                           None if host_stats is None else C.c_void_p(host_stats.data_ptr()), float(seq),
                                           _stream(self.device)))
+        return merged, stats
+
+    def topk_race_window(self, expect_return: torch.Tensor, expo: torch.Tensor, temperature: float, kmax: int, kmin: int, rmax: int,
+                         lst: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None,
+                         list_scores: Optional[torch.Tensor] = None):
+        """``topk_window`` plus the rmax best candidates by race key temperature * E - log expo (the multinomial draw's race),
+        in one list: lst[rmax + i] = i-th best by score (i <= kmax), lst[rmax - 1 - i] = i-th best racer.  Returns (lst, stats)."""
+        n = expect_return.numel()
+        assert expect_return.is_contiguous() and expect_return.dtype == torch.float32
+        assert expo.is_contiguous() and expo.dtype == torch.float32 and expo.numel() == n
+        if lst is None:
+            lst = torch.empty((rmax + kmax + 1,), dtype=torch.int32, device=self.device)
+        if stats is None:
+            stats = torch.empty((4,), dtype=torch.float32, device=self.device)
+        assert lst.numel() >= rmax + min(kmax + 1, n)
+        check(self.lib.m3pc_topk_race_window(self._h, _ptr(expect_return), _ptr(expo), float(temperature), n, int(kmax), int(kmin),
+                                             int(rmax), _ptr(lst), _ptr(stats), _ptr(list_scores), None, 0.0, _stream(self.device)))
+        return lst, stats
+
+    def rescore_merge_race(self, scores: torch.Tensor, expo: torch.Tensor, temperature: float, lst: torch.Tensor, r: int, n: int,
+                           list_scores: torch.Tensor, list_rescored: torch.Tensor, delta: float = 0.0,
+                           merged: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, host_stats=None, seq: float = 0.0):
+        """``rescore_merge`` over r race entries followed by n score entries (lst / list_scores / list_rescored start at the first
+        race entry); stats (8 floats) = [shift, deviation, need, margin, -, need_race, best listed race key, its threshold]."""
+        assert scores.is_contiguous() and scores.dtype == torch.float32 and lst.dtype == torch.int32
+        assert lst.numel() >= r + n and list_scores.numel() >= r + n and list_rescored.numel() >= r + n
+        if merged is None:
+            merged = torch.empty_like(scores)
+        if stats is None:
+            stats = torch.empty((8,), dtype=torch.float32, device=self.device)
+        assert stats.numel() >= 8
+        check(self.lib.m3pc_rescore_merge_race(self._h, _ptr(scores), _ptr(expo), float(temperature), scores.numel(), _ptr(lst), int(r),
+                                               int(n), _ptr(list_scores), _ptr(list_rescored), float(delta), _ptr(merged), _ptr(stats),
+                                               None if host_stats is None else C.c_void_p(host_stats.data_ptr()), float(seq),
+                                               _stream(self.device)))
         return merged, stats
 
     def select_buffers(self, n: int):

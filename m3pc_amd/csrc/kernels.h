@@ -379,13 +379,18 @@ void launch_select(const SelectP& p, hipStream_t st);
 // indices of the k largest values (descending; ties -> lower index first), n <= 16384, k <= n
 void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st);
 // re-score window statistics: idx = the kk best entries of v (best first); stats = {n, margin to the best entry outside the n,
-// max, raw count over all n_total entries}; top_scores (optional, kk) = v[idx[i]]
+// max, raw count over all n_total entries}; top_scores (optional) = v[idx[i]] for i in [-rr, kk): rr race entries sit in front of idx
 void launch_window_stats(const float* v, int n_total, const int* idx, int kk, int kmin, int kmax, float window, float* stats,
-                         float* host_stats, float seq, float* top_scores, hipStream_t st);
-// out = b - median(b_top - f_top), listed entries replaced by their fp32 re-scores;
-// stats = {shift, max deviation, #{b > best listed fp32 + shift - delta}, margin of that threshold over the best un-listed b}
-void launch_rescore_merge(const float* b, int n_total, const int* idx, int n, const float* b_top, const float* f_top, float delta,
-                          float* out, float* stats, float* host_stats, float seq, hipStream_t st);
+                         float* host_stats, float seq, float* top_scores, hipStream_t st, int rr = 0);
+// list[rmax + i] = the i-th best entry of v (i < kk); list[rmax - 1 - i] = the i-th best by race key tau v - log expo (i < rr)
+void launch_topk_race(const float* v, const float* expo, float tau, int n, int kk, int rr, int rmax, int* list, hipStream_t st);
+// list = r race entries then n score entries (the n best of b, best first), list_scores = b[list[i]], f = their fp32 re-scores:
+// out = b - median(list_scores - f), listed entries replaced by f;  stats (8 floats) = {shift, max deviation,
+// need = #{b > best f + shift - delta}, margin of that threshold over the best un-listed b, -, need_race (expo given: the number
+// of candidates whose race key can still reach the best listed fp32 race key), that key, its threshold on the bf16 key scale}
+void launch_rescore_merge(const float* b, int n_total, const int* list, int r, int n, const float* list_scores, const float* f,
+                          float delta, const float* expo, float tau, float* out, float* stats, float* host_stats, float seq,
+                          hipStream_t st);
 // dst[index[i]] = src[i]
 void launch_scatter(const float* src, const int* index, int n, float* dst, int* index_copy, hipStream_t st);  // + index_copy[i] = index[i]
 

@@ -2740,6 +2740,21 @@ int m3pc_topk_window(m3pc_handle* h, const float* expect_return, int n_total, in
     return check_launch("topk_window");
 }
 
+int m3pc_topk_race_window(m3pc_handle* h, const float* expect_return, const float* expo, float temperature, int n_total, int kmax,
+                          int kmin, int rmax, int* list, float* stats, float* list_scores, float* host_stats, float seq, void* stream) {
+    if (!h || !expect_return || !expo || !list || !stats) return fail(M3PC_EINVAL, "null argument");
+    if (n_total < 1 || n_total > 16384) return fail(M3PC_EINVAL, "top-k supports n_total <= 16384");
+    if (kmax < 1 || kmax > 1023 || kmin < 1 || kmin > kmax) return fail(M3PC_EINVAL, "bad kmin/kmax");
+    if (rmax < 1 || rmax > 64 || rmax > n_total) return fail(M3PC_EINVAL, "rmax %d outside [1, min(64, n_total)]", rmax);
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->device));
+    const int kk = kmax + 1 < n_total ? kmax + 1 : n_total;
+    launch_topk_race(expect_return, expo, temperature, n_total, kk, rmax, rmax, list, st);
+    launch_window_stats(expect_return, n_total, list + rmax, kk, kmin, kmax, 0.f, stats, host_stats, seq,
+                        list_scores ? list_scores + rmax : nullptr, st, rmax);
+    return check_launch("topk_race_window");
+}
+
 int m3pc_rescore_merge(m3pc_handle* h, const float* scores, int n_total, const int* index, int n, const float* top_scores,
                        const float* top_rescored, float delta, float* merged, float* stats, float* host_stats, float seq,
                        void* stream) {
@@ -2747,9 +2762,22 @@ int m3pc_rescore_merge(m3pc_handle* h, const float* scores, int n_total, const i
     if (n_total < 1 || n < 1 || n > 1024 || n > n_total) return fail(M3PC_EINVAL, "n %d outside [1, min(1024, n_total)]", n);
     if (!(delta >= 0.f)) return fail(M3PC_EINVAL, "delta must be >= 0");
     HIPCHK(hipSetDevice(h->device));
-    launch_rescore_merge(scores, n_total, index, n, top_scores, top_rescored, delta, merged, stats, host_stats, seq,
+    launch_rescore_merge(scores, n_total, index, 0, n, top_scores, top_rescored, delta, nullptr, 0.f, merged, stats, host_stats, seq,
                          (hipStream_t)stream);
     return check_launch("rescore_merge");
+}
+
+int m3pc_rescore_merge_race(m3pc_handle* h, const float* scores, const float* expo, float temperature, int n_total, const int* list,
+                            int r, int n, const float* list_scores, const float* list_rescored, float delta, float* merged,
+                            float* stats, float* host_stats, float seq, void* stream) {
+    if (!h || !scores || !expo || !list || !list_scores || !list_rescored || !merged || !stats) return fail(M3PC_EINVAL, "null argument");
+    if (n_total < 1 || n < 1 || r < 0 || r + n > 1024 || n > n_total || r > n_total)
+        return fail(M3PC_EINVAL, "r %d + n %d outside [1, 1024] / n_total %d", r, n, n_total);
+    if (!(delta >= 0.f)) return fail(M3PC_EINVAL, "delta must be >= 0");
+    HIPCHK(hipSetDevice(h->device));
+    launch_rescore_merge(scores, n_total, list, r, n, list_scores, list_rescored, delta, expo, temperature, merged, stats, host_stats,
+                         seq, (hipStream_t)stream);
+    return check_launch("rescore_merge_race");
 }
 
 int m3pc_rescore_listed(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* actions, const float* rewards,

@@ -99,6 +99,23 @@ __device__ __forceinline__ unsigned int orderable(float f) {
     if (u == 0x80000000u) u = 0u;  // -0.0 orders as +0.0 (a tie, decided by the index), as in a float compare
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+// The multinomial draw of learner.py:324-325 as a race: torch.multinomial(p, 1) = argmax_j p_j / q_j, q ~ Exp(1), and with
+// p = softmax(tau (E - max E)) that is argmax_j (tau E_j - log q_j).  race_key is that key for one candidate; the certified
+// re-score compares keys built from bf16 scores with keys built from fp32 re-scores (m3pc_topk_race_window / _merge_race).
+__device__ __forceinline__ float race_key(float tau, float e, float q) { return __fsub_rn(__fmul_rn(tau, e), logf(q)); }
+
+// What a top-k ranks and where the winners go: value[e] = v[e], or race_key(tau, v[e], expo[e]) when expo is given; the
+// element of rank r (descending; ties to the lower index) is written to out[r * out_stride].
+struct TopSrc {
+    const float* v;
+    const float* expo;
+    float tau;
+    int k;
+    int* out;
+    int out_stride;
+};
+__device__ __forceinline__ float src_value(const TopSrc& s, int e) { return s.expo ? race_key(s.tau, s.v[e], s.expo[e]) : s.v[e]; }
+
 __global__ __launch_bounds__(1024) void topk_kernel(const float* v, int n, int npow2, int k, int* idx_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
     const int tid = threadIdx.x;
@@ -126,15 +143,16 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* v, int n, int n
 // values with k rounds of (register-local arg-max, 64-lane butterfly) -- no barrier --, then wave 0 does the same over
 // the 16 k survivors.  Same order as the bitonic kernel (descending value, ties to the lower index); ~3x faster
 // at n = 1024 and independent of n up to 16384 (the replicated top-k of an 8-GPU run sorts 8192 scores).
-__global__ __launch_bounds__(1024) void topk_select_kernel(const float* v, int n, int k, int* idx_out) {
+__global__ __launch_bounds__(1024) void topk_select_kernel(TopSrc src, int n) {
     __shared__ float cv[16 * 64];
     __shared__ int ci[16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int k = src.k;
     float val[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         const int e = s * 1024 + tid;
-        val[s] = e < n ? v[e] : -INFINITY;
+        val[s] = e < n ? src_value(src, e) : -INFINITY;
     }
     for (int r = 0; r < k; ++r) {
         ArgMax a{-INFINITY, 0x7fffffff};
@@ -166,7 +184,7 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float* v, int n
         for (int j = 0; j < 16; ++j) a = better(a, ArgMax{mv[j], mi[j]});
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) a = better(a, ArgMax{__shfl_xor(a.v, o), __shfl_xor(a.i, o)});
-        if (lane == 0) idx_out[r] = a.i;
+        if (lane == 0) src.out[r * src.out_stride] = a.i;
 #pragma unroll
         for (int j = 0; j < 16; ++j)
             if (mi[j] == a.i) mv[j] = -INFINITY;
@@ -203,6 +221,33 @@ __global__ __launch_bounds__(256) void topk_rank_blocks_kernel(const float* v, i
     if (q == 0 && e < n) {
         rank = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
         if (rank < k) idx_out[rank] = e;
+    }
+}
+
+// Two rankings in one launch (n <= 2048): blockIdx.y picks the source -- the scores themselves / the race keys.
+__global__ __launch_bounds__(256) void topk_rank_blocks2_kernel(TopSrc s0, TopSrc s1, int n) {
+    __shared__ __attribute__((aligned(16))) unsigned long long keys[2048];
+    __shared__ int part[4][64];
+    const TopSrc s = blockIdx.y ? s1 : s0;
+    const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+    for (int e = tid; e < 2048; e += 256) keys[e] = e < n ? ((unsigned long long)orderable(src_value(s, e)) << 32) | (unsigned int)(~e) : 0ull;
+    __syncthreads();
+    const int e = blockIdx.x * 64 + lane;
+    const unsigned long long mine = e < n ? keys[e] : 0ull;
+    const int n4 = (((n + 3) / 4) + 1) & ~1;
+    int rank = 0;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const int j0 = q * n4, j1 = j0 + n4 < 2048 ? j0 + n4 : 2048;
+#pragma unroll 8
+    for (int j = j0; j < j1; j += 2) {
+        const u64x2 kj = *(const u64x2*)&keys[j];
+        rank += (kj.x > mine) + (kj.y > mine);
+    }
+    part[q][lane] = rank;
+    __syncthreads();
+    if (q == 0 && e < n) {
+        rank = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+        if (rank < s.k) s.out[rank * s.out_stride] = e;
     }
 }
 
@@ -247,7 +292,7 @@ void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st) {
         return;
     }
     if (k <= 64 && n <= 16384) {
-        hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(1024), 0, st, v, n, k, idx_out);
+        hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(1024), 0, st, TopSrc{v, nullptr, 0.f, k, idx_out, 1}, n);
         return;
     }
     int np = 2;
@@ -260,6 +305,21 @@ void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st) {
     hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), (size_t)np * 8, st, v, n, np, k, idx_out);
 }
 
+// The two candidate lists of the certified re-score in one buffer (m3pc_topk_race_window): list[rmax + i] = the i-th best
+// entry of v (i <= kk - 1), list[rmax - 1 - i] = the i-th best entry by race key (i < rr): the r best racers and the n best
+// scorers are the contiguous slice [rmax - r, rmax + n).
+void launch_topk_race(const float* v, const float* expo, float tau, int n, int kk, int rr, int rmax, int* list, hipStream_t st) {
+    if (n <= 0 || kk <= 0) return;
+    const TopSrc s0{v, nullptr, 0.f, kk, list + rmax, 1};
+    const TopSrc s1{v, expo, tau, rr, list + rmax - 1, -1};
+    if (n <= 2048) {
+        hipLaunchKernelGGL(topk_rank_blocks2_kernel, dim3((n + 63) / 64, rr > 0 ? 2 : 1), dim3(256), 0, st, s0, s1, n);
+        return;
+    }
+    launch_topk(v, n, kk, list + rmax, st);
+    if (rr > 0) hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(1024), 0, st, s1, n);  // (rr <= 64, n <= 16384)
+}
+
 // idx: the kk best entries of v, best first.  n = clamp(#{i < kk: v[idx[i]] >= v[idx[0]] - window}, kmin, kmax) and the
 // distance from the best entry to the best one NOT among those n (infinity when there is none).
 // Window statistics of the bound-driven re-score: idx = the kk best entries of v (best first).  The raw count of entries
@@ -267,7 +327,7 @@ void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st) {
 // kmax entries it may list (stats[3] > kmax: the listed prefix no longer covers the window).
 __global__ __launch_bounds__(256) void window_stats_kernel(const float* v, int n_total, const int* idx, int kk, int kmin, int kmax,
                                                            float window, float* stats, float* host_stats, float seq,
-                                                           float* top_scores) {
+                                                           float* top_scores, int rr) {
     __shared__ int part[4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float mx = v[idx[0]];
@@ -277,7 +337,7 @@ __global__ __launch_bounds__(256) void window_stats_kernel(const float* v, int n
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
     if (lane == 0) part[wid] = cnt;
     if (top_scores)
-        for (int i = tid; i < kk; i += 256) top_scores[i] = v[idx[i]];
+        for (int i = tid - rr; i < kk; i += 256) top_scores[i] = v[idx[i]];  // (entries -rr .. -1: the race list in front of idx)
     __syncthreads();
     cnt = part[0] + part[1] + part[2] + part[3];
     int n = cnt < kmin ? kmin : cnt;
@@ -300,109 +360,128 @@ __global__ __launch_bounds__(256) void window_stats_kernel(const float* v, int n
     }
 }
 void launch_window_stats(const float* v, int n_total, const int* idx, int kk, int kmin, int kmax, float window, float* stats,
-                         float* host_stats, float seq, float* top_scores, hipStream_t st) {
+                         float* host_stats, float seq, float* top_scores, hipStream_t st, int rr) {
     hipLaunchKernelGGL(window_stats_kernel, dim3(1), dim3(256), 0, st, v, n_total, idx, kk, kmin, kmax, window, stats, host_stats, seq,
-                       top_scores);
+                       top_scores, rr);
 }
 
-// Merge of a bf16 score vector with the fp32 re-scores of its n best entries (planner: certified re-score).
-//   d_i = b_top[i] - f_top[i] over the n listed entries;  c = lower median(d): the common shift of the bf16 scores;
-//   out[j] = b[j] - c for every j, then out[idx[i]] = f_top[i].
-// Certificate: with |(b_j - f_j) - c| <= delta for every candidate, an un-listed j can only beat the best listed fp32 score
-// f* if b_j - c > f* - delta.  need = #{j : b[j] > f* + c - delta} over the WHOLE vector (the listed entries are the n
-// largest b, so this set is a prefix of the descending order): need <= n certifies that the arg-max of `out` is the fp32
-// arg-max; otherwise the entries n .. need-1 of the order still have to be re-scored.
-//   stats = {c, max_i |d_i - c|, need, (f* + c - delta) - (largest un-listed b) [inf when everything is listed]}
-__global__ __launch_bounds__(1024) void rescore_merge_kernel(const float* b, int n_total, const int* idx, int n, const float* b_top,
-                                                             const float* f_top, float delta, float* out, float* stats,
-                                                             float* host_stats, float seq) {
+// Merge of a bf16 score vector with the fp32 re-scores of the listed candidates (planner: certified re-score).  The list holds
+// r race entries (the r best by race key, any order) followed by n score entries (the n best by bf16 score, best first); m = r + n.
+//   d_i = b[list[i]] - f[i] over the m listed entries;  c = lower median(d): the common shift of the bf16 scores;
+//   out[j] = b[j] - c for every j, then out[list[i]] = f[i] (score entries first, race entries behind them: deterministic when a
+//   candidate sits in both parts).
+// Arg-max certificate: with |(b_j - f_j) - c| <= delta for every candidate, an un-listed j can only beat the best listed fp32 score
+// f* if b_j - c > f* - delta.  need = #{j : b[j] > f* + c - delta} over the WHOLE vector (the score entries are the n largest b, so
+// this set is a prefix of the descending order): need <= n certifies that the arg-max of `out` is the fp32 arg-max; otherwise the
+// entries n .. need-1 of the order still have to be re-scored.
+// Race certificate (expo given): K* = max over the listed entries of race_key(tau, f_i, q_i) is a key the multinomial's winner at
+// least reaches; an un-listed j can only win if tau (b_j - c + delta) - log q_j >= K*, i.e. race_key(tau, b_j, q_j) >= K* +
+// tau (c - delta).  need_race = the number of such j over the WHOLE vector -- a prefix of the descending race-key order -- so
+// need_race <= r certifies that arg-max_j p_j / q_j over `out` is the fp32 draw; otherwise the race entries r .. need_race-1
+// still have to be re-scored.
+//   stats = {c, max_i |d_i - c|, need, (f* + c - delta) - (largest un-listed b) [inf when everything is listed], -, need_race,
+//            K*, K* + tau (c - delta)}   (slot 4 of the host copy carries the sequence number)
+__global__ __launch_bounds__(1024) void rescore_merge_kernel(const float* b, int n_total, const int* list, int r, int n,
+                                                             const float* list_scores, const float* f, float delta, const float* expo,
+                                                             float tau, float* out, float* stats, float* host_stats, float seq,
+                                                             int nstats) {
     __shared__ float d[1024];
     __shared__ int ids[1024];
     __shared__ float c_sh;
-    __shared__ float sv[16], sf[16], sb[16];
-    __shared__ int sc[16];
+    __shared__ float sv[16], sf[16], sb[16], sk[16];
+    __shared__ int sc[16], sr[16];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid < n) {
-        d[tid] = b_top[tid] - f_top[tid];
-        ids[tid] = idx[tid];
+    const int m = r + n;
+    float kf = -INFINITY;
+    if (tid < m) {
+        d[tid] = list_scores[tid] - f[tid];
+        ids[tid] = list[tid];
+        if (expo) kf = race_key(tau, f[tid], expo[ids[tid]]);
     }
     __syncthreads();
-    if (tid < n) {
+    if (tid < m) {
         const float me = d[tid];
         int rank = 0;
-        for (int j = 0; j < n; ++j) {
+        for (int j = 0; j < m; ++j) {
             const float o = d[j];
             rank += (o < me || (o == me && j < tid)) ? 1 : 0;
         }
-        if (rank == (n - 1) / 2) c_sh = me;
+        if (rank == (m - 1) / 2) c_sh = me;
     }
     __syncthreads();
     const float c = c_sh;
-    float dev = tid < n ? fabsf(d[tid] - c) : 0.f;
-    float fb = tid < n ? f_top[tid] : -INFINITY;
+    float dev = tid < m ? fabsf(d[tid] - c) : 0.f;
+    float fb = tid < m ? f[tid] : -INFINITY;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         dev = fmaxf(dev, __shfl_xor(dev, o));
         fb = fmaxf(fb, __shfl_xor(fb, o));
+        kf = fmaxf(kf, __shfl_xor(kf, o));
     }
     if (lane == 0) {
         sv[wid] = dev;
         sf[wid] = fb;
+        sk[wid] = kf;
     }
     __syncthreads();
-    float fbest = sf[0], devmax = sv[0];
+    float fbest = sf[0], devmax = sv[0], kbest = sk[0];
     for (int w = 1; w < 16; ++w) {
         fbest = fmaxf(fbest, sf[w]);
         devmax = fmaxf(devmax, sv[w]);
+        kbest = fmaxf(kbest, sk[w]);
     }
-    const float thr = fbest + c - delta;  // on the bf16 scale
-    int cnt = 0;
-    float bout = -INFINITY;  // largest b among the un-listed: everything below the n-th largest b (the list is a prefix)
-    const float b_last = b_top[n - 1];
+    const float thr = fbest + c - delta;            // on the bf16 scale
+    const float thr_r = kbest + tau * (c - delta);  // on the bf16 race-key scale
+    int cnt = 0, cnt_r = 0;
+    float bout = -INFINITY;  // largest b among the un-listed: everything below the n-th largest b (the score entries are a prefix)
+    const float b_last = list_scores[m - 1];
     for (int j = tid; j < n_total; j += 1024) {
         const float v = b[j];
         out[j] = v - c;
         cnt += v > thr ? 1 : 0;
         if (v < b_last) bout = fmaxf(bout, v);
+        if (expo) cnt_r += race_key(tau, v, expo[j]) >= thr_r ? 1 : 0;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         cnt += __shfl_xor(cnt, o);
+        cnt_r += __shfl_xor(cnt_r, o);
         bout = fmaxf(bout, __shfl_xor(bout, o));
     }
     if (lane == 0) {
         sc[wid] = cnt;
+        sr[wid] = cnt_r;
         sb[wid] = bout;
     }
     __syncthreads();
-    if (tid < n) out[ids[tid]] = f_top[tid];
+    if (tid >= r && tid < m) out[ids[tid]] = f[tid];
+    __syncthreads();
+    if (tid < r) out[ids[tid]] = f[tid];
     if (tid == 0) {
-        int need = 0;
+        int need = 0, need_r = 0;
         float bo = -INFINITY;
         for (int w = 0; w < 16; ++w) {
             need += sc[w];
+            need_r += sr[w];
             bo = fmaxf(bo, sb[w]);
         }
         // (ties with the n-th listed score count as listed above: a tie at the list's edge keeps `need` honest through cnt)
         const float margin = n >= n_total ? INFINITY : thr - bo;
-        stats[0] = c;
-        stats[1] = devmax;
-        stats[2] = (float)need;
-        stats[3] = margin;
+        const float st8[8] = {c, devmax, (float)need, margin, 0.f, (float)need_r, kbest, thr_r};
+        for (int i = 0; i < nstats; ++i) stats[i] = st8[i];
         if (host_stats) {
-            host_stats[0] = c;
-            host_stats[1] = devmax;
-            host_stats[2] = (float)need;
-            host_stats[3] = margin;
+            for (int i = 0; i < nstats; ++i)
+                if (i != 4) host_stats[i] = st8[i];
             __threadfence_system();
             __hip_atomic_store(host_stats + 4, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
-void launch_rescore_merge(const float* b, int n_total, const int* idx, int n, const float* b_top, const float* f_top, float delta,
-                          float* out, float* stats, float* host_stats, float seq, hipStream_t st) {
-    hipLaunchKernelGGL(rescore_merge_kernel, dim3(1), dim3(1024), 0, st, b, n_total, idx, n, b_top, f_top, delta, out, stats,
-                       host_stats, seq);
+void launch_rescore_merge(const float* b, int n_total, const int* list, int r, int n, const float* list_scores, const float* f,
+                          float delta, const float* expo, float tau, float* out, float* stats, float* host_stats, float seq,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(rescore_merge_kernel, dim3(1), dim3(1024), 0, st, b, n_total, list, r, n, list_scores, f, delta, expo, tau, out,
+                       stats, host_stats, seq, expo ? 8 : 4);
 }
 
 __global__ void scatter_kernel(const float* src, const int* index, int n, float* dst, int* index_copy) {

@@ -33,6 +33,7 @@ import numpy as np
 import torch
 
 from . import capi, dist as mdist
+from .certificate import RACE_MAX, _TicketOps, _WindowOps, resolve as _resolve_certificate
 from .tokenizers import ContinuousTokenizer, DataStatistics, SquashedNormal, TokenizerManager
 
 KEYS = capi.KEYS
@@ -55,7 +56,7 @@ class _Slot:
         self.i = i
         self.owner = None
         self.device = device
-        self.b_top = self.f_top = self.stats = self.mstats = None
+        self.b_top = self.f_top = self.b_lst = self.f_lst = self.stats = self.mstats = None
         self.hs_win = self.hs_mrg = None
         self.win = self.win_np = self.win_dev = self.eps_buf = self.expo_buf = None
         self.ev_in = self.ev_pol = self.ev_cand = self.ev_done = self.ev_h2d = None
@@ -63,10 +64,13 @@ class _Slot:
     def ready(self, planner):
         if self.b_top is None:
             dev = self.device
-            self.b_top = torch.empty((1024,), dtype=torch.float32, device=dev)  # their bf16 scores
-            self.f_top = torch.empty((1024,), dtype=torch.float32, device=dev)  # their fp32 re-scores
+            # the re-score lists of the step (m3pc_topk_race_window): R race entries in front of the score entries
+            R = planner._R
+            self.b_lst = torch.empty((R + 1024,), dtype=torch.float32, device=dev)  # their bf16 scores
+            self.f_lst = torch.empty((R + 1024,), dtype=torch.float32, device=dev)  # their fp32 re-scores
+            self.b_top, self.f_top = self.b_lst[R:], self.f_lst[R:]
             self.stats = torch.empty((4,), dtype=torch.float32, device=dev)
-            self.mstats = torch.empty((4,), dtype=torch.float32, device=dev)
+            self.mstats = torch.empty((8,), dtype=torch.float32, device=dev)
             self.hs_win, self.hs_mrg = capi.HostStats(), capi.HostStats()
             self.win = torch.zeros((planner.T * (planner.S + planner.A + 1),), dtype=torch.float32).pin_memory()
             self.win_np = self.win.numpy()
@@ -83,95 +87,6 @@ class _Slot:
         return self
 
 
-class _TicketOps:
-    """The device work of ``HipPlanner._resolve_certificate`` for one plan step in flight (its re-scores run through the
-    step's slot, on the step's tail stream).  A plain object per resolution -- NOT a class defined per call: a class object
-    sits in reference cycles, and a cycle that reaches the ticket keeps the step's device tensors alive until the cyclic
-    collector runs; the caching allocator then has to hipMalloc fresh blocks (a device synchronisation each) and the step
-    pipeline falls apart (measured: 780 -> 400 plan-steps/s in most runs)."""
-    __slots__ = ("planner", "tk", "top")
-
-    def __init__(self, planner, tk):
-        self.planner, self.tk, self.top = planner, tk, None
-
-    def read(self):
-        sl = self.tk.slot
-        return sl.hs_mrg.wait(self.tk.seq_mrg, sl.mstats)
-
-    def extend(self, lo, hi):
-        pl, tk = self.planner, self.tk
-        sl, N = tk.slot, tk.er_b.numel()
-        with pl._on(tk):
-            rs, tail = pl._rescore_args(tk)
-            pl.handle.rescore(*rs, tk.top[lo:hi], *tail, N, slot=sl.i, out=sl.f_top[lo:hi], want_actions=False)
-        tk.n_done = hi
-
-    def window_set(self, need, delta):
-        pl, tk = self.planner, self.tk
-        tk.delta = delta
-        with pl._on(tk):
-            self.top = pl._rescore_window_set(tk, need)
-        return tk.n_done
-
-    def merge_select(self, n, delta):
-        pl, tk = self.planner, self.tk
-        tk.delta = delta
-        with pl._on(tk):
-            pl._merge(tk, n)
-            tk.sel = pl.handle.select(tk.er, tk.a0, float(pl.cfg.temperature), tk.expo, out=tk.outbuf)
-            if tk.tchain is not None:
-                tk.slot.ev_done.record(tk.tchain)
-
-
-class _WindowOps:
-    """The device work of ``HipPlanner._resolve_certificate`` for window w of a lock-step group (fp32 re-scores through
-    m3pc_score_actions on the window's own rows).  ``c``: the group's state (a plain namespace; see _TicketOps on why this is
-    not a class defined inside the call)."""
-    __slots__ = ("c", "w", "pending")
-
-    def __init__(self, c, w):
-        self.c, self.w, self.pending = c, w, None
-
-    def read(self):
-        c, w = self.c, self.w
-        if self.pending is not None:
-            c.stats_h[w], self.pending = self.pending.cpu(), None
-        return [float(v) for v in c.stats_h[w]]
-
-    def _score(self, ix):
-        c, w = self.c, self.w
-        return torch.cat([c.hdl.score_actions(c.smode, c.s[w], c.a[w], c.r[w], c.acts[w, ix[c0 : c0 + c.cap].long()], None, c.h,
-                                              c.lmbda, c.disc) for c0 in range(0, ix.numel(), c.cap)])
-
-    def extend(self, lo, hi):
-        c, w = self.c, self.w
-        c.ftops[w] = torch.cat([c.ftops[w][:lo], self._score(c.tops[w][lo:hi])]).contiguous()
-
-    def window_set(self, need, dlt):
-        c, w = self.c, self.w
-        cnt = min(need, c.N)
-        if cnt <= 1024:  # the `need` best candidates by bf16 score, re-scored in chunks of the chain workspace
-            vals, idx = torch.topk(c.er[w], cnt)
-            c.tops[w], c.btops[w] = idx.to(torch.int32).contiguous(), vals.contiguous()
-            c.ftops[w] = self._score(c.tops[w]).contiguous()
-            self.merge_select(cnt, dlt)
-            return cnt
-        # beyond what the merge kernel lists: EVERY candidate of the window in fp32 -- the select then runs on fp32 scores
-        # alone (a merge of the best entry with itself keeps the statistics protocol alive)
-        er32 = c.hdl.score_actions(c.smode, c.s[w], c.a[w], c.r[w], c.acts[w], None, c.h, c.lmbda, c.disc).contiguous()
-        best = torch.argmax(er32).to(torch.int32).reshape(1)
-        bval = er32.max().reshape(1).contiguous()
-        c.tops[w], c.btops[w], c.ftops[w] = best, bval, bval
-        c.merged[w], self.pending = c.hdl.rescore_merge(er32, best, 1, bval, bval, delta=0.0)
-        c.sels[w] = c.hdl.select(c.merged[w], c.acts[w, :, 0], c.temp, c.expos[w])
-        return c.N
-
-    def merge_select(self, n, dlt):
-        c, w = self.c, self.w
-        c.merged[w], self.pending = c.hdl.rescore_merge(c.er[w], c.tops[w], n, c.btops[w], c.ftops[w], delta=dlt)
-        c.sels[w] = c.hdl.select(c.merged[w], c.acts[w, :, 0], c.temp, c.expos[w])
-
-
 class PlanTicket:
     """One plan step in flight (``HipPlanner.plan_async``).  ``result()`` -> what ``action_sample`` returns for the window:
     the eval action (A,) when the step was issued with eval=True, else the sampled action (1, A); ``pair()`` -> both;
@@ -184,8 +99,9 @@ class PlanTicket:
         self.eps = self.expo = self.res = self.er_b = self.er = self.a0 = self.sel = self.top = None
         self.tail_enqueued = False
         self.deferred = False
-        self.kmin = self.kmax = self.n_done = self.index = 0
-        self.grow_in, self.kfirst_in = 0.0, 0
+        self.kmin = self.kmax = self.n_done = self.r_done = self.index = 0
+        self.grow_in, self.kfirst_in, self.rfirst_in = 0.0, 0, 0
+        self.lst, self.R, self.wset = None, 0, None
         self.seq_mrg = 0.0
         self.delta = None
         self.seq_win = 0.0
@@ -213,7 +129,7 @@ class HipPlanner:
                  group=None, generator: Optional[torch.Generator] = None, max_batch: int = 1,
                  rescore: str = "bound", rescore_min: int = 8, rescore_max: int = 128, rescore_delta: Optional[float] = None,
                  max_windows: int = 1, pipeline_depth: int = 2, chain_priority: int = -1, tail_stream: bool = True,
-                 defer_join: bool = True, goal_batch: int = 0):
+                 defer_join: bool = True, goal_batch: int = 0, race_min: int = 2, calibration_windows: int = 3):
         """cfg: any object with traj_length, action_samples, horizon, discount, temperature, lmbda,
         plan_guidance (finetune.py RunConfig fields read at learner.py:276,319,342).
         tokenizer_manager: a TokenizerManager (this package's) or {key: {"mean","std","min","max"}}.
@@ -248,9 +164,10 @@ class HipPlanner:
         _, n_local = mdist.shard_range(N, 0, self.world)
         hidden = 0 if q_state_dict is None else q_state_dict["q1.net.0.weight"].shape[0]
         nw = max(int(max_windows), 1)
-        # chain workspace: the fp32 re-score sets (all windows of a lock-step batch together), the calibration subset
-        self._n_cal = min(256, N)  # (r4 sweep: with 64 the bound was exceeded by some candidate in 9 % of 320 trials)
-        max_rescore = max(int(rescore_max) * nw, int(rescore_topk), self._n_cal, 1) if precision == "bf16" else 1
+        # chain workspace: the fp32 re-score sets (all windows of a lock-step batch together): a first pass is at most rescore_max
+        # score entries + RACE_MAX race entries
+        self._R = max(min(RACE_MAX, N), 1)  # race entries a step lists (m3pc_topk_race_window)
+        max_rescore = max((int(rescore_max) + self._R) * nw, int(rescore_topk), 1) if precision == "bf16" else 1
         self._max_batch = max(int(max_batch), nw, 1)
         self.handle = capi.Handle(S, A, T, n_embd, n_head, n_enc_layer, n_dec_layer,
                                   max_candidates=max(n_local * nw, 1), max_batch=self._max_batch,
@@ -263,12 +180,16 @@ class HipPlanner:
         assert rescore in ("bound", "topk")
         self.rescore = rescore if self.precision == capi.PREC_BF16 else "none"
         self.rescore_min, self.rescore_max = int(rescore_min), int(rescore_max)
+        self.race_min = max(1, int(race_min))  # race entries of a first pass (the winner of the bf16 race + one runner-up)
         self._delta_fixed = None if rescore_delta is None else float(rescore_delta)
         # Adaptive state of the certified re-score.  It must not depend on how many steps are in flight (a pipelined run has
         # to reproduce the serial one bit for bit), so it is LAGGED: step t uses what the steps up to t - capi.SLOTS saw --
         # exactly the steps that are certain to be resolved when step t is issued (its slot's previous owner is step
         # t - SLOTS) -- whatever has been resolved since.  _delta0: the calibrated bound; _hist[t] = (deviation, need) of step t.
         self._delta0: Optional[float] = self._delta_fixed
+        self._cal_windows = max(1, int(calibration_windows))
+        self._cal_left = self._cal_windows  # full-pass calibrations still to run behind the last weight load
+        self.calibration_factor = 1.5
         self._hist: Dict[int, tuple] = {}
         self._step_index = 0
         self.generator = generator
@@ -300,7 +221,6 @@ class HipPlanner:
         self.action_list = []       # zero-shot "piid_allout" (action_piid_list_sample)
         self._force_collective = False  # test hook: run the all-gather even in a world of one
         self._bf16_offset = 0.0     # test hook: a constant added to the bf16 scores before the re-score
-        self._predrawn = None       # (mode, h, eps, expo) drawn by action_sample ahead of the window copy
         self._stage, self._stage_i = None, 0  # two pinned window staging buffers (+ the event of the copy that read each last)
         self._ev_main = None        # recorded behind the last use of the chain workspaces on the CALLER's stream (_mark_main)
 
@@ -312,6 +232,7 @@ class HipPlanner:
             self._finish(tk)  # steps in flight were issued against the old weights: resolve them first
         self.handle.load_weights(state_dict)
         self._delta0 = getattr(self, "_delta_fixed", None)  # the bf16 error bound belongs to the weights: re-calibrate
+        self._cal_left = getattr(self, "_cal_windows", 3)
         self._hist = {}
         self.delta_grown = 0
 
@@ -323,25 +244,28 @@ class HipPlanner:
             return None
         if self._delta_fixed is not None:
             return self._delta0
-        return max([self._delta0] + [1.5 * d for d, _ in self._hist.values()])
+        return max([self._delta0] + [1.5 * v[0] for v in self._hist.values()])
 
     @_delta.setter
     def _delta(self, value):
         self._delta0 = value
         self._hist = {}
+        self._cal_left = 0  # (an explicit bound stands: no further calibration passes until the next weight load)
 
     def _adapt(self, index: int):
-        """(growth of delta, size of the first re-score pass) for step `index`, from the steps up to index - SLOTS."""
+        """(growth of delta, size of the first re-score pass by score, by race key) for step `index`, from the steps up to
+        index - SLOTS."""
         seen = [(i, v) for i, v in self._hist.items() if i <= index - capi.SLOTS]
-        grow = max([1.5 * d for _, (d, _) in seen], default=0.0) if self._delta_fixed is None else 0.0
+        grow = max([1.5 * v[0] for _, v in seen], default=0.0) if self._delta_fixed is None else 0.0
         # first pass: what the 80th percentile of the recent steps' certificates asked for, in fours (a second pass costs a
         # whole fp32 chain, ~0.3 ms; four more candidates in the first ~0.02-0.05 ms)
-        recent = sorted(n for _, (_, n) in sorted(seen)[-16:])
-        kfirst = self.rescore_min
+        recent = sorted(seen)[-16:]
+        kfirst, rfirst = self.rescore_min, self.race_min
         if recent:
-            q = recent[min(len(recent) - 1, int(0.8 * len(recent)))]
+            q = sorted(v[1] for _, v in recent)[min(len(recent) - 1, int(0.8 * len(recent)))]
             kfirst = max(self.rescore_min, -(-q // 4) * 4)
-        return grow, kfirst
+            rfirst = max(self.race_min, sorted(v[2] for _, v in recent)[min(len(recent) - 1, int(0.8 * len(recent)))])
+        return grow, kfirst, min(rfirst, self._R)
 
     def load_critic(self, q_state_dict, obs_mean, obs_std):
         self.handle.set_critic(q_state_dict, obs_mean, obs_std)
@@ -470,7 +394,7 @@ class HipPlanner:
         tk = PlanTicket(self, sl, mode, states, actions, rewards, float(rtg), int(h), float(lmbda), returns)
         sl.owner = tk
         tk.index, self._step_index = self._step_index, self._step_index + 1
-        tk.grow_in, tk.kfirst_in = self._adapt(tk.index)
+        tk.grow_in, tk.kfirst_in, tk.rfirst_in = self._adapt(tk.index)
         main = torch.cuda.current_stream(self.device)
         chain = self._chain_stream() if pipelined else None
         tk.chain = chain
@@ -481,7 +405,9 @@ class HipPlanner:
         tk.outbuf = hd.select_buffers(N)
         if self.rescore != "none":
             tk.er = torch.empty((N,), dtype=torch.float32, device=self.device)
-            tk.top = torch.empty((1024,), dtype=torch.int32, device=self.device)
+            tk.R = self._R
+            tk.lst = torch.empty((tk.R + 1024,), dtype=torch.int32, device=self.device)  # race entries | score entries
+            tk.top = tk.lst[tk.R :]
         with (torch.cuda.stream(chain) if chain is not None else contextlib.nullcontext()):
             if chain is not None and not inputs_ready:
                 sl.ev_in.record(main)
@@ -489,10 +415,6 @@ class HipPlanner:
             # the variates of the step in the serial order of draws: eps, then the multinomial's exponentials.  (Pipelined:
             # drawn on the chain stream -- the generator's state advances on the host in issue order either way -- so that
             # nothing but the candidate pass sits on the current stream.)
-            expo = None
-            if eps is None and self._predrawn is not None and self._predrawn[:2] == (mode, h):
-                eps, expo = self._predrawn[2:]  # action_sample drew them before the window's H2D copy (same order of draws)
-            self._predrawn = None
             if chain is not None:
                 chain.wait_event(sl.ev_done)  # (see _Slot.ready: the slot's buffers are free once its previous owner is done)
                 if self._ev_main is not None:
@@ -502,9 +424,7 @@ class HipPlanner:
             if eps is None:
                 eps = self._draw_eps(mode, h, sl.eps_buf if chain is not None else None)
             tk.eps = eps = eps.reshape(N, -1, A)
-            if expo is None:
-                expo = sl.expo_buf.exponential_(1, generator=self.generator) if chain is not None else self._draw_expo()
-            tk.expo = expo
+            tk.expo = sl.expo_buf.exponential_(1, generator=self.generator) if chain is not None else self._draw_expo()
             if chain is not None:
                 sl.ev_pol.record(chain)
         if chain is not None:
@@ -556,8 +476,10 @@ class HipPlanner:
             else:
                 rs, tail = self._rescore_args(tk)
                 if self.rescore == "bound":
-                    if self._delta0 is None:
-                        self._delta0 = self._calibrate(tk)
+                    if self._delta_fixed is None and self._cal_left > 0:
+                        self._cal_left -= 1
+                        d = self._calibrate(tk)
+                        self._delta0 = d if self._delta0 is None else max(self._delta0, d)
                     kmax = max(min(self.rescore_max, N - 1 if N > 1 else 1), 1)
                     kmin = max(min(max(self.rescore_min, tk.kfirst_in), N, kmax), 1)
                     tk.delta = max(self._delta0, tk.grow_in)
@@ -565,25 +487,43 @@ class HipPlanner:
                     kmax = kmin = max(min(self.rescore_topk, N, hd.max_rescore), 1)
                     tk.delta = 0.0
                 tk.kmin, tk.kmax = kmin, kmax
-                # The kmax + 1 best candidates by bf16 score, best first.  The set that has to be re-scored is a prefix of this
-                # list whose length only the re-score itself can tell (m3pc_rescore_merge's certificate), so its first kmin
-                # entries are re-scored, merged and the select is enqueued BEFORE anybody reads anything: the device never
-                # waits for the host.  _finish reads the certificate (host-mapped statistics, no stream synchronisation) and
-                # only when it asks for more the rest is re-scored and merge + select are repeated on the same variates.
-                hd.topk_window(tk.er_b, kmax, kmin, 0.0, top=tk.top, stats=sl.stats, top_scores=sl.b_top)
-                hd.rescore(*rs, tk.top[:kmin], *tail, N, slot=sl.i, out=sl.f_top[:kmin], want_actions=False)
-                tk.n_done = kmin
-                self._merge(tk, kmin)
+                # The kmax + 1 best candidates by bf16 score, best first, and (bound mode) the R best by race key.  The sets that
+                # have to be re-scored are prefixes of these lists whose lengths only the re-score itself can tell
+                # (m3pc_rescore_merge_race's certificates), so the first kmin / rfirst entries are re-scored, merged and the
+                # select is enqueued BEFORE anybody reads anything: the device never waits for the host.  _finish reads the
+                # certificates (host-mapped statistics, no stream synchronisation) and only when they ask for more the rest is
+                # re-scored and merge + select are repeated on the same variates.
+                R = tk.R
+                if self.rescore == "bound":
+                    rfirst = max(min(tk.rfirst_in, R), 1)
+                    hd.topk_race_window(tk.er_b, tk.expo, float(cfg.temperature), kmax, kmin, R, lst=tk.lst, stats=sl.stats,
+                                        list_scores=sl.b_lst)
+                else:
+                    rfirst = 0
+                    hd.topk_window(tk.er_b, kmax, kmin, 0.0, top=tk.top, stats=sl.stats, top_scores=sl.b_top)
+                hd.rescore(*rs, tk.lst[R - rfirst : R + kmin], *tail, N, slot=sl.i, out=sl.f_lst[R - rfirst : R + kmin],
+                           want_actions=False)
+                tk.n_done, tk.r_done = kmin, rfirst
+                self._merge(tk, kmin, rfirst)
             tk.sel = hd.select(tk.er, tk.a0, float(cfg.temperature), tk.expo, out=tk.outbuf)
             if tk.tchain is not None:
                 sl.ev_done.record(tk.tchain)
 
-    def _merge(self, tk, n, index=None, b_top=None, f_top=None):
+    def _merge(self, tk, n, r=0):
+        """Merge + certificates over the r race entries and n score entries re-scored so far (score entries: the step's list
+        buffer, or the window-set path's own tensors ``tk.wset`` behind the buffer's race entries)."""
         sl = tk.slot
         tk.seq_mrg = sl.hs_mrg.next_seq()
-        self.handle.rescore_merge(tk.er_b, tk.top if index is None else index, n, sl.b_top if b_top is None else b_top,
-                                  sl.f_top if f_top is None else f_top, delta=tk.delta, merged=tk.er, stats=sl.mstats,
-                                  host_stats=sl.hs_mrg.buf, seq=tk.seq_mrg)
+        o = tk.R - r
+        lists = (tk.lst[o:], sl.b_lst[o:], sl.f_lst[o:])
+        if tk.wset is not None:
+            tk.keep = lists = tuple(torch.cat([a[:r], b]).contiguous() for a, b in zip(lists, tk.wset))
+        if self.rescore == "bound":
+            self.handle.rescore_merge_race(tk.er_b, tk.expo, float(self.cfg.temperature), lists[0], r, n, lists[1], lists[2],
+                                           delta=tk.delta, merged=tk.er, stats=sl.mstats, host_stats=sl.hs_mrg.buf, seq=tk.seq_mrg)
+        else:
+            self.handle.rescore_merge(tk.er_b, lists[0], n, lists[1], lists[2], delta=tk.delta, merged=tk.er, stats=sl.mstats,
+                                      host_stats=sl.hs_mrg.buf, seq=tk.seq_mrg)
 
     def _finish(self, tk):
         """Resolve a ticket: enqueue what is still missing, read the re-score's certificate, finish the re-score if it asks
@@ -600,13 +540,15 @@ class HipPlanner:
         if self.rescore == "bound":
             N = tk.er_b.numel()
             ops = _TicketOps(self, tk)
-            extra = self._resolve_certificate(N, tk.kmax, tk.n_done, tk.delta, ops)
+            extra = _resolve_certificate(self, N, tk.kmax, tk.R, tk.n_done, tk.r_done, tk.delta, ops)
             tk.delta = extra["delta"]
-            extra["n_first"] = tk.kmin
+            extra["n_first"], extra["n_race_first"] = tk.kmin, min(max(tk.rfirst_in, 1), tk.R)
             top = ops.top if ops.top is not None else tk.top[: extra["n_rescored"]]
             extra["n_rescored"] = int(top.numel())
-            # what this step saw feeds the steps from SLOTS later on (_adapt): the bound, and the size of the first pass
-            self._hist[tk.index] = (float(extra["deviation"]), min(int(extra["n_in_window"]), tk.kmax))
+            extra["race"] = tk.lst[tk.R - extra["n_race"] : tk.R].flip(0)  # the re-scored racers, best bf16 race key first
+            # what this step saw feeds the steps from SLOTS later on (_adapt): the bound, and the sizes of the first pass
+            self._hist[tk.index] = (float(extra["deviation"]), min(int(extra["n_in_window"]), tk.kmax),
+                                    min(int(extra["need_race"]), tk.R))
             for i in [i for i in self._hist if i < tk.index - 64]:
                 # (old enough that every step still to come would count it anyway: fold its deviation into the base bound)
                 if self._delta_fixed is None:
@@ -629,62 +571,16 @@ class HipPlanner:
             sl.owner = None
         return tk.out
 
-    def _resolve_certificate(self, N, kmax, n_done, delta, ops):
-        """The certified re-score's protocol (HipPlanner.__init__: rescore="bound"), in ONE place for the pipelined ticket
-        (``_finish``) and the lock-step batch (``_action_sample_lockstep``).  A first pass has been enqueued already: the
-        ``n_done`` best candidates by bf16 score re-scored in fp32, merged, selected.  ``ops`` does the device work:
-            read()                 -> (shift, deviation, need, margin) of the LAST merge (blocks the host until they are there)
-            extend(lo, hi)         fp32 re-score of the entries [lo, hi) of the sorted candidate list
-            window_set(need)       -> (n_done, needs_merge): the list is too short -- re-score the `need` best candidates
-                                   (or, beyond 1024, every candidate) and leave the merged vector + select enqueued
-            merge_select(n, delta) merge + select again over the n re-scored entries
-        Loop: read the certificate; raise delta when this step's re-scored set deviates by more than it allows (then merge
-        again: `need` depends on delta); re-score up to `need` when the certificate asks for more; stop when it is satisfied,
-        when everything has been re-scored, or after the window-set slow path.  Returns the step's record."""
-        saturated, first_need = False, None
-        while True:
-            shift, dev, need, margin = ops.read()
-            need = int(need)
-            if first_need is None:
-                first_need = need
-            redo = False
-            # delta bounds the deviation of (bf16 - fp32) from the common shift: every step checks it on its re-scored set
-            # and raises it when 1.5 x what it saw is more (the same numbers, hence the same decision, on every rank and at
-            # any pipeline depth)
-            if self._delta_fixed is None and 1.5 * dev > delta:
-                delta = 1.5 * dev
-                self.delta_grown += 1
-                redo = n_done < N and not saturated
-            if saturated or n_done >= N:
-                break
-            if need > n_done and not redo:
-                if need <= kmax:
-                    ops.extend(n_done, need)
-                    n_done = need
-                    redo = True
-                else:
-                    if not self._warned_saturated:
-                        self._warned_saturated = True
-                        warnings.warn(f"m3pc_amd: {need} candidates may still hold the fp32 arg-max (delta={delta:.3g}, rescore_max="
-                                      f"{self.rescore_max}); re-scoring the whole window set in fp32 (slow path)")
-                    n_done = ops.window_set(need, delta)
-                    saturated = True
-                    continue
-            if not redo:
-                break
-            ops.merge_select(n_done, delta)
-        return dict(n_rescored=n_done, n_in_window=first_need, min_margin_outside=float(margin), delta=delta, saturated=saturated,
-                    shift=shift, deviation=dev)
-
-    def _rescore_window_set(self, tk, need):
-        """The certificate asks for more candidates than the rescore_max the list holds: re-score the whole set -- the `need`
-        best candidates by bf16 score -- in chunks of the chain workspace (or, beyond 1024 of them, every candidate in fp32).
-        Slow path, taken only when the bf16 noise exceeds the score spread.  Called inside the tail's stream context."""
+    def _rescore_window_set(self, tk, need, everything=False):
+        """A certificate asks for more candidates than the step's lists hold: re-score the whole set -- the `need` best
+        candidates by bf16 score -- in chunks of the chain workspace (or, beyond the merge kernel's capacity or when the race
+        list is exhausted, every candidate in fp32).  Slow path, taken only when the bf16 noise exceeds the score spread.
+        Called inside the tail's stream context."""
         cfg, hd, sl = self.cfg, self.handle, tk.slot
         N = tk.er_b.numel()
         rs, tail = self._rescore_args(tk)
         cnt = min(need, N)
-        if cnt <= 1024:
+        if cnt <= 1024 - RACE_MAX and not everything:
             vals, idx = torch.topk(tk.er_b, cnt)
             idx = idx.to(torch.int32).contiguous()
             f = torch.empty((cnt,), dtype=torch.float32, device=self.device)
@@ -692,8 +588,8 @@ class HipPlanner:
             for c0 in range(0, cnt, cap):
                 c1 = min(cnt, c0 + cap)
                 hd.rescore(*rs, idx[c0:c1], *tail, N, slot=sl.i, out=f[c0:c1], want_actions=False)
-            self._merge(tk, cnt, index=idx, b_top=vals.contiguous(), f_top=f)
-            tk.keep = (vals, idx, f)
+            tk.wset = (idx, vals.contiguous(), f)  # (stands in for the score entries; the race entries stay and may still grow)
+            self._merge(tk, cnt, tk.r_done)
             tk.top[:cnt].copy_(idx)
             idx = tk.top[:cnt]
             tk.n_done = cnt
@@ -712,6 +608,7 @@ class HipPlanner:
             tk.keep = (er32, best, bval)
             self.handle.rescore_merge(er32.contiguous(), best, 1, bval, bval, delta=0.0, merged=tk.er, stats=sl.mstats,
                                       host_stats=sl.hs_mrg.buf, seq=self._next_mrg_seq(tk))
+            torch.cuda.synchronize(self.device)  # (the candidate workspace is free again before any later step's pass)
         tk.sel = hd.select(tk.er, tk.a0, float(cfg.temperature), tk.expo, out=tk.outbuf)
         if tk.tchain is not None:
             sl.ev_done.record(tk.tchain)
@@ -722,16 +619,24 @@ class HipPlanner:
         return tk.seq_mrg
 
     def _calibrate(self, tk) -> float:
-        """delta of the bound-driven re-score: fp32 scores of n_cal candidates (a fixed pseudo-random subset, the same
-        on every rank) against their bf16 scores; 1.5 x the largest deviation of (bf16 - fp32) from its median."""
+        """delta of the certified re-score from ONE FULL fp32 candidate pass over this step's candidates (the same on every
+        rank): 1.5 x the largest deviation of (bf16 - fp32) from its median over all N.  Run on each of the first
+        ``calibration_windows`` steps behind a weight load (the bound is their maximum) -- per-weight-load setup like the
+        weight re-pack, ~10 ms each at N = 1024: the device is synchronised around the pass, which runs in the candidate
+        workspace.  (Round 4 calibrated on 256 candidates of one window: a sample maximum of 256 under-estimates the maximum
+        over N x every later window, and some candidate exceeded the bound in 1.75 % of 1200 steps.)"""
+        cfg, hd = self.cfg, self.handle
         N = tk.er_b.numel()
-        rs, tail = self._rescore_args(tk)
-        g = torch.Generator().manual_seed(0x5eed)
-        ids = torch.randperm(N, generator=g)[: min(self._n_cal, N, self.handle.max_rescore)].to(torch.int32).to(self.device)
-        f32, _ = self.handle.rescore(*rs, ids, *tail, N, slot=tk.slot.i, want_actions=False)
-        d = tk.er_b[ids.long()] - f32
+        torch.cuda.synchronize(self.device)
+        begin, count = mdist.shard_range(N, self.rank, self.world)
+        r32 = hd.candidate_pass(tk.mode, tk.states, tk.actions, tk.rewards, tk.eps, tk.h, tk.lmbda, float(cfg.discount), N,
+                                begin, count, precision=capi.PREC_FP32, slot=tk.slot.i)
+        f32, _ = mdist.gather_candidates(r32["expect_return"], r32["sample_actions"][:, 0], N, self.group)
+        d = tk.er_b - f32
         dev = float((d - d.median()).abs().max())
-        return max(1.5 * dev, 1e-6 * float(f32.abs().max()), 1e-30)
+        out = max(self.calibration_factor * dev, 1e-6 * float(f32.abs().max()), 1e-30)
+        torch.cuda.synchronize(self.device)
+        return out
 
     def _split(self, trajectory):
         """(states, actions, rewards, rtg, returns_row) of a reference-style trajectory dict of (1,T,D) tensors.  A window
@@ -1070,56 +975,68 @@ class HipPlanner:
             er, acts = res["expect_return"], res["sample_actions"]
             stats_h = None
             merged = [er[w] for w in range(Eg)]
-            if self.rescore != "none":
-                smode = capi.MODE_RTG if mode == capi.MODE_RTG else capi.MODE_CRITIC
-                if self.rescore == "bound":
-                    if self._delta is None:  # calibrate on window 0 of the group: n_cal of its candidates in fp32
-                        g = torch.Generator().manual_seed(0x5eed)
-                        cid = torch.randperm(N, generator=g)[: self._n_cal].to(self.device)
-                        f32 = self.handle.score_actions(smode, s[0], a[0], r[0], acts[0, cid], None, h, lmbda, float(cfg.discount))
-                        d = er[0, cid] - f32
-                        self._delta = max(1.5 * float((d - d.median()).abs().max()), 1e-6 * float(f32.abs().max()), 1e-30)
-                    # The certified re-score of HipPlanner.__init__'s docstring, for all windows of the group at once: the kmin best
-                    # candidates of every window in ONE fp32 pass, merge + select enqueued for every window, THEN one host read
-                    # of the certificates; windows that ask for more candidates get a second pass of their own.
-                    kmax = max(min(self.rescore_max, N - 1 if N > 1 else 1), 1)
-                    kmin = max(min(self.rescore_min, N, kmax), 1)
-                    tops, btops = [], []
-                    for w in range(Eg):
-                        bt = torch.empty((kmax + 1,), dtype=torch.float32, device=self.device)
-                        tops.append(self.handle.topk_window(er[w], kmax, kmin, 0.0, top_scores=bt)[0])
-                        btops.append(bt)
-                    counts = [kmin] * Eg
-                else:
-                    k = min(self.rescore_topk, N)
-                    tops = [torch.topk(er[w], k).indices.to(torch.int32) for w in range(Eg)]
-                    btops = [er[w][tops[w].long()].contiguous() for w in range(Eg)]
-                    counts = [k] * Eg
-                delta = float(self._delta) if self.rescore == "bound" else 0.0
-                pick = torch.cat([tops[w][: counts[w]].long() for w in range(Eg)])
-                wsel = torch.arange(Eg, dtype=torch.int32, device=self.device).repeat_interleave(counts[0])
-                f32 = self.handle.score_actions(smode, s, a, r, acts[wsel.long(), pick], wsel, h, lmbda, float(cfg.discount))
-                ftops, mstats = [], []
-                for w in range(Eg):  # fp32 scores for the set, shift-corrected bf16 scores for the rest (m3pc_rescore_merge)
-                    ftops.append(f32[w * counts[w] : (w + 1) * counts[w]].contiguous())
-                    merged[w], st_w = self.handle.rescore_merge(er[w], tops[w], counts[w], btops[w], ftops[w], delta=delta)
-                    mstats.append(st_w)
+            # the multinomial's exponentials of every window (the same order of draws as before the race lists needed them early)
             expos = [torch.empty((N,), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
                      for _ in range(Eg)]
-            sels = [self.handle.select(merged[j], acts[j, :, 0], float(cfg.temperature), expos[j]) for j in range(Eg)]
+            temp = float(cfg.temperature)
+            bound = self.rescore == "bound"
+            if self.rescore != "none":
+                smode = capi.MODE_RTG if mode == capi.MODE_RTG else capi.MODE_CRITIC
+                R = self._R if bound else 0
+                if bound:
+                    if self._delta is None:  # calibrate on window 0 of the group: all of its candidates in fp32
+                        f32 = self.handle.score_actions(smode, s[0], a[0], r[0], acts[0], None, h, lmbda, float(cfg.discount))
+                        d = er[0] - f32
+                        self._delta = max(self.calibration_factor * float((d - d.median()).abs().max()), 1e-6 * float(f32.abs().max()),
+                                          1e-30)
+                    # The certified re-score of certificate.py, for all windows of the group at once: the kmin best candidates
+                    # by score and the rfirst best by race key of every window in ONE fp32 pass, merge + select enqueued for
+                    # every window, THEN one host read of the certificates; windows that ask for more get passes of their own.
+                    kmax = max(min(self.rescore_max, N - 1 if N > 1 else 1), 1)
+                    kmin = max(min(self.rescore_min, N, kmax), 1)
+                    rfirst = max(min(self.race_min, R), 1)
+                    lsts, blst = [], []
+                    for w in range(Eg):
+                        bt = torch.empty((R + kmax + 1,), dtype=torch.float32, device=self.device)
+                        lsts.append(self.handle.topk_race_window(er[w], expos[w], temp, kmax, kmin, R, list_scores=bt)[0])
+                        blst.append(bt)
+                else:
+                    kmax = kmin = min(self.rescore_topk, N)
+                    rfirst = 0
+                    lsts = [torch.topk(er[w], kmin).indices.to(torch.int32) for w in range(Eg)]
+                    blst = [er[w][lsts[w].long()].contiguous() for w in range(Eg)]
+                delta = float(self._delta) if bound else 0.0
+                m0 = rfirst + kmin
+                pick = torch.cat([lsts[w][R - rfirst : R + kmin].long() for w in range(Eg)])
+                wsel = torch.arange(Eg, dtype=torch.int32, device=self.device).repeat_interleave(m0)
+                f32 = self.handle.score_actions(smode, s, a, r, acts[wsel.long(), pick], wsel, h, lmbda, float(cfg.discount))
+                flst, mstats = [], []
+                for w in range(Eg):  # fp32 scores for the sets, shift-corrected bf16 scores for the rest (m3pc_rescore_merge[_race])
+                    fl = torch.empty_like(blst[w])
+                    fl[R - rfirst : R + kmin] = f32[w * m0 : (w + 1) * m0]
+                    flst.append(fl)
+                    o = R - rfirst
+                    if bound:
+                        merged[w], st_w = self.handle.rescore_merge_race(er[w], expos[w], temp, lsts[w][o:], rfirst, kmin, blst[w][o:],
+                                                                        fl[o:], delta=delta)
+                    else:
+                        merged[w], st_w = self.handle.rescore_merge(er[w], lsts[w], kmin, blst[w], fl, delta=delta)
+                    mstats.append(st_w)
+            sels = [self.handle.select(merged[j], acts[j, :, 0], temp, expos[j]) for j in range(Eg)]
             certs = [None] * Eg
-            if self.rescore == "bound":
-                stats_h = torch.stack(mstats).cpu()  # the one host read of the group: [shift, deviation, need, margin] per window
+            counts = [kmin if self.rescore != "none" else 0] * Eg
+            if bound:
+                stats_h = torch.stack(mstats).cpu()  # the one host read of the group: the certificates' statistics per window
                 ctx = types.SimpleNamespace(hdl=self.handle, cap=max(self.handle.max_rescore, 1), disc=float(cfg.discount),
-                                            temp=float(cfg.temperature), stats_h=stats_h, smode=smode, s=s, a=a, r=r, acts=acts, h=h,
-                                            lmbda=lmbda, N=N, er=er, tops=tops, btops=btops, ftops=ftops, merged=merged, sels=sels,
-                                            expos=expos)
+                                            temp=temp, stats_h=stats_h, smode=smode, s=s, a=a, r=r, acts=acts, h=h,
+                                            lmbda=lmbda, N=N, er=er, lsts=lsts, blst=blst, flst=flst, merged=merged, sels=sels,
+                                            expos=expos, R=R, wset=[None] * Eg, nd=[kmin] * Eg, rd=[rfirst] * Eg)
                 delta_first = delta
                 for w in range(Eg):
                     ops_w = _WindowOps(ctx, w)
                     if delta > delta_first:  # an earlier window of the group raised the bound: this window's certificate again, under it
-                        ops_w.merge_select(counts[w], delta)
-                    certs[w] = self._resolve_certificate(N, kmax, counts[w], delta, ops_w)
+                        ops_w.merge_select(ctx.nd[w], ctx.rd[w], delta)
+                    certs[w] = _resolve_certificate(self, N, kmax, R, ctx.nd[w], ctx.rd[w], delta, ops_w)
                     if certs[w]["delta"] > delta:  # this window saw a larger deviation than the bound: raised for everybody from here on
                         delta = self._delta = certs[w]["delta"]
                     counts[w] = certs[w]["n_rescored"]
@@ -1128,6 +1045,7 @@ class HipPlanner:
                 out[i] = ev if eval else sa[0]
                 info[i] = dict(expect_return=merged[j], argmax=am, sample_idx=si, eval_action=ev, sample_action=sa, horizon=h,
                                n_rescored=None if certs[j] is None else counts[j],
+                               n_race=None if certs[j] is None else certs[j]["n_race"],
                                min_margin_outside=None if certs[j] is None else certs[j]["min_margin_outside"],
                                saturated=None if certs[j] is None else certs[j]["saturated"],
                                delta=self._delta)
@@ -1181,7 +1099,6 @@ class HipPlanner:
         """learner.py:329-417 (the ``horizon`` argument is ignored there too: cfg.horizon rules)."""
         if eval:
             assert rtg is not None
-        self._predrawn = None
         if plan:
             guidance = self.cfg.plan_guidance
             assert guidance in _MODES, guidance

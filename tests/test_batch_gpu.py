@@ -240,10 +240,17 @@ def test_c3_planner_bf16_rescore_keeps_reference_argmax():
     p._eps = lambda shape: eps
     hist = synth.make_history(dims, 0)
     hist["path_length"] = 500
+    # the reference's multinomial draw for the stored seed (make_golden.py: torch.manual_seed(77) in front of rtg / critic guiding)
+    q = torch.empty(4096, dtype=torch.float32).exponential_(1, generator=torch.Generator().manual_seed(77))
+    p._draw_expo = lambda: q.cuda()
     ev = p.action_sample(hist, plan=True, eval=True, rtg=3.0)
     assert int(p.last["argmax"].item()) == int(g["argmax"])
     assert int(g["argmax"]) in p.last["topk"].cpu().numpy()
     assert np.abs(ev.cpu().numpy() - g["eval_action"]).max() < 2e-2
+    # the SAMPLED action (learner.py:324-325) in bf16: the certified race reproduces the reference's index
+    if int(torch.argmax(torch.from_numpy(g["p"].reshape(-1)) / q)) == int(g["sample_idx"].reshape(-1)[0]):
+        assert int(p.last["sample_idx"].item()) == int(g["sample_idx"].reshape(-1)[0])
+        assert np.abs(p.last["sample_action"].cpu().numpy().reshape(-1) - g["sample_action"].reshape(-1)).max() < 2e-5
     p.handle.close()
 
 

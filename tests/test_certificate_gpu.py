@@ -1,8 +1,10 @@
-"""The certified bf16 -> fp32 re-score, quantified (VERDICT r3 item 4a), and a soak of the step pipeline (4b).
+"""The certified bf16 -> fp32 re-score, quantified (VERDICT r3 item 4a, r4 item 1), and a soak of the step pipeline (4b).
 
 Sweep: for many (weight seed, window, eps) trials the bf16 planner's step is compared with a FULL fp32 pass over the same
-candidates: the arg-max must be the reference's in every trial (learner.py:318-325 picks by it; "argmax indices bit-exact" is
-the north star's bar), and the largest deviation of (bf16 - fp32) from the common shift over ALL candidates -- not only the
+candidates: the arg-max AND the multinomial index must be the fp32 planner's in every trial (learner.py:318-325: the eval
+action is weighted by p, the sampled action -- what every online rollout step executes -- is a0[multinomial(p)]; "argmax
+indices bit-exact" is the north star's bar), for the headline shape, critic guidance at temperature 1 (BASELINE config 3), the
+T=64 shard of config 4 and the reference's shipped N=625/H=4/T=8, and the largest deviation of (bf16 - fp32) from the common shift over ALL candidates -- not only the
 re-scored set -- is recorded relative to the bound delta the step used.  The table goes to gpurun_out/ (copied to profiles/).
 
 Soak: a few hundred plan steps issued through plan_async / action_sample / load_state_dict in random order and at random
@@ -23,9 +25,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _cfg(T, N, H):
-    return types.SimpleNamespace(traj_length=T, action_samples=N, horizon=H, discount=0.99, temperature=0.01, lmbda=0.6,
-                                 plan_guidance="rtg_guiding", device="cuda")
+def _cfg(T, N, H, tau=0.01, guidance="rtg_guiding"):
+    return types.SimpleNamespace(traj_length=T, action_samples=N, horizon=H, discount=0.99, temperature=tau, lmbda=0.6,
+                                 plan_guidance=guidance, device="cuda")
 
 
 def _window(dims, i):
@@ -34,58 +36,82 @@ def _window(dims, i):
     return h
 
 
+SWEEPS = [  # env, guidance, temperature, N, T, H, weight seeds, trials per seed
+    ("hopper", "rtg_guiding", 0.01, 1024, 32, 16, 5, 40),             # BASELINE config 2 (the headline)
+    ("hopper", "rtg_guiding", 0.01, 256, 32, 16, 4, 30),
+    ("walker2d", "critic_lambda_guiding", 1.0, 4096, 32, 16, 3, 16),  # BASELINE config 3: Q-value scale, temperature 1
+    ("halfcheetah", "rtg_guiding", 0.01, 2048, 64, 32, 3, 16),        # one rank's share of BASELINE config 4
+    ("hopper", "rtg_guiding", 0.01, 625, 8, 4, 4, 30),                # the reference's shipped config (config.yaml:5,77-79)
+]
+
+
 @pytest.mark.slow
-@pytest.mark.parametrize("N,T,H,seeds,per_seed", [(1024, 32, 16, 5, 40), (256, 32, 16, 4, 30)])
-def test_certificate_sweep_argmax_and_deviation(N, T, H, seeds, per_seed):
-    per_seed *= int(os.environ.get("M3PC_SWEEP_SCALE", "1"))  # (a longer sweep for the record: profiles/r04_certificate_sweep_long_*)
-    dims = synth.Dims(11, 3, T)
+@pytest.mark.parametrize("env,guidance,tau,N,T,H,seeds,per_seed", SWEEPS, ids=[f"{s[0]}-{s[1].split('_')[0]}-N{s[3]}-T{s[4]}" for s in SWEEPS])
+def test_certificate_sweep_argmax_sample_index_and_deviation(env, guidance, tau, N, T, H, seeds, per_seed):
+    per_seed *= int(os.environ.get("M3PC_SWEEP_SCALE", "1"))  # (a longer sweep for the record: profiles/r05_certificate_sweep_long_*)
+    S, A = synth.ENV_DIMS[env]
+    dims = synth.Dims(S, A, T)
+    mode = capi.MODE_RTG if guidance == "rtg_guiding" else capi.MODE_CRITIC
     rows = []
-    mismatches = 0
+    mismatches = sample_mismatches = 0
     for ws in range(seeds):
         sd, st = synth.make_state_dict(dims, ws), synth.make_tokenizer_stats(dims, ws)
-        pb = HipPlanner(_cfg(T, N, H), sd, st, None, precision="bf16", generator=torch.Generator(device="cuda").manual_seed(1))
-        pf = HipPlanner(_cfg(T, N, H), sd, st, None, precision="fp32", generator=torch.Generator(device="cuda").manual_seed(1))
+        qsd, om, os_ = synth.make_critic(dims, ws) if mode == capi.MODE_CRITIC else (None, None, None)
+        mk = lambda prec: HipPlanner(_cfg(T, N, H, tau, guidance), sd, st, qsd, om, os_, precision=prec,
+                                     generator=torch.Generator(device="cuda").manual_seed(1))
+        pb, pf = mk("bf16"), mk("fp32")  # (same generator seed: both draw the same Exp(1) variates step for step)
         for t in range(per_seed):
             hist = _window(dims, t)
             eps = synth.make_eps(N, dims, 1000 * ws + t).cuda()
             rtg = 3.0 + 0.25 * (t % 5)
             sb, ab, rb, h, g = pb.assemble_window(hist, rtg=rtg)
-            pb._guide(capi.MODE_RTG, sb, ab, rb, g, h, 0.6, eps=eps)
+            sab, _ = pb._guide(mode, sb, ab, rb, g, h, 0.6, eps=eps)
             lb = pb.last
             b, merged = lb["expect_return_bf16"].clone(), lb["expect_return"].clone()
-            am_b = int(lb["argmax"].item())
-            pf._guide(capi.MODE_RTG, sb, ab, rb, g, h, 0.6, eps=eps)
+            am_b, si_b = int(lb["argmax"].item()), int(lb["sample_idx"].item())
+            saf, _ = pf._guide(mode, sb, ab, rb, g, h, 0.6, eps=eps)
             f = pf.last["expect_return"]
-            am_f = int(pf.last["argmax"].item())
+            am_f, si_f = int(pf.last["argmax"].item()), int(pf.last["sample_idx"].item())
             d = b - f
             c = float(lb["shift"])
             ratio = float((d - c).abs().max()) / float(lb["delta"])
             gap = torch.topk(f, 2).values
             mismatches += int(am_b != am_f)
+            sample_mismatches += int(si_b != si_f)
             # the re-scored entries of the merged vector ARE the fp32 scores
-            top = lb["topk"].long()
+            top = torch.cat([lb["topk"].long(), lb["race"].long()])
             assert float((merged[top] - f[top]).abs().max()) <= 5e-5 * float(f.abs().max())
-            rows.append(dict(weight_seed=ws, trial=t, argmax_match=am_b == am_f, ratio=round(ratio, 4), delta=round(float(lb["delta"]), 4),
-                             n_rescored=int(lb["n_rescored"]), need_first=int(lb["n_in_window"]), saturated=bool(lb["saturated"]),
+            assert si_b != si_f or torch.equal(sab, saf)
+            rows.append(dict(weight_seed=ws, trial=t, argmax_match=am_b == am_f, sample_idx_match=si_b == si_f, ratio=round(ratio, 4),
+                             delta=round(float(lb["delta"]), 4), n_rescored=int(lb["n_rescored"]), need_first=int(lb["n_in_window"]),
+                             n_race=int(lb["n_race"]), need_race_first=int(lb["need_race"]), saturated=bool(lb["saturated"]),
+                             second_pass=bool(lb["n_rescored"] > lb["n_first"] or lb["n_race"] > lb["n_race_first"]),
                              top1_top2_gap=round(float(gap[0] - gap[1]), 4), score_sigma=round(float(f.std()), 3)))
         pb.handle.close()
         pf.handle.close()
     ratios = np.array([r["ratio"] for r in rows])
-    summary = dict(config=f"hopper rtg_guiding N={N} T={T} H={H}", trials=len(rows), argmax_mismatches=mismatches,
+    tot = [r["n_rescored"] + r["n_race"] for r in rows]
+    summary = dict(config=f"{env} {guidance} N={N} T={T} H={H} temperature={tau}", trials=len(rows), argmax_mismatches=mismatches,
+                   sample_idx_mismatches=sample_mismatches,
                    ratio_max=float(ratios.max()), ratio_p99=float(np.quantile(ratios, 0.99)), ratio_median=float(np.median(ratios)),
                    trials_with_ratio_above_1=int((ratios > 1).sum()),
-                   n_rescored_mean=float(np.mean([r["n_rescored"] for r in rows])), n_rescored_max=int(max(r["n_rescored"] for r in rows)),
+                   n_rescored_mean=float(np.mean(tot)), n_rescored_max=int(max(tot)),
+                   n_by_score_mean=float(np.mean([r["n_rescored"] for r in rows])), n_by_race_mean=float(np.mean([r["n_race"] for r in rows])),
+                   need_race_first_max=int(max(r["need_race_first"] for r in rows)),
+                   second_pass_trials=int(sum(r["second_pass"] for r in rows)),
                    saturated_trials=int(sum(r["saturated"] for r in rows)),
                    what="ratio = max over ALL candidates of |(bf16 - fp32) - shift| / delta of the step; > 1 means a candidate outside "
-                        "the bound existed in that trial (the arg-max may still be right: it needs such a candidate inside the gap)")
+                        "the bound existed in that trial (the arg-max / draw may still be right: it needs such a candidate inside the "
+                        "gap); n_rescored = score-list + race-list candidates re-scored in fp32")
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
         tag = "_long" if os.environ.get("M3PC_SWEEP_SCALE") else ""
-        with open(os.path.join(out_dir, f"r04_certificate_sweep{tag}_N{N}.json"), "w") as fh:
+        with open(os.path.join(out_dir, f"r05_certificate_sweep{tag}_{env}_{guidance.split('_')[0]}_N{N}_T{T}.json"), "w") as fh:
             json.dump(dict(summary=summary, rows=rows), fh, indent=0)
     print(json.dumps(summary))
-    assert len(rows) >= 120
+    assert len(rows) >= 45
     assert mismatches == 0, summary
+    assert sample_mismatches == 0, summary
 
 
 def _churn(rng, keep):

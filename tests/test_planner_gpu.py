@@ -107,18 +107,12 @@ def test_c2_bf16_with_fp32_rescore_keeps_reference_argmax():
     ref = g["expect_return_shifted"][top]
     assert np.abs(got - ref).max() <= 5e-5 * float(er.abs().max())
     assert np.abs(ev.cpu().numpy() - g["eval_action"]).max() < 5e-3
-    # The sampling branch (learner.py:324-325) in bf16 mode.  p = softmax(0.01 (E - max E)) is nearly flat on this workload and the
-    # un-re-scored candidates' scores carry the bf16 deviation (a few units => a few per cent of their weight), so the index
-    # torch.multinomial draws is NOT guaranteed to equal the reference's (here: 369 against 8 for the stored seed; fp32 mode
-    # reproduces it, test_hip_parity.py).  What holds: every weight is within the deviation band of the reference's, and the
-    # candidate drawn from the bf16 p is a near-winner of the reference's own race argmax(p / q), q ~ Exp(1) (ATen's algorithm).
+    # The sampling branch (learner.py:324-325) in bf16 mode: every weight is within the deviation band of the reference's (the
+    # un-re-scored candidates' scores carry the bf16 deviation); the INDEX drawn is certified separately (tests/test_race_gpu.py:
+    # the reference's stored-seed index is reproduced).
     pb, pr = p.last["p"].cpu().double(), torch.from_numpy(g["p"].reshape(-1)).double()
     band = float(np.exp(0.01 * 4 * p.last["delta"]) - 1.0)
     assert float((pb / pr - 1).abs().max()) <= band, (float((pb / pr - 1).abs().max()), band)
-    q = torch.empty(1024, dtype=torch.float32).exponential_(1, generator=torch.Generator().manual_seed(77)).double()
-    idx_b = int(torch.multinomial(p.last["p"].cpu(), 1, generator=torch.Generator().manual_seed(77)))
-    if int(torch.argmax(pr / q)) == int(g["sample_idx"].reshape(-1)[0]):  # (the replay above is ATen's draw)
-        assert float((pr / q)[idx_b] / (pr / q).max()) >= 1.0 - 2 * band
     p.handle.close()
 
 
