@@ -262,6 +262,9 @@ def main():
     ap.add_argument("--env", default="hopper", choices=["hopper", "walker2d", "halfcheetah"],
                     help="state/action dims of the D4RL family (BASELINE configs 3-4 use walker2d / halfcheetah)")
     ap.add_argument("--guidance", default="rtg_guiding", choices=["rtg_guiding", "critic_lambda_guiding"])
+    ap.add_argument("--no-certify-sample", action="store_true",
+                    help="A/B switch: certify the arg-max only (round-4 behaviour), not the multinomial index of the sampled action")
+    ap.add_argument("--race-min", type=int, default=0, help="race entries of a first re-score pass (0: the planner's default)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU (tests/test_bench_launch_cpu.py): the ranks meet over gloo and rank 0 prints a stub line")
     args = ap.parse_args()
@@ -326,6 +329,7 @@ def main():
     planner = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), qsd, om, os_,
                          precision=args.precision, rescore_topk=args.rescore_topk, device=local_rank, generator=gen,
                          rescore=args.rescore, **({"rescore_min": args.rescore_min} if args.rescore_min else {}), group=group,
+                         certify_sample=not args.no_certify_sample, **({"race_min": args.race_min} if args.race_min else {}),
                          pipeline_depth=max(1, min(args.depth, capi.SLOTS - 1)))
     hist = synth.make_history(dims, 0 if (shard_cand or world == 1) else rank)  # env sharding: every rank its own environment
     hist["path_length"] = 500
@@ -345,7 +349,7 @@ def main():
             for _ in range(k):
                 step()
                 if record:
-                    n_re.append(planner.last.get("n_rescored", args.rescore_topk))
+                    n_re.append(planner.last.get("n_rescored", args.rescore_topk) + planner.last.get("n_race", 0))
             return
         flight = deque()
         for _ in range(k):
@@ -354,12 +358,12 @@ def main():
                 tk = flight.popleft()
                 tk.pair()
                 if record:
-                    n_re.append(tk.info.get("n_rescored", args.rescore_topk))
+                    n_re.append(tk.info.get("n_rescored", args.rescore_topk) + tk.info.get("n_race", 0))
         while flight:
             tk = flight.popleft()
             tk.pair()
             if record:
-                n_re.append(tk.info.get("n_rescored", args.rescore_topk))
+                n_re.append(tk.info.get("n_rescored", args.rescore_topk) + tk.info.get("n_race", 0))
 
     def barrier():
         if world > 1:

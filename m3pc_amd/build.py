@@ -38,12 +38,12 @@ def _stale(target: str, deps) -> bool:
 
 def build_library(force: bool = False, verbose: bool = False, lab: bool = False) -> str:
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, n) for n in ("kernels.h", "gemm_epilogue.h", "gemm_stage_asm.h")] + \
+    headers = [os.path.join(CSRC, n) for n in ("kernels.h", "gemm_epilogue.h", "gemm_stage_asm.h", "exports.map")] + \
               [os.path.join(os.path.dirname(HERE), "include", n) for n in ("m3pc_hip.h", "m3pc_hip_debug.h")]
     objdir = os.path.join(CSRC, "build_lab" if lab else "build")
     os.makedirs(objdir, exist_ok=True)
     flags = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-             "-fno-gpu-rdc", "-ffp-contract=off"] + (["-DM3PC_LAB"] if lab else [])
+             "-fno-gpu-rdc", "-ffp-contract=off", "-fvisibility=hidden"] + (["-DM3PC_LAB"] if lab else [])
     jobs = []
     objs = []
     lib = LAB_LIB if lab else LIB
@@ -66,7 +66,7 @@ def build_library(force: bool = False, verbose: bool = False, lab: bool = False)
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(lib, objs):
-        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs])
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", f"-Wl,--version-script={os.path.join(CSRC, 'exports.map')}", "-o", lib, *objs])
     return lib
 
 

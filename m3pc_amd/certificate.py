@@ -139,7 +139,10 @@ class _WindowOps:
         lists = (c.lsts[w][o:], c.blst[w][o:], c.flst[w][o:])
         if c.wset[w] is not None:  # (the window-set path's own score entries behind the race entries of the list buffer)
             lists = tuple(torch.cat([a[:r], b]).contiguous() for a, b in zip(lists, c.wset[w]))
-        c.merged[w], self.pending = c.hdl.rescore_merge_race(c.er[w], c.expos[w], c.temp, lists[0], r, n, lists[1], lists[2], delta=dlt)
+        if c.R > 0:
+            c.merged[w], self.pending = c.hdl.rescore_merge_race(c.er[w], c.expos[w], c.temp, lists[0], r, n, lists[1], lists[2], delta=dlt)
+        else:
+            c.merged[w], self.pending = c.hdl.rescore_merge(c.er[w], lists[0], n, lists[1], lists[2], delta=dlt)
         c.sels[w] = c.hdl.select(c.merged[w], c.acts[w, :, 0], c.temp, c.expos[w])
 
 

@@ -1734,6 +1734,9 @@ int find_tensor(const m3pc_named_tensor* list, int n, const std::string& name) {
 // =====================================================================================================
 static int fill_rtok(m3pc_handle* h, const double* rtg, int n_windows, hipStream_t st);
 
+// the library is built with -fvisibility=hidden: the C ABI below (include/m3pc_hip.h, and in the lab build m3pc_hip_debug.h) is
+// everything it exports
+#pragma GCC visibility push(default)
 extern "C" {
 
 const char* m3pc_last_error(void) { return g_err; }
@@ -3217,3 +3220,4 @@ int m3pc_profile_read(m3pc_handle* h, int precision, long long* launches, double
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

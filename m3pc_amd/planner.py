@@ -129,7 +129,7 @@ class HipPlanner:
                  group=None, generator: Optional[torch.Generator] = None, max_batch: int = 1,
                  rescore: str = "bound", rescore_min: int = 8, rescore_max: int = 128, rescore_delta: Optional[float] = None,
                  max_windows: int = 1, pipeline_depth: int = 2, chain_priority: int = -1, tail_stream: bool = True,
-                 defer_join: bool = True, goal_batch: int = 0, race_min: int = 2, calibration_windows: int = 3):
+                 defer_join: bool = True, goal_batch: int = 0, race_min: int = 2, calibration_windows: int = 3, certify_sample: bool = True):
         """cfg: any object with traj_length, action_samples, horizon, discount, temperature, lmbda,
         plan_guidance (finetune.py RunConfig fields read at learner.py:276,319,342).
         tokenizer_manager: a TokenizerManager (this package's) or {key: {"mean","std","min","max"}}.
@@ -166,7 +166,9 @@ class HipPlanner:
         nw = max(int(max_windows), 1)
         # chain workspace: the fp32 re-score sets (all windows of a lock-step batch together): a first pass is at most rescore_max
         # score entries + RACE_MAX race entries
-        self._R = max(min(RACE_MAX, N), 1)  # race entries a step lists (m3pc_topk_race_window)
+        # race entries a step lists (m3pc_topk_race_window); certify_sample=False: none -- the arg-max (hence eval_action) stays
+        # certified, the multinomial index is then a near-winner of the reference's draw only (round-4 behaviour, A/B switch)
+        self._R = max(min(RACE_MAX, N), 1) if certify_sample else 0
         max_rescore = max((int(rescore_max) + self._R) * nw, int(rescore_topk), 1) if precision == "bf16" else 1
         self._max_batch = max(int(max_batch), nw, 1)
         self.handle = capi.Handle(S, A, T, n_embd, n_head, n_enc_layer, n_dec_layer,
@@ -257,15 +259,15 @@ class HipPlanner:
         index - SLOTS."""
         seen = [(i, v) for i, v in self._hist.items() if i <= index - capi.SLOTS]
         grow = max([1.5 * v[0] for _, v in seen], default=0.0) if self._delta_fixed is None else 0.0
-        # first pass: what the 80th percentile of the recent steps' certificates asked for, in fours (a second pass costs a
-        # whole fp32 chain, ~0.3 ms; four more candidates in the first ~0.02-0.05 ms)
+        # first pass: what the 80th percentile of the recent steps' certificates asked for -- by score and by race key together,
+        # in fours (a second pass costs a whole fp32 chain, ~0.3 ms; four more candidates in the first ~0.02-0.05 ms; the few-row
+        # fp32 kernels work in 64-row tiles, 8 candidates = 392 encoder / 256 decoder rows fill 7 / 4 of them), at least
+        # rescore_min in all: the race entries take their share of that floor instead of adding to it
         recent = sorted(seen)[-16:]
-        kfirst, rfirst = self.rescore_min, self.race_min
-        if recent:
-            q = sorted(v[1] for _, v in recent)[min(len(recent) - 1, int(0.8 * len(recent)))]
-            kfirst = max(self.rescore_min, -(-q // 4) * 4)
-            rfirst = max(self.race_min, sorted(v[2] for _, v in recent)[min(len(recent) - 1, int(0.8 * len(recent)))])
-        return grow, kfirst, min(rfirst, self._R)
+        q80 = lambda vals: sorted(vals)[min(len(vals) - 1, int(0.8 * len(vals)))]
+        rfirst = min(max(self.race_min, q80([v[2] for _, v in recent]) if recent else 0), self._R)
+        total = max(self.rescore_min, -(-(q80([v[1] for _, v in recent]) + rfirst) // 4) * 4) if recent else self.rescore_min
+        return grow, max(total - rfirst, 1), rfirst
 
     def load_critic(self, q_state_dict, obs_mean, obs_std):
         self.handle.set_critic(q_state_dict, obs_mean, obs_std)
@@ -481,7 +483,7 @@ class HipPlanner:
                         d = self._calibrate(tk)
                         self._delta0 = d if self._delta0 is None else max(self._delta0, d)
                     kmax = max(min(self.rescore_max, N - 1 if N > 1 else 1), 1)
-                    kmin = max(min(max(self.rescore_min, tk.kfirst_in), N, kmax), 1)
+                    kmin = max(min(tk.kfirst_in, N, kmax), 1)
                     tk.delta = max(self._delta0, tk.grow_in)
                 else:
                     kmax = kmin = max(min(self.rescore_topk, N, hd.max_rescore), 1)
@@ -494,7 +496,7 @@ class HipPlanner:
                 # certificates (host-mapped statistics, no stream synchronisation) and only when they ask for more the rest is
                 # re-scored and merge + select are repeated on the same variates.
                 R = tk.R
-                if self.rescore == "bound":
+                if self.rescore == "bound" and R > 0:
                     rfirst = max(min(tk.rfirst_in, R), 1)
                     hd.topk_race_window(tk.er_b, tk.expo, float(cfg.temperature), kmax, kmin, R, lst=tk.lst, stats=sl.stats,
                                         list_scores=sl.b_lst)
@@ -518,7 +520,7 @@ class HipPlanner:
         lists = (tk.lst[o:], sl.b_lst[o:], sl.f_lst[o:])
         if tk.wset is not None:
             tk.keep = lists = tuple(torch.cat([a[:r], b]).contiguous() for a, b in zip(lists, tk.wset))
-        if self.rescore == "bound":
+        if self.rescore == "bound" and tk.R > 0:
             self.handle.rescore_merge_race(tk.er_b, tk.expo, float(self.cfg.temperature), lists[0], r, n, lists[1], lists[2],
                                            delta=tk.delta, merged=tk.er, stats=sl.mstats, host_stats=sl.hs_mrg.buf, seq=tk.seq_mrg)
         else:
@@ -545,7 +547,7 @@ class HipPlanner:
             extra["n_first"], extra["n_race_first"] = tk.kmin, min(max(tk.rfirst_in, 1), tk.R)
             top = ops.top if ops.top is not None else tk.top[: extra["n_rescored"]]
             extra["n_rescored"] = int(top.numel())
-            extra["race"] = tk.lst[tk.R - extra["n_race"] : tk.R].flip(0)  # the re-scored racers, best bf16 race key first
+            extra["race"] = tk.lst[tk.R - extra["n_race"] : tk.R]  # the re-scored racers (a view: best bf16 race key LAST)
             # what this step saw feeds the steps from SLOTS later on (_adapt): the bound, and the sizes of the first pass
             self._hist[tk.index] = (float(extra["deviation"]), min(int(extra["n_in_window"]), tk.kmax),
                                     min(int(extra["need_race"]), tk.R))
@@ -993,12 +995,15 @@ class HipPlanner:
                     # by score and the rfirst best by race key of every window in ONE fp32 pass, merge + select enqueued for
                     # every window, THEN one host read of the certificates; windows that ask for more get passes of their own.
                     kmax = max(min(self.rescore_max, N - 1 if N > 1 else 1), 1)
-                    kmin = max(min(self.rescore_min, N, kmax), 1)
-                    rfirst = max(min(self.race_min, R), 1)
+                    rfirst = max(min(self.race_min, R), 1) if R > 0 else 0
+                    kmin = max(min(self.rescore_min - rfirst, N, kmax), 1)  # (the race entries share the floor of the first pass)
                     lsts, blst = [], []
                     for w in range(Eg):
                         bt = torch.empty((R + kmax + 1,), dtype=torch.float32, device=self.device)
-                        lsts.append(self.handle.topk_race_window(er[w], expos[w], temp, kmax, kmin, R, list_scores=bt)[0])
+                        if R > 0:
+                            lsts.append(self.handle.topk_race_window(er[w], expos[w], temp, kmax, kmin, R, list_scores=bt)[0])
+                        else:
+                            lsts.append(self.handle.topk_window(er[w], kmax, kmin, 0.0, top_scores=bt)[0])
                         blst.append(bt)
                 else:
                     kmax = kmin = min(self.rescore_topk, N)
@@ -1016,7 +1021,7 @@ class HipPlanner:
                     fl[R - rfirst : R + kmin] = f32[w * m0 : (w + 1) * m0]
                     flst.append(fl)
                     o = R - rfirst
-                    if bound:
+                    if bound and R > 0:
                         merged[w], st_w = self.handle.rescore_merge_race(er[w], expos[w], temp, lsts[w][o:], rfirst, kmin, blst[w][o:],
                                                                         fl[o:], delta=delta)
                     else:

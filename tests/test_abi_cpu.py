@@ -31,6 +31,16 @@ def test_every_declared_symbol_is_exported(lib):
     assert set(names) == set(capi.EXPORTS)
 
 
+def test_the_library_exports_its_c_abi_and_nothing_else(lib):
+    """-fvisibility=hidden + csrc/exports.map: no C++ internal (launchers, kernel handles) in the dynamic symbol table; the
+    defined dynamic symbols of the product library are exactly the entry points of include/m3pc_hip.h."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", build.LIB], capture_output=True, text=True, check=True).stdout
+    names = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert not [n for n in names if n.startswith("_Z")], [n for n in names if n.startswith("_Z")][:5]
+    assert names == sorted(capi.EXPORTS)
+
+
 def test_abi_version_and_error_string(lib):
     assert lib.m3pc_abi_version() == capi.ABI_VERSION
     assert isinstance(lib.m3pc_last_error(), bytes)

@@ -66,7 +66,7 @@ def test_bound_rescore_keeps_the_reference_argmax(g5):
         assert int(last["argmax"].item()) == ref_am, (case, int(last["argmax"].item()), ref_am)
         top = last["topk"].cpu().numpy()
         assert ref_am in top, (case, "reference arg-max was not re-scored")
-        assert 4 <= last["n_rescored"] == top.size
+        assert 4 <= last["n_rescored"] + last["n_race"] and last["n_rescored"] == top.size
         assert last["delta"] > 0 and last["min_margin_outside"] >= 0
         # every candidate inside the window was re-scored: either the listed prefix covered the window (containment held
         # with the bound's own room) or the whole window set went through the chunked fallback
@@ -110,7 +110,8 @@ def test_fixed_delta_and_topk_modes():
     eps = synth.make_eps(256, dims, 3).cuda()
     p = _planner(dims, 256, 16, 0.01, "rtg_guiding", 0, rescore_delta=0.0, rescore_min=5)
     _run(p, dims, 0, 400, eps)
-    assert 5 <= p.last["n_rescored"] <= 16 and p.last["n_first"] == 5  # delta 0: the floor (plus whatever beats the fp32 best outright)
+    # delta 0: the floor -- race entries included -- plus whatever beats the fp32 best outright
+    assert 3 <= p.last["n_rescored"] <= 16 and p.last["n_first"] + p.last["n_race_first"] == 5
     p.handle.close()
     p = _planner(dims, 256, 16, 0.01, "rtg_guiding", 0, rescore="topk", rescore_topk=7)
     _run(p, dims, 0, 400, eps)
