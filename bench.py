@@ -262,6 +262,10 @@ def main():
     ap.add_argument("--env", default="hopper", choices=["hopper", "walker2d", "halfcheetah"],
                     help="state/action dims of the D4RL family (BASELINE configs 3-4 use walker2d / halfcheetah)")
     ap.add_argument("--guidance", default="rtg_guiding", choices=["rtg_guiding", "critic_lambda_guiding"])
+    ap.add_argument("--serial-halves", action="store_true",
+                    help="run the two candidate halves of a step one after the other on one stream (m3pc_profile_enable(h, 3)); with "
+                         "--depth 0 every launch then runs alone on the chip: the arrangement of roofline.frac, for an external "
+                         "kernel trace (profiles/r05_kernel_stats_alone.csv)")
     ap.add_argument("--no-certify-sample", action="store_true",
                     help="A/B switch: certify the arg-max only (round-4 behaviour), not the multinomial index of the sampled action")
     ap.add_argument("--race-min", type=int, default=0, help="race entries of a first re-score pass (0: the planner's default)")
@@ -338,6 +342,9 @@ def main():
     mode = capi.MODE_CRITIC if critic_mode else capi.MODE_RTG
     depth = max(0, min(args.depth, capi.SLOTS - 1))
 
+    if args.serial_halves:
+        planner.handle.profile_enable(3)
+
     def step():  # one plan step alone, serial
         return planner._guide(mode, states, actions, rewards, rtg, h, 0.6)
 
@@ -411,7 +418,7 @@ def main():
         cls_ = planner.handle.profile_read(prec, reset=False)
         tail_ = planner.handle.profile_read(capi.PROF_LAYER_TAIL, reset=False)
         all_ = planner.handle.profile_read(-1, reset=True)
-        planner.handle.profile_enable(False)
+        planner.handle.profile_enable(3 if args.serial_halves else False)
         return cls_, tail_, all_
 
     # as run: the steps pipelined and the two candidate halves on two streams exactly as in the timed region (a bracket also
@@ -439,16 +446,31 @@ def main():
         kname = f"the {args.precision} MFMA GEMM launches (gemm_line_kernel / gemm_glds_ring3_kernel / gemm_kernel)"
     alone = al_fl / (al_ms * 1e-3) / 1e12 if al_ms > 0 else None
     step_s = elapsed / args.steps
-    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.precision),
+    # `frac` is the kernel's own efficiency: every launch ALONE on the chip (serial order, the halves one after the other on one
+    # stream, m3pc_profile_enable(h, 2)) -- the figure whose launches-per-step x duration fits inside ms_per_step and that
+    # profiles/r05_kernel_stats_alone.csv reproduces.  `as_run` holds the brackets of the same launches as the timed region runs
+    # (steps pipelined, halves on two streams): concurrent brackets overlap, so their sum exceeds the step -- sharing, not efficiency.
+    as_run = {"avg_launch_us": 1e3 * dom_ms / max(dom_l, 1), "achieved": round(achieved, 2), "frac": round(achieved / peak, 4),
+              "kernel_ms_per_step": dom_ms / args.steps,
+              "note": "HIP-event brackets as the timed region runs: steps pipelined, the two candidate halves on two streams -- a bracket "
+                      "also holds what the other streams run on the chip meanwhile; brackets of concurrent launches overlap (their sum "
+                      "may exceed ms_per_step)"}
+    if alone is not None:
+        top = {"achieved": round(alone, 2), "frac": round(alone / peak, 4), "avg_launch_us": 1e3 * al_ms / max(al_l, 1),
+               "kernel_ms_per_step": al_ms / args.steps, "arrangement": "alone: serial order, candidate halves one after the other on one stream"}
+    else:
+        top = {"achieved": as_run["achieved"], "frac": as_run["frac"], "avg_launch_us": as_run["avg_launch_us"],
+               "kernel_ms_per_step": as_run["kernel_ms_per_step"], "arrangement": "as run (--no-alone-pass)"}
+    roofline = {"bound": "mfma", "achieved": top["achieved"], "peak": peak, "unit": "TFLOP/s",
+                "frac": top["frac"], "traffic": pmc_traffic(args.precision),
                 "peak_measured": 1800.0 if args.precision == "bf16" else None,  # register-resident v_mfma loop at the 1.75 GHz the chip holds
                 "kernel": kname,
-                "flops_per_launch": dom_fl / max(dom_l, 1), "avg_launch_us": 1e3 * dom_ms / max(dom_l, 1),
-                "launches_per_step": dom_l / args.steps, "kernel_ms_per_step": dom_ms / args.steps,
-                "note": "HIP-event brackets on the stream of each launch in an instrumented pass of the same K steps, run as the timed "
-                        "region runs: steps pipelined, the two candidate halves on two streams, so a launch shares the chip with the "
-                        "other streams' kernels for part of its bracket; `alone` = the same launches in the serial order with the "
-                        "halves one after the other on one stream (m3pc_profile_enable(h, 2)), each alone on the chip",
+                "flops_per_launch": dom_fl / max(dom_l, 1), "avg_launch_us": top["avg_launch_us"],
+                "launches_per_step": dom_l / args.steps, "kernel_ms_per_step": top["kernel_ms_per_step"],
+                "arrangement": top["arrangement"],
+                "note": "HIP-event brackets on the stream of each launch in instrumented passes of the same K steps (outside the timed "
+                        "region): achieved = algorithmic flops per launch / average launch duration with every launch alone on the chip",
+                "as_run": as_run,
                 "alone": None if alone is None else {"avg_launch_us": 1e3 * al_ms / max(al_l, 1), "achieved": round(alone, 2),
                                                       "frac": round(alone / peak, 4)},
                 # every MFMA launch of the compute dtype (fused tails, fused decoder input, Q|K|V / head GEMMs)
@@ -468,7 +490,8 @@ def main():
             par = f"env-shard x{world} (one environment per GPU, no collective)" if world > 1 else "1 GPU"
         flight_txt = (f"{depth} independent plan steps in flight (policy pass / candidate pass / re-score of neighbouring steps on "
                       f"different streams)") if depth else "serial order"
-        metric = "MPC plan-steps/sec (N=1024, H=16, hopper-medium-v2)"
+        metric = "MPC plan-steps/sec (N=1024, H=16, hopper-medium-v2)" + (
+            f"; independent plan steps, {depth} in flight" if depth else "; one step at a time (serial)")
         if args.config == "c4":
             metric = "MPC plan-steps/sec (N=16384, H=32, halfcheetah-medium-expert-v2, candidate-sharded)"
         out = {"metric": metric, "value": round(value, 2),
@@ -479,7 +502,10 @@ def main():
                "config": {"workload": f"{args.env}-medium-v2 shapes (S={S},A={A}) {args.guidance} N={args.candidates}"
                                       + ("/GPU" if (shard_cand and not args.strong) else "") + f" H={H} "
                                       f"T={T} {args.precision} candidate pass + fp32 policy pass + fp32 re-score ("
-                                      + (f"certified set, {sum(n_re) / max(len(n_re), 1):.1f} candidates on average" if args.rescore == "bound"
+                                      + (f"arg-max and multinomial draw certified under the calibrated bound delta, {sum(n_re) / max(len(n_re), 1):.1f} candidates "
+                                          f"re-scored on average" if args.rescore == "bound" and not args.no_certify_sample
+                                         else f"arg-max certified under the calibrated bound delta, {sum(n_re) / max(len(n_re), 1):.1f} candidates on average"
+                                         if args.rescore == "bound"
                                          else f"top-{args.rescore_topk}") + f"); {flight_txt}; window resident in HBM",
                           "candidates_per_gpu": n_local, "global_candidates": n_global, "horizon": H, "traj_length": T,
                           "steps_in_flight": depth, "settle_steps": args.settle, "parallelism": par},
@@ -521,26 +547,51 @@ def finish_with_collective_legs(args, out, rank, local_rank, world):
     """Behind the headline measurement of an environment-sharded multi-GPU run: the candidate-sharded legs (RCCL all-gather
     on the data path) under a wall-clock watchdog, then rank 0's ONE JSON line.  A leg that hangs or fails costs its own
     entry, never the headline: on timeout rank 0 prints the line with {"error": "timeout"} and every rank exits with code 0."""
-    def on_timeout():
+    store = None
+    try:
+        store = torch.distributed.distributed_c10d._get_default_store()
+    except Exception:
+        pass
+
+    def peer_failure():
+        """The message a failing rank left in the rendezvous store (a rank that raises before a collective would
+        otherwise leave the others waiting in it until the watchdog's limit, and its message would be lost)."""
+        try:
+            if store is not None and store.check(["m3pc_leg_fail"]):
+                return store.get("m3pc_leg_fail").decode()[:300]
+        except Exception:
+            pass
+        return None
+
+    def on_timeout(reason="timeout"):
         if rank == 0:
-            out["c4"] = {"error": "timeout"}
-            out["c2_candidates_strong"] = {"error": "timeout"}
+            for leg in ("c4", "c4_pipelined", "c2_candidates_strong"):
+                out[leg] = {"error": reason}
+            out["collective_legs_ok"] = False
             out["collective_timeout_s"] = args.collective_timeout
             print(json.dumps(out), flush=True)
 
     def legs():
         try:
             res = collective_legs(args, rank, local_rank, world)
-        except Exception as e:  # (every rank fails alike or the others time out)
-            res = {"c4": {"error": repr(e)[:300]}}
+        except Exception as e:
+            msg = f"rank {rank}: {e!r}"[:300]
+            try:
+                if store is not None:
+                    store.set("m3pc_leg_fail", msg)
+            except Exception:
+                pass
+            res = {"c4": {"error": msg}, "collective_legs_ok": False}
+            return res  # (no barrier: the other ranks leave through their watchdogs as soon as they see the message)
         torch.distributed.barrier()
         return res
 
-    res = run_guarded(legs, args.collective_timeout, on_timeout)
+    res = run_guarded(legs, args.collective_timeout, on_timeout, abort_reason=peer_failure)
     if rank == 0:
         out.update(res)
+        out.setdefault("collective_legs_ok", all("error" not in v for v in res.values() if isinstance(v, dict)))
         print(json.dumps(out), flush=True)
-    run_guarded(torch.distributed.destroy_process_group, 30.0, lambda: None)
+    run_guarded(torch.distributed.destroy_process_group, 30.0, lambda *a: None)
 
 
 def main_c5(args, rank, local_rank, world):
@@ -568,6 +619,16 @@ def main_c5(args, rank, local_rank, world):
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def c4_full_leg(local_rank, steps=6):
+    """BASELINE configs[3] at its full size on ONE GPU: halfcheetah shapes, rtg_guiding, N=16384, H=32, T=64 (about 60 GB of
+    workspace): the single-GPU figure a candidate-sharded N-rank run of the same step divides by.  Serial and pipelined."""
+    ser = plan_leg(local_rank, "halfcheetah", "rtg_guiding", 16384, 32, 64, steps=steps, warm=2, settle=4, depth=0)
+    pip = plan_leg(local_rank, "halfcheetah", "rtg_guiding", 16384, 32, 64, steps=steps, warm=2, settle=4, depth=2,
+                   what="BASELINE configs[3] on ONE GPU: halfcheetah shapes rtg_guiding, all N=16384 candidates, H=32 T=64 bf16")
+    pip["serial_ms_per_step"] = ser["ms_per_step"]
+    return pip
 
 
 def plan_leg(local_rank, env, guidance, N, H, T, steps=20, warm=4, settle=12, depth=2, group=None, what=""):
@@ -670,32 +731,63 @@ def collective_legs(args, rank, local_rank, world):
     if args.dry_run:
         if os.environ.get("M3PC_BENCH_HANG_LEG"):
             time.sleep(3600)
+        if os.environ.get("M3PC_BENCH_FAIL_LEG_RANK") == str(rank):  # (one rank raises before the collective: the others must not wait)
+            raise RuntimeError("injected leg failure")
+        if os.environ.get("M3PC_BENCH_FAIL_LEG_RANK"):
+            time.sleep(3600)  # (stands for the collective the failed rank never enters)
         res["c4"] = {"dry_run": True}
+        res["c4_pipelined"] = {"dry_run": True}
+        res["c4_full"] = {"dry_run": True}
         res["c2_candidates_strong"] = {"dry_run": True}
         return res
     res["c4"] = plan_leg(local_rank, "halfcheetah", "rtg_guiding", 16384, 32, 64, steps=12, warm=3, settle=6, depth=0, group=grp,
                          what=f"BASELINE configs[3]: halfcheetah shapes rtg_guiding N=16384 H=32 T=64 bf16, candidates sharded over {world} "
                               f"ranks, one RCCL all-gather of scores + first actions per step, serial steps (strong scaling)")
+    # the same sharded step with two independent plan steps in flight (the all-gather stays on the current stream, the policy
+    # pass and the re-score + select of the neighbouring steps on the chain streams, as at one rank): the 1-GPU yardsticks are
+    # pipelined, so this is the leg a scaling figure has to be read from
+    res["c4_pipelined"] = plan_leg(local_rank, "halfcheetah", "rtg_guiding", 16384, 32, 64, steps=12, warm=3, settle=6, depth=2, group=grp,
+                                   what=f"BASELINE configs[3] as `c4`, two independent plan steps in flight")
+    # the denominator, same definition, same run: the WHOLE N=16384 step on ONE GPU (rank 0; the other ranks wait at the barrier)
+    if rank == 0:
+        try:
+            res["c4_full"] = c4_full_leg(local_rank)
+        except Exception as e:
+            res["c4_full"] = {"error": repr(e)[:300]}
+    torch.distributed.barrier(grp)
+    if rank == 0 and "error" not in res["c4_full"]:
+        for leg, key in (("c4", "serial_ms_per_step"), ("c4_pipelined", "ms_per_step")):
+            if "error" not in res[leg]:
+                res[leg]["scaling_eff"] = round(res["c4_full"][key] / (world * res[leg]["ms_per_step"]), 4)
+                res[leg]["scaling_eff_what"] = f"c4_full.{key} (one GPU, all 16384 candidates) / ({world} x this leg's ms_per_step)"
     res["c2_candidates_strong"] = plan_leg(local_rank, "hopper", "rtg_guiding", 1024, 16, 32, steps=20, warm=4, settle=12, depth=0, group=grp,
                                            what=f"the headline shape with its 1024 candidates sharded over {world} ranks (strong), one "
                                                 "RCCL all-gather per step, serial steps")
     return res
 
 
-def run_guarded(fn, timeout_s, on_timeout):
+def run_guarded(fn, timeout_s, on_timeout, abort_reason=None):
     """fn() with a watchdog: when it has not returned after timeout_s seconds (a collective that never completes cannot be
-    interrupted from Python), on_timeout() runs on the watchdog thread and the process ends with exit code 0 -- the
-    headline measurement is done by then and must not be lost with the side legs."""
+    interrupted from Python) -- or as soon as abort_reason() returns a message (a peer rank's failure) -- on_timeout(reason)
+    runs on the watchdog thread and the process ends with exit code 0: the headline measurement is done by then and must not
+    be lost with the side legs (the line carries "collective_legs_ok": false for whoever reads it)."""
     import threading
     done = threading.Event()
 
     def watch():
-        if not done.wait(timeout_s):
-            try:
-                on_timeout()
-            finally:
-                sys.stdout.flush()
-                os._exit(0)
+        t_end = time.monotonic() + timeout_s
+        reason = None
+        while not done.wait(1.0):
+            reason = abort_reason() if abort_reason is not None else None
+            if reason is not None or time.monotonic() >= t_end:
+                break
+        if done.is_set():
+            return
+        try:
+            on_timeout(reason or "timeout")
+        finally:
+            sys.stdout.flush()
+            os._exit(0)
 
     threading.Thread(target=watch, daemon=True).start()
     try:
@@ -866,7 +958,8 @@ def extras(args, dims, cfg, hist, planner, S, A):
                                                  what="BASELINE configs[2]: walker2d shapes critic_lambda_guiding N=4096 H=16 T=32 bf16")),
                          ("c4_shard", lambda: plan_leg(0, "halfcheetah", "rtg_guiding", 2048, 32, 64, steps=20, settle=12,
                                                        what="one rank's share of BASELINE configs[3] as a plan step of its own: halfcheetah "
-                                                            "shapes rtg_guiding, 2048 of the 16384 candidates, H=32 T=64 bf16"))):
+                                                            "shapes rtg_guiding, 2048 of the 16384 candidates, H=32 T=64 bf16")),
+                         ("c4_full", lambda: c4_full_leg(0))):
             try:
                 out[name] = fn()
             except Exception as e:

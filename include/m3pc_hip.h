@@ -370,7 +370,8 @@ int m3pc_select(m3pc_handle* h, const float* expect_return, const float* a0, lon
 /* kernel-level timing of the last plan_step for bench.py / profiling: when enabled the library
  * brackets the MFMA launches with hipEvents on the stream they run on.  enable = 2: in addition the two candidate
  * halves of a plan step (normally overlapped on two streams) run one after the other on `stream`, so that a
- * bracket holds that launch alone. */
+ * bracket holds that launch alone.  enable = 3: that ordering WITHOUT the event brackets (for an external kernel trace
+ * of every launch alone on the chip: rocprofv3 -- python3 bench.py --depth 0 --serial-halves). */
 int m3pc_profile_enable(m3pc_handle* h, int enable);
 /* sums since the last reset over the MFMA launches of one arithmetic (precision = M3PC_PREC_*, or -1 for
  * all) or over the fused layer-tail launches alone (M3PC_PROF_LAYER_TAIL: the dominant kernel, block_fused.hip):

@@ -3189,8 +3189,8 @@ int m3pc_debug_clock_big(long long* out4) {
 
 int m3pc_profile_enable(m3pc_handle* h, int enable) {
     if (!h) return fail(M3PC_EINVAL, "null handle");
-    h->prof = enable != 0;
-    h->prof_serial = enable == 2;
+    h->prof = enable == 1 || enable == 2;
+    h->prof_serial = enable == 2 || enable == 3;
     return 0;
 }
 

@@ -120,6 +120,11 @@ def plan_case(case, rank, world):
         torch.cuda.synchronize()
         out = dict(expect_return=p.last["expect_return"].cpu(), argmax=p.last["argmax"].cpu(), sample_idx=p.last["sample_idx"].cpu(),
                    eval_action=ev.cpu(), sample_action=sa.cpu(), n_rescored=p.last["n_rescored"], world=p.world)
+        # the sharded step with two plan steps in flight (bench.py's c4_pipelined leg): the gather stays on the current stream
+        tks = [p._issue(mode, s, a, r, rtg, h, 0.6, pipelined=True, inputs_ready=True) for _ in range(3)]
+        pairs = [tk.pair() for tk in tks]
+        torch.cuda.synchronize()
+        out["pipelined"] = torch.cat([torch.cat([x.reshape(-1), y.reshape(-1)]) for x, y in pairs]).cpu()
         p.handle.close()
         return out
 
@@ -127,7 +132,7 @@ def plan_case(case, rank, world):
         assert ref["world"] == 1
         got = plan(dist.group.WORLD, True)
         assert got["world"] == world
-        bad = [k for k in ("expect_return", "argmax", "sample_idx", "eval_action", "sample_action") if not torch.equal(ref[k], got[k])]
+        bad = [k for k in ("expect_return", "argmax", "sample_idx", "eval_action", "sample_action", "pipelined") if not torch.equal(ref[k], got[k])]
         if got["n_rescored"] != ref["n_rescored"]:
             bad.append("n_rescored")
         # a planner without an explicit generator must be refused when sharded (silent RNG divergence)

@@ -42,6 +42,7 @@ def test_multi_gpu_default_runs_the_collective_legs():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
     assert d["rccl_ranks_seen"] == 2 and "c4" in d and "c2_candidates_strong" in d
+    assert "c4_pipelined" in d and "c4_full" in d and d["collective_legs_ok"] is True  # 
 
 
 def test_a_hung_collective_leg_costs_its_entry_not_the_headline():
@@ -55,7 +56,20 @@ def test_a_hung_collective_leg_costs_its_entry_not_the_headline():
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d["c4"] == {"error": "timeout"} and d["n_gpus"] == 2 and d["steps"] == 5
+    assert d["c4"] == {"error": "timeout"} and d["n_gpus"] == 2 and d["steps"] == 5 and d["collective_legs_ok"] is False
+
+
+def test_a_rank_that_fails_in_a_leg_is_reported_at_once_with_its_message():
+    """one rank raises while setting up a leg (before any collective); the other ranks, which would sit in the
+    all-gather until the watchdog's limit, see its message in the rendezvous store and leave within seconds; the headline
+    line carries the message and "collective_legs_ok": false."""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--steps", "5", "--warmup", "1", "--collective-timeout", "200"], {"M3PC_BENCH_FAIL_LEG_RANK": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert time.time() - t0 < 90
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert d["collective_legs_ok"] is False and "injected leg failure" in d["c4"]["error"] and "rank 1" in d["c4"]["error"]
 
 
 def test_no_collective_legs_flag():
