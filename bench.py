@@ -233,7 +233,7 @@ def main():
     ap.add_argument("--candidates", type=int, default=1024, help="candidates per plan step (per GPU when sharded weakly)")
     ap.add_argument("--horizon", type=int, default=16)
     ap.add_argument("--traj-length", type=int, default=32)
-    ap.add_argument("--depth", type=int, default=2, help="independent plan steps in flight (0: the serial order)")
+    ap.add_argument("--depth", type=int, default=3, help="independent plan steps in flight (0: the serial order)")
     ap.add_argument("--rescore", default="bound", choices=["bound", "topk"],
                     help="fp32 re-score set: certified (every candidate that can still hold the arg-max; default) or a fixed top-k")
     ap.add_argument("--rescore-topk", type=int, default=16)
@@ -268,6 +268,9 @@ def main():
                          "kernel trace (profiles/r05_kernel_stats_alone.csv)")
     ap.add_argument("--no-certify-sample", action="store_true",
                     help="A/B switch: certify the arg-max only (round-4 behaviour), not the multinomial index of the sampled action")
+    ap.add_argument("--chain-mode", default="alternate", choices=["alternate", "split"],
+                    help="pipelined steps: a step's policy pass and re-score on the chain stream of its parity (alternate), or all "
+                         "policy passes on one stream and all re-scores on the other (split, rounds 3-4)")
     ap.add_argument("--race-min", type=int, default=0, help="race entries of a first re-score pass (0: the planner's default)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU (tests/test_bench_launch_cpu.py): the ranks meet over gloo and rank 0 prints a stub line")
@@ -334,6 +337,7 @@ def main():
                          precision=args.precision, rescore_topk=args.rescore_topk, device=local_rank, generator=gen,
                          rescore=args.rescore, **({"rescore_min": args.rescore_min} if args.rescore_min else {}), group=group,
                          certify_sample=not args.no_certify_sample, **({"race_min": args.race_min} if args.race_min else {}),
+                         chain_mode=args.chain_mode,
                          pipeline_depth=max(1, min(args.depth, capi.SLOTS - 1)))
     hist = synth.make_history(dims, 0 if (shard_cand or world == 1) else rank)  # env sharding: every rank its own environment
     hist["path_length"] = 500
@@ -625,13 +629,13 @@ def c4_full_leg(local_rank, steps=6):
     """BASELINE configs[3] at its full size on ONE GPU: halfcheetah shapes, rtg_guiding, N=16384, H=32, T=64 (about 60 GB of
     workspace): the single-GPU figure a candidate-sharded N-rank run of the same step divides by.  Serial and pipelined."""
     ser = plan_leg(local_rank, "halfcheetah", "rtg_guiding", 16384, 32, 64, steps=steps, warm=2, settle=4, depth=0)
-    pip = plan_leg(local_rank, "halfcheetah", "rtg_guiding", 16384, 32, 64, steps=steps, warm=2, settle=4, depth=2,
+    pip = plan_leg(local_rank, "halfcheetah", "rtg_guiding", 16384, 32, 64, steps=steps, warm=2, settle=4, depth=3,
                    what="BASELINE configs[3] on ONE GPU: halfcheetah shapes rtg_guiding, all N=16384 candidates, H=32 T=64 bf16")
     pip["serial_ms_per_step"] = ser["ms_per_step"]
     return pip
 
 
-def plan_leg(local_rank, env, guidance, N, H, T, steps=20, warm=4, settle=12, depth=2, group=None, what=""):
+def plan_leg(local_rank, env, guidance, N, H, T, steps=20, warm=4, settle=12, depth=3, group=None, what=""):
     """Another BASELINE plan-step shape on this GPU (or, with `group`, candidate-sharded over the ranks of this run): `steps`
     plan steps, `depth` in flight (0: serial -- a sharded step gathers on the current stream), with the F_alg-based MFMA fraction."""
     import types
@@ -746,8 +750,8 @@ def collective_legs(args, rank, local_rank, world):
     # the same sharded step with two independent plan steps in flight (the all-gather stays on the current stream, the policy
     # pass and the re-score + select of the neighbouring steps on the chain streams, as at one rank): the 1-GPU yardsticks are
     # pipelined, so this is the leg a scaling figure has to be read from
-    res["c4_pipelined"] = plan_leg(local_rank, "halfcheetah", "rtg_guiding", 16384, 32, 64, steps=12, warm=3, settle=6, depth=2, group=grp,
-                                   what=f"BASELINE configs[3] as `c4`, two independent plan steps in flight")
+    res["c4_pipelined"] = plan_leg(local_rank, "halfcheetah", "rtg_guiding", 16384, 32, 64, steps=12, warm=3, settle=6, depth=3, group=grp,
+                                   what=f"BASELINE configs[3] as `c4`, three independent plan steps in flight")
     # the denominator, same definition, same run: the WHOLE N=16384 step on ONE GPU (rank 0; the other ranks wait at the barrier)
     if rank == 0:
         try:

@@ -150,6 +150,7 @@ struct m3pc_handle {
     int* d_topk = nullptr;        // (1024,) candidate ids of the last top-k
     float* er_top = nullptr;      // (1024,) their fp32 re-scores
     float* sa_buf = nullptr;      // (max(max_candidates, max_rescore), h, A) scratch for m3pc_rescore
+    float* sa_chain[2] = {nullptr, nullptr};  // the same for re-scores that run in the chain workspaces (one per slot parity)
     float* splitk_ws = nullptr;   // raw split-K slabs of the few-row fp32 GEMMs
     long long splitk_ws_bytes = 0;
     // Step slots: the per-step state a plan step leaves behind its policy pass (loc / sd of the policy head, the normalised
@@ -166,7 +167,9 @@ struct m3pc_handle {
     // half by set_view().  `base` is the candidate workspace (max_candidates); the few-row fp32 chains run in two small ones of
     // their own -- `pchain` the policy pass (batch <= max_batch), `chain` the re-score (<= max_rescore candidates) -- so that a
     // policy pass, a re-score and a candidate pass of three different steps can be enqueued on three streams at the same time
-    // without sharing a buffer.
+    // without sharing a buffer.  There are TWO of each, picked by the parity of the step slot (m3pc_plan_args::slot & 1): the
+    // chains of consecutive steps may then run on two streams at the same time (m3pc_amd/planner.py: the policy pass and the
+    // re-score of a step on the stream of its parity) -- in the pipelined step the re-score chain of one stream was the bottleneck.
     struct Base {
         float *X = nullptr, *Y = nullptr, *EncOut = nullptr, *G = nullptr, *cand = nullptr, *pred[2] = {nullptr, nullptr},
               *qv = nullptr, *splitk_ws = nullptr;
@@ -174,7 +177,7 @@ struct m3pc_handle {
         long long splitk_ws_bytes = 0;
         long long R = 0;       // token rows
         int max_cand = 0;      // candidates (rows of cand / pred / qv)
-    } base, chain, pchain;
+    } base, chain[2], pchain[2];  // chain / pchain: one per step-slot parity (see below)
     Base* cur = nullptr;
     bool two_stream = true;       // candidate halves on two streams (M3PC_TWO_STREAM=0: one stream); measured -2.5 % step time on C2
     bool allow_splitk = true;     // see gemm(): off while sharded candidates are scored
@@ -258,8 +261,8 @@ void bind_ws(m3pc_handle* h, m3pc_handle::Base* b) {
 }
 struct WsScope {  // binds a chain workspace for the duration of a few-row fp32 pass
     m3pc_handle* h;
-    WsScope(m3pc_handle* h_, bool chain, bool policy = false) : h(h_) {
-        if (chain) bind_ws(h, policy ? &h->pchain : &h->chain);
+    WsScope(m3pc_handle* h_, bool chain, bool policy = false, int slot = 0) : h(h_) {
+        if (chain) bind_ws(h, policy ? &h->pchain[slot & 1] : &h->chain[slot & 1]);
     }
     ~WsScope() { bind_ws(h, &h->base); }
 };
@@ -1800,8 +1803,10 @@ int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out) {
         const int mr = D.max_rescore > 0 ? D.max_rescore : 64;
         long long R = (long long)mr * 2 * T;
         if (R < 4 * T) R = 4 * T;
-        CHK(alloc_ws(h.get(), h->chain, R, mr, 32LL << 20));
-        CHK(alloc_ws(h.get(), h->pchain, (long long)D.max_batch * 4 * T, 1, 32LL << 20));
+        for (int par = 0; par < 2; ++par) {
+            CHK(alloc_ws(h.get(), h->chain[par], R, mr, 32LL << 20));
+            CHK(alloc_ws(h.get(), h->pchain[par], (long long)D.max_batch * 4 * T, 1, 32LL << 20));
+        }
     }
     for (int s = 0; s < M3PC_SLOTS; ++s) {
         CHK(dmalloc(&h->slot[s].loc, (size_t)D.max_batch * T * h->A + 64));
@@ -1811,7 +1816,9 @@ int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out) {
     CHK(dmalloc(&h->sel_scratch, 64));
     CHK(dmalloc(&h->d_topk, 1024));
     CHK(dmalloc(&h->er_top, 1024));
-    CHK(dmalloc(&h->sa_buf, (size_t)(D.max_candidates > h->chain.max_cand ? D.max_candidates : h->chain.max_cand) * T * h->A));
+    CHK(dmalloc(&h->sa_buf, (size_t)(D.max_candidates > h->chain[0].max_cand ? D.max_candidates : h->chain[0].max_cand) * T * h->A));
+    CHK(dmalloc(&h->sa_chain[0], (size_t)h->chain[0].max_cand * T * h->A));
+    CHK(dmalloc(&h->sa_chain[1], (size_t)h->chain[0].max_cand * T * h->A));
     bind_ws(h.get(), &h->base);
     bind_slot(h.get(), 0);
     // ONE extra stream per device for all handles of the process: a process has four hardware queues, and with more
@@ -1887,14 +1894,16 @@ int m3pc_destroy(m3pc_handle* h) {
     }
     hipFree(h->mask_tokens);
     free_ws(h->base);
-    free_ws(h->chain);
-    free_ws(h->pchain);
+    for (int par = 0; par < 2; ++par) {
+        free_ws(h->chain[par]);
+        free_ws(h->pchain[par]);
+    }
     for (int s = 0; s < M3PC_SLOTS; ++s) {
         hipFree(h->slot[s].loc);
         hipFree(h->slot[s].sd);
         hipFree(h->slot[s].rtok);
     }
-    void* bufs[] = {h->sel_scratch, h->d_topk, h->er_top, h->sa_buf, h->c_om, h->c_os, h->goal_ws};
+    void* bufs[] = {h->sel_scratch, h->d_topk, h->er_top, h->sa_buf, h->sa_chain[0], h->sa_chain[1], h->c_om, h->c_os, h->goal_ws};
     for (size_t i = 1; i < h->auxs.size(); ++i) {
         hipStreamDestroy(h->auxs[i]);
         hipEventDestroy(h->ev_joins[i]);
@@ -2386,7 +2395,7 @@ int m3pc_policy_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* state
     h->allow_splitk = true;
     int rc;
     {
-        WsScope ws(h, true, true);
+        WsScope ws(h, true, true, a->slot);
         rc = forward_impl(h, pl, in, 1, nullptr, nullptr, nullptr, h->loc, h->sd, DT_F32, st);
     }
     h->allow_splitk = false;
@@ -2558,7 +2567,7 @@ int m3pc_score_actions(m3pc_handle* h, const m3pc_plan_args* a, int n_windows, c
     if (a->horizon < 1 || a->horizon > T) return fail(M3PC_EINVAL, "horizon %d outside [1, T=%d]", a->horizon, T);
     if (a->mode != M3PC_MODE_RTG && a->mode != M3PC_MODE_CRITIC) return fail(M3PC_EINVAL, "mode must be RTG or CRITIC scoring");
     if (a->precision != M3PC_PREC_FP32 && a->precision != M3PC_PREC_BF16) return fail(M3PC_EINVAL, "bad precision");
-    if (n < 1 || (n > h->dm.max_candidates && !(a->precision == M3PC_PREC_FP32 && n <= h->chain.max_cand)))
+    if (n < 1 || (n > h->dm.max_candidates && !(a->precision == M3PC_PREC_FP32 && n <= h->chain[0].max_cand)))
         return fail(M3PC_ENOMEM, "n_count %d outside [1, max_candidates=%d]", n, h->dm.max_candidates);
     if (n_windows < 1 || (n_windows > 1 && !window_index)) return fail(M3PC_EINVAL, "n_windows > 1 needs window_index");
     if (a->mode == M3PC_MODE_CRITIC && !h->critic_set) return fail(M3PC_ESTATE, "critic weights not set");
@@ -2566,7 +2575,7 @@ int m3pc_score_actions(m3pc_handle* h, const m3pc_plan_args* a, int n_windows, c
     HIPCHK(hipSetDevice(h->device));
     const int dt = a->precision == M3PC_PREC_BF16 ? DT_BF16 : DT_F32;
     // few-row fp32 calls (the re-score of a batched plan) run in the chain workspace, like m3pc_rescore
-    WsScope ws(h, dt == DT_F32 && n <= h->chain.max_cand);
+    WsScope ws(h, dt == DT_F32 && n <= h->chain[0].max_cand, false, a->slot);
     if (h->cur == &h->base) CHK(ws_sync(h, st));
     SampleP sp;
     memset(&sp, 0, sizeof(sp));
@@ -2623,7 +2632,7 @@ int m3pc_policy_pass_batch(m3pc_handle* h, const m3pc_plan_args* a, int n_window
     in.bstride[M3PC_RETURNS] = T;
     h->allow_splitk = true;
     {
-        WsScope ws(h, true, true);
+        WsScope ws(h, true, true, a->slot);
         const int rc = forward_impl(h, pl, in, E, nullptr, nullptr, nullptr, h->loc, h->sd, DT_F32, st);
         h->allow_splitk = false;
         if (rc) return rc;
@@ -2684,16 +2693,16 @@ int m3pc_rescore(m3pc_handle* h, const m3pc_plan_args* a, const float* states, c
     const int T = h->T;
     if (a->horizon < 1 || a->horizon > T || a->mode < 0 || a->mode > 2) return fail(M3PC_EINVAL, "bad horizon/mode");
     // runs in the chain workspace when it fits (so that it can be enqueued beside a candidate pass), else in the candidate one
-    const bool in_chain = n <= h->chain.max_cand;
+    const bool in_chain = n <= h->chain[0].max_cand;
     if (n < 1 || (!in_chain && n > h->dm.max_candidates))
-        return fail(M3PC_ENOMEM, "n %d outside [1, max(max_rescore=%d, max_candidates=%d)]", n, h->chain.max_cand, h->dm.max_candidates);
+        return fail(M3PC_ENOMEM, "n %d outside [1, max(max_rescore=%d, max_candidates=%d)]", n, h->chain[0].max_cand, h->dm.max_candidates);
     if (a->mode != M3PC_MODE_RTG && !h->critic_set) return fail(M3PC_ESTATE, "critic weights not set");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->device));
     bind_slot(h, a->slot);
-    WsScope ws(h, in_chain);
+    WsScope ws(h, in_chain, false, a->slot);
     if (!in_chain) CHK(ws_sync(h, st));
-    float* sa = sample_actions ? sample_actions : h->sa_buf;
+    float* sa = sample_actions ? sample_actions : (in_chain ? h->sa_chain[a->slot & 1] : h->sa_buf);
     SampleP sp;
     memset(&sp, 0, sizeof(sp));
     sp.hist_actions = actions;
@@ -2720,7 +2729,7 @@ int m3pc_rescore_topk(m3pc_handle* h, const m3pc_plan_args* a, const float* stat
                       const float* rewards, const float* eps, float* expect_return, int k, int* topk_index, void* stream) {
     if (!h || !a || !expect_return) return fail(M3PC_EINVAL, "null argument");
     if (a->n_total < 1 || a->n_total > 16384) return fail(M3PC_EINVAL, "top-k supports n_total <= 16384");
-    if (k < 1 || k > a->n_total || (k > h->dm.max_candidates && k > h->chain.max_cand) || k > 1024)
+    if (k < 1 || k > a->n_total || (k > h->dm.max_candidates && k > h->chain[0].max_cand) || k > 1024)
         return fail(M3PC_EINVAL, "k %d outside [1, min(n_total, max(max_candidates, max_rescore), 1024)]", k);
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->device));

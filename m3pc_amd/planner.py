@@ -128,8 +128,9 @@ class HipPlanner:
                  n_dec_layer: int = 1, precision: str = "fp32", rescore_topk: int = 16, device: Optional[int] = None,
                  group=None, generator: Optional[torch.Generator] = None, max_batch: int = 1,
                  rescore: str = "bound", rescore_min: int = 8, rescore_max: int = 128, rescore_delta: Optional[float] = None,
-                 max_windows: int = 1, pipeline_depth: int = 2, chain_priority: int = -1, tail_stream: bool = True,
-                 defer_join: bool = True, goal_batch: int = 0, race_min: int = 2, calibration_windows: int = 3, certify_sample: bool = True):
+                 max_windows: int = 1, pipeline_depth: int = 3, chain_priority: int = -1, tail_stream: bool = True,
+                 defer_join: bool = True, goal_batch: int = 0, race_min: int = 2, calibration_windows: int = 3, certify_sample: bool = True,
+                 chain_mode: str = "alternate"):
         """cfg: any object with traj_length, action_samples, horizon, discount, temperature, lmbda,
         plan_guidance (finetune.py RunConfig fields read at learner.py:276,319,342).
         tokenizer_manager: a TokenizerManager (this package's) or {key: {"mean","std","min","max"}}.
@@ -217,7 +218,16 @@ class HipPlanner:
         self._tail_stream = bool(tail_stream)
         self._defer_join = bool(defer_join)  # pipelined steps: the step's tail, not the current stream, joins the candidate parts
         self._chain_priority = int(chain_priority)  # -1: high priority -- its short dependent launches go first when a CU frees up
-        self._pending = None        # pipelined ticket whose tail (re-score + select) is not enqueued yet
+        self._pending = []          # pipelined tickets whose tail (re-score + select) is not enqueued yet, oldest first
+        # How the two chain streams of the process are used by pipelined steps.
+        #   "alternate" (default): a step runs BOTH its fp32 chains -- its policy pass and, two issues later, its re-score +
+        #     select -- on the stream of its slot's parity, in the library's chain workspaces of that parity: per stream
+        #     policy(t+2) | tail(t) | policy(t+4) | tail(t+2) ...; the chains of consecutive steps overlap.
+        #   "split" (rounds 3-4): every policy pass on one stream, every tail on the other.  Measured (r5, pipeline_phases.py): a
+        #     tail takes ~1.15 ms beside the candidate passes (0.37 ms alone), the tails of consecutive steps queue on their one
+        #     stream back to back, and that stream -- not the candidate passes (1.04 ms + gaps) -- set the step rate.
+        assert chain_mode in ("alternate", "split")
+        self._alternate = chain_mode == "alternate"
         self._warned_saturated = False
         self.delta_grown = 0        # how often the per-step deviation check raised delta since the last weight load
         self.action_list = []       # zero-shot "piid_allout" (action_piid_list_sample)
@@ -338,7 +348,8 @@ class HipPlanner:
         """The multinomial's exponentials (ATen's own algorithm: argmax(p / q), q ~ Exp(1))."""
         return torch.empty((int(self.cfg.action_samples),), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
 
-    def _chain_stream(self):
+    def _chain_streams(self):
+        """(stream 0, stream 1) of this device and priority, shared by every planner of the process."""
         if self._chain is None:
             # one pair of streams per (device, priority) for every planner of the process: the device gives a process four
             # hardware queues (current stream, the library's stream for the second candidate half, these two) -- with more
@@ -349,7 +360,15 @@ class HipPlanner:
                                        torch.cuda.Stream(device=self.device, priority=self._chain_priority))
             self._chain, t = _CHAIN_STREAMS[key]
             self._tchain = t if self._tail_stream else self._chain
-        return self._chain
+        return self._chain, self._tchain
+
+    def _streams_of(self, sl):
+        """(policy-pass stream, tail stream) of the pipelined step that owns slot ``sl`` (see ``chain_mode``)."""
+        a, b = self._chain_streams()
+        if self._alternate and self._tail_stream:
+            c = (a, b)[sl.i & 1]
+            return c, c
+        return a, b
 
     def _acquire_slot(self):
         sl = self._slots[self._next_slot]
@@ -398,9 +417,9 @@ class HipPlanner:
         tk.index, self._step_index = self._step_index, self._step_index + 1
         tk.grow_in, tk.kfirst_in, tk.rfirst_in = self._adapt(tk.index)
         main = torch.cuda.current_stream(self.device)
-        chain = self._chain_stream() if pipelined else None
+        chain, tchain = self._streams_of(sl) if pipelined else (None, None)
         tk.chain = chain
-        tk.tchain = self._tchain if pipelined else None
+        tk.tchain = tchain
         hd = self.handle
         # what the caller gets back (and the re-score's merged vector / candidate list) lives in the CURRENT stream's memory
         # pool: the caller consumes it there, so that is where its blocks must be recycled
@@ -429,6 +448,13 @@ class HipPlanner:
             tk.expo = sl.expo_buf.exponential_(1, generator=self.generator) if chain is not None else self._draw_expo()
             if chain is not None:
                 sl.ev_pol.record(chain)
+        if chain is not None and self._alternate:
+            # alternate mode: this stream's order is policy(t) | tail(t-2) | policy(t+2) | tail(t): the tail of the step two
+            # issues back (same parity, its candidate pass is enqueued long since) goes behind this step's policy pass, so that
+            # the policy pass -- which the candidate pass of THIS step waits for -- is not held up by it
+            for old in [o for o in self._pending if o.tchain is chain]:
+                self._pending.remove(old)
+                self._enqueue_tail(old)
         if chain is not None:
             main.wait_event(sl.ev_pol)
         begin, count = mdist.shard_range(N, self.rank, self.world)
@@ -446,9 +472,11 @@ class HipPlanner:
         tk.res, tk.er_b, tk.a0 = res, er, a0
         if chain is not None:
             sl.ev_cand.record(main)
-            prev, self._pending = self._pending, tk
-            if prev is not None and not prev.tail_enqueued:
-                self._enqueue_tail(prev)
+            if not self._alternate:  # split mode: step t's tail goes out with step t+1, behind that step's policy pass
+                for old in self._pending:
+                    self._enqueue_tail(old)
+                self._pending = []
+            self._pending.append(tk)
         else:
             self._enqueue_tail(tk)
             self._mark_main()
@@ -534,8 +562,7 @@ class HipPlanner:
             return tk.out
         cfg, hd, sl = self.cfg, self.handle, tk.slot
         if not tk.tail_enqueued:
-            if self._pending is tk:
-                self._pending = None
+            self._pending = [o for o in self._pending if o is not tk]
             self._enqueue_tail(tk)
         extra = {}
         top = None
@@ -875,10 +902,11 @@ class HipPlanner:
         h, return_to_go = self._window_host(sequence_history, rtg, percentage, sl.win_np)
         # copied on the CHAIN stream: the current stream is in order behind the previous step's candidate pass, the chain
         # stream is not
-        with torch.cuda.stream(self._chain_stream()) as _:
-            self._chain.wait_event(sl.ev_done)  # (the slot's previous owner has finished with the slot's device buffers)
+        chain = self._streams_of(sl)[0]
+        with torch.cuda.stream(chain) as _:
+            chain.wait_event(sl.ev_done)  # (the slot's previous owner has finished with the slot's device buffers)
             dev = sl.win_dev.copy_(sl.win, non_blocking=True)
-            sl.ev_h2d.record(self._chain)
+            sl.ev_h2d.record(chain)
         states, actions, rewards = self._blocks(dev)
         tk = self._issue(_MODES[guidance], states, actions, rewards, return_to_go, h, lmbda, pipelined=True, slot=sl,
                          inputs_ready=True)
@@ -888,9 +916,10 @@ class HipPlanner:
 
     def flush(self):
         """Enqueue whatever a pipelined step still holds back (the tail of the last ticket)."""
-        if self._pending is not None and not self._pending.tail_enqueued:
-            tk, self._pending = self._pending, None
-            self._enqueue_tail(tk)
+        pend, self._pending = self._pending, []
+        for tk in pend:
+            if not tk.tail_enqueued:
+                self._enqueue_tail(tk)
 
     @torch.no_grad()
     def action_sample_batch(self, sequence_histories, percentage=1.0, eval=False, rtg=None, lockstep: bool = False):
