@@ -198,7 +198,12 @@ int m3pc_goal_step(m3pc_handle* h, int batch, const float* states, const float* 
  *              M3PC_GOAL_ID:   action_id_sample (learner.py:60-149), one forward under the gid mask (masks.py:50-69)
  *   precision  M3PC_PREC_BF16: bf16 MFMA kernels of the candidate pass (fused layer tails); M3PC_PREC_FP32: fp32 MFMA.
  *              Either way a window's result does not depend on which other windows share the call, as long as the
- *              batch sizes fall in the same kernel regime (environment sharding: no collective).
+ *              batch sizes fall in the same kernel regime (environment sharding: no collective).  fp32: bit-identical at any
+ *              batch size.  bf16: bit-identical between calls of the same regime; the regime boundaries are >= 2048 windows
+ *              (the call runs as two parts on two streams), >= 12288 token rows per pass (fused layer tails; below: the
+ *              split / GEMM forms), >= 64 windows (two short windows per attention tile) and >= 1024 (window, head) items
+ *              (pipelined attention) -- a remainder shard that crosses one agrees with the unsharded call to the bf16
+ *              tolerance (|d loc| <= 3e-2), not bit for bit; shard evenly, or use fp32, where bits must match.
  *   window_states  device out (E,T,S), optional: the observation rows the inverse-dynamics forward saw
  *   out_mu/out_std device out (E,A): DiagGaussianActor loc / std at token idx (mtm_model.py:313-321)
  * Runs in the candidate workspace. */

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libm3pc_hip.so")
 SOURCES = ["gemm.hip", "gemm_glds.hip", "gemm_big.hip", "gemm_line.hip", "gemm_f32_direct.hip", "block_fused.hip", "attn.hip",
-           "attn_bf16.hip", "elementwise.hip", "select.hip", "m3pc.hip"]
+           "attn_bf16.hip", "elementwise.hip", "select.hip", "m3pc_plans.hip", "m3pc_passes.hip", "m3pc.hip"]
 # the lab build (libm3pc_hip_lab.so, `python -m m3pc_amd.build --lab`, used by tools/ with M3PC_LIB=...): adds the experimental
 # GEMM tilings, the timing variants of block_fused.hip and the M3PC_GEMM_VARIANT environment override (-DM3PC_LAB)
 LAB_SOURCES = ["gemm_ring.hip", "gemm_persist.hip", "gemm_rs.hip"]
@@ -38,7 +38,7 @@ def _stale(target: str, deps) -> bool:
 
 def build_library(force: bool = False, verbose: bool = False, lab: bool = False) -> str:
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, n) for n in ("kernels.h", "gemm_epilogue.h", "gemm_stage_asm.h", "exports.map")] + \
+    headers = [os.path.join(CSRC, n) for n in ("kernels.h", "gemm_epilogue.h", "gemm_stage_asm.h", "m3pc_internal.h", "exports.map")] + \
               [os.path.join(os.path.dirname(HERE), "include", n) for n in ("m3pc_hip.h", "m3pc_hip_debug.h")]
     objdir = os.path.join(CSRC, "build_lab" if lab else "build")
     os.makedirs(objdir, exist_ok=True)

@@ -461,10 +461,12 @@ template <typename T, int HDT>
 static void launch_split(const AttnP& p, hipStream_t st) {
     constexpr int ROWF = HDT * 32 + 4;
     const size_t smem = (size_t)(5 * 32 * ROWF + 256) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};  // (> 64 KiB of dynamic LDS needs the opt-in once per kernel AND device)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void*)attn_split_kernel<T, HDT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set[dev] = true;
     }
     dim3 grid(p.batch, p.n_head, (p.Lq + 31) / 32), block(256);
     hipLaunchKernelGGL((attn_split_kernel<T, HDT>), grid, block, smem, st, p);
@@ -472,10 +474,12 @@ static void launch_split(const AttnP& p, hipStream_t st) {
 
 template <typename T, int HDT, int NCH>
 static void launch_nch(const AttnP& p, dim3 grid, dim3 block, size_t smem, hipStream_t st) {
-    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-    if (!attr_set) {
+    static bool attr_set[64] = {};  // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void*)attn_kernel<T, HDT, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL((attn_kernel<T, HDT, NCH>), grid, block, smem, st, p);
 }

@@ -1107,14 +1107,27 @@ __global__ __launch_bounds__(192, 1) void attn_bf16_pipe_mix_kernel(AttnP p, int
     }
 #endif
 }
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE opt-in: cached per (kernel, device) -- a process with handles on two
+// GPUs must set it on both (a process-wide flag left the second device without it, and its large-LDS launches failed
+// instead of falling back to the direct kernel).
+template <typename K>
+static bool lds_opt_in(K kernel, int bytes) {
+    static bool done[64] = {}, ok[64] = {};  // (one pair of tables per kernel instantiation)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (!done[dev]) {
+        ok[dev] = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+        done[dev] = true;
+    }
+    return ok[dev];
+}
 template <int N1, int N2>
 static bool launch_pipe_mix(const AttnP& p, hipStream_t st) {
     const int n_items = p.batch * p.n_head;
     const int grid = n_items < 256 ? n_items : 256;
     constexpr int LDSB = 2 * ((N2 + 3) / 4) * 1024 + 4 * (2 * APIPE_IMG + 1024);
     static_assert(LDSB <= 160 * 1024, "LDS");
-    static const bool attr_ok = hipFuncSetAttribute((const void*)attn_bf16_pipe_mix_kernel<N1, N2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess;
-    if (!attr_ok) return false;
+    if (!lds_opt_in(attn_bf16_pipe_mix_kernel<N1, N2>, LDSB)) return false;
     hipLaunchKernelGGL((attn_bf16_pipe_mix_kernel<N1, N2>), dim3(grid), dim3(192), LDSB, st, p, n_items);
     return true;
 }
@@ -1122,9 +1135,7 @@ template <int N1>
 static bool launch_pipe_dec(const AttnP& p, hipStream_t st) {
     const int n_items = p.batch * p.n_head;
     const int grid = n_items < 256 ? n_items : 256;  // one workgroup per CU (4 x 26 KB of K|V buffers); a multiple of the 4 heads
-    static const bool attr_ok = hipFuncSetAttribute((const void*)attn_bf16_pipe_dec_kernel<N1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    8 * APIPE_IMG) == hipSuccess;
-    if (!attr_ok) return false;
+    if (!lds_opt_in(attn_bf16_pipe_dec_kernel<N1>, 8 * APIPE_IMG)) return false;
     hipLaunchKernelGGL((attn_bf16_pipe_dec_kernel<N1>), dim3(grid), dim3(192), 8 * APIPE_IMG, st, p, n_items);
     return true;
 }
@@ -1138,9 +1149,7 @@ static bool launch_pipe(const AttnP& p, hipStream_t st) {
 #endif
     cap -= cap % p.n_head;
     const int grid = n_items < cap ? n_items : cap;
-    static const bool attr_ok = hipFuncSetAttribute((const void*)attn_bf16_pipe_kernel<N1, SH>,
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * APIPE_BUF) == hipSuccess;
-    if (!attr_ok) return false;  // (78 KB of dynamic LDS refused: the direct kernel takes the launch)
+    if (!lds_opt_in(attn_bf16_pipe_kernel<N1, SH>, 2 * APIPE_BUF)) return false;  // (78 KB of dynamic LDS refused: the direct kernel takes the launch)
     size_t lds_bytes = 2 * APIPE_BUF;
 #ifdef M3PC_LAB  // (occupancy experiment: a smaller allocation than the kernel uses -- out-of-range LDS accesses are dropped -- timing only)
     static const int env_lds = M3PC_ENV("M3PC_ATTN_PIPE_LDS") ? atoi(M3PC_ENV("M3PC_ATTN_PIPE_LDS")) : 0;

@@ -1418,7 +1418,9 @@ bool launch_kv_fused(const KvFusedP& p, hipStream_t st) {
     return true;
 }
 
-bool launch_block_fused(const BlockP& p, hipStream_t st) {
+// Everything launch_block_fused checks before it launches: a caller that has to commit to the fused tail EARLIER than the launch
+// (pruned_decoder's `mixp` path lays its inputs out for this kernel) asks here first.
+bool block_fused_accepts(const BlockP& p) {
     if (p.M <= 0) return true;
     if (((uintptr_t)p.O & 15) || (p.ldo % 8) || ((uintptr_t)p.wstream & 1023)) return false;
     if (!p.rowtab && (((uintptr_t)p.res & 15) || (p.ldr % 4) || (unsigned long long)p.M * p.ldr * 4 >= 0xfffffff0ull)) return false;  // (32-bit buffer offsets)
@@ -1440,6 +1442,12 @@ bool launch_block_fused(const BlockP& p, hipStream_t st) {
     if (p.split) {  // four workgroups per tile, fp32 partials to four slabs of M rows behind Xout (block_split_reduce sums them)
         if (p.Hout || p.QKVout || p.head_out[0] || !p.Xout || p.Xout == p.res || p.res_L > 0) return false;
     }
+    return true;
+}
+
+bool launch_block_fused(const BlockP& p, hipStream_t st) {
+    if (p.M <= 0) return true;
+    if (!block_fused_accepts(p)) return false;
     const dim3 grid((p.M + 127) / 128), block(256);
 #ifdef M3PC_LAB  // timing experiments (tools/block_bench.py): the lab build only
     if (p.variant == 1) hipLaunchKernelGGL((block_fused_kernel<1, 0>), grid, block, 0, st, p);

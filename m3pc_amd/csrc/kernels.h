@@ -136,6 +136,7 @@ void launch_pack_block_stream(const bf16_t* Wo, const bf16_t* W1, const bf16_t* 
 void launch_pack_block_qkv(const bf16_t* Wqkv_next, bf16_t* out, hipStream_t st);
 void launch_pack_block_heads(const bf16_t* Wh0, const bf16_t* Wh1, bf16_t* out, hipStream_t st);  // or: the two scalar heads' Linear(512,512)  // behind them: the next layer's in_proj
 bool launch_block_fused(const BlockP& p, hipStream_t st);  // false: arguments not covered (caller takes the unfused path)
+bool block_fused_accepts(const BlockP& p);                 // the same checks without the launch
 struct SplitReduceP {       // behind launch_block_fused(split = 1): x = sum of the slabs -> Xout; LN_B?(LN_A(x)) -> Hout
     const float* slabs;     // (block_split_n(), M, 512) fp32
     int M;

@@ -11,1720 +11,20 @@
 // Candidate pass ("pass 2", learner.py:288-293) is exactly pruned: decoder rows of masked tokens do not
 // depend on the candidate, so only the 2h scored tokens are pushed through out-proj/FFN/heads and only the
 // un-masked tokens through the K/V projection.
-#include <math.h>
-#include <stdarg.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
+#include "m3pc_internal.h"
 
-#include <map>
-#include <mutex>
-#include <memory>
-#include <string>
-#include <vector>
-
-#include "../../include/m3pc_hip.h"
-#ifdef M3PC_LAB
-#include "../../include/m3pc_hip_debug.h"
-#endif
-#include "kernels.h"
-
-using namespace m3pc;
-
-static thread_local char g_err[512] = "";
-static int fail(int code, const char* fmt, ...) {
+namespace m3pc {
+thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
 }
-#define HIPCHK(x)                                                                                     \
-    do {                                                                                              \
-        hipError_t e_ = (x);                                                                          \
-        if (e_ != hipSuccess) return fail(M3PC_EHIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-#define CHK(x)               \
-    do {                     \
-        int rc_ = (x);       \
-        if (rc_ != 0) return rc_; \
-    } while (0)
-
-static const char* KEYN[4] = {"states", "actions", "rewards", "returns"};
+}  // namespace m3pc
 
 namespace {
-
-struct Tensor {
-    float* f = nullptr;    // fp32 device
-    bf16_t* b = nullptr;   // bf16 copy (GEMM weights only)
-    long long numel = 0;
-    bool gemm = false;
-    bool loaded = false;
-};
-
-struct SharedTables {  // candidate-independent decoder quantities of one plan, one precision
-    bool valid = false;
-    float* Yall = nullptr;   // (4T, d)  decoder inputs with mask tokens everywhere a token is masked
-    void* QKVm = nullptr;    // (Lm, 3d) q|k|v of masked tokens (operand dtype)
-    void* QKVq = nullptr;    // (nq, 3d) rows of the scored tokens (valid when they are all masked)
-    float* Yq = nullptr;     // (nq, d)  decoder inputs of the scored tokens
-    // softmax block of the (shared) queries against the masked tokens' keys, pre-reduced (AttnP::pre_m/l/O); bf16 only
-    float *pre_m = nullptr, *pre_l = nullptr, *pre_O = nullptr;
-};
-
-constexpr int N_QUERY = 4;
-struct Plan {
-    std::string key;
-    int T = 0, Le = 0, Lm = 0;
-    int kept[4] = {0, 0, 0, 0}, enc_off[4] = {0, 0, 0, 0};
-    bool prefix[4] = {true, true, true, true};
-    std::vector<int> dec_src;    // (4T) encoder index or -1
-    std::vector<int> masked;     // decoder indices of masked tokens
-    int2* d_tokmap = nullptr;    // (Le)
-    int* d_dec_rowsrc = nullptr; // (4T): enc row, or -(key)-1 -> mask token table
-    int* d_masked_rowsrc = nullptr;  // (Lm): -(i)-1 rows of a (4T, *) table
-    // decoder position tables of the kept tokens of key k, (kept[k], d): h->Edec[k] itself when the kept set is the prefix
-    // 0..kept-1 (every finetune mask), else the kept rows gathered (the zero-shot pi mask keeps states 0..idx and T-1)
-    const float* edec_kept[4] = {nullptr, nullptr, nullptr, nullptr};
-    float* edec_own[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool edec_valid = false;
-    // query sets of the pruned decoder: the decoder tokens whose outputs the caller reads, n_groups groups of grp tokens
-    // per batch element, group s = tokens of key qkeys[s]
-    struct Query {
-        bool built = false;
-        int nq = 0, h = 0;
-        int n_groups = 2, grp = 0;
-        int qkeys[2] = {0, 0};
-        bool all_masked = true;
-        // nu > 0: the un-masked query tokens are exactly the first nu queries, consecutive tokens of ONE key whose encoder rows
-        // are consecutive too (critic_lambda_guiding: states[idx]; goal path inference: states[0..idx]) -- the decoder then
-        // builds per-sequence rows for those nu queries only and takes the others from the shared tables
-        int nu = 0, nu_key = 0, nu_enc0 = 0, nu_kept0 = 0;
-        int* d_q_rowsrc_tab = nullptr;  // (nq): -(i)-1 rows of (4T,*) tables
-        int* d_q_rowsrc_mix = nullptr;  // (nq): enc row or -(i)-1 rows of Yall
-        SharedTables tab[2];
-    } query[N_QUERY];  // index: 0 rtg (rewards, returns), 1 critic (states, rewards), 2 goal path inference (the state rows the
-                       // overlay reads), 3 goal inverse dynamics (the action token at idx)
-};
-
-struct EventPair {
-    hipEvent_t a, b;
-    double flops;
-    int dt;
-    int kind;  // 0: GEMM launch, 1: fused layer tail (block_fused_kernel), 2: fused decoder input (kv_fused_kernel)
-};
-
-}  // namespace
-
-struct m3pc_handle {
-    m3pc_dims dm;
-    int device = 0;
-    int d = 0, nh = 0, hd = 0, T = 0, S = 0, A = 0, ff = 0, feat[4] = {0, 0, 0, 0};
-    std::map<std::string, Tensor> w;
-    bool weights_loaded = false;
-    long long load_stats[4] = {0, 0, 0, 0};  // last m3pc_load_weights: tensors copied, layer-tail streams packed, kv streams packed, tables invalidated
-    // derived tables
-    float* WT[4] = {nullptr, nullptr, nullptr, nullptr};
-    float* Eenc[4] = {nullptr, nullptr, nullptr, nullptr};
-    float* Edec[4] = {nullptr, nullptr, nullptr, nullptr};
-    float* mask_tokens = nullptr;  // (4, d)
-    // tokenizer
-    bool tok_set[4] = {false, false, false, false};
-    int tok_norm[4] = {0, 0, 0, 0};
-    float* tok_mean[4] = {nullptr, nullptr, nullptr, nullptr};
-    float* tok_std[4] = {nullptr, nullptr, nullptr, nullptr};
-    std::vector<float> h_mean[4], h_std[4];
-    // critic
-    bool critic_set = false;
-    float *cW1T[2] = {nullptr, nullptr}, *cb1[2] = {nullptr, nullptr}, *cW2T[2] = {nullptr, nullptr},
-          *cb2[2] = {nullptr, nullptr}, *cW3[2] = {nullptr, nullptr}, *cb3[2] = {nullptr, nullptr};
-    float *cW1F[2] = {nullptr, nullptr}, *cW2F[2] = {nullptr, nullptr};  // MFMA operand order (critic_pack)
-    float *c_om = nullptr, *c_os = nullptr;
-    // workspace
-    long long R = 0;
-    float *X = nullptr, *Y = nullptr, *EncOut = nullptr, *G = nullptr;
-    void *Hn = nullptr, *QKV = nullptr, *O = nullptr, *F = nullptr, *Z = nullptr;
-    float *cand = nullptr, *loc = nullptr, *sd = nullptr, *rtok = nullptr, *pred[2] = {nullptr, nullptr}, *qv = nullptr;
-    float* sel_scratch = nullptr;
-    float* goal_ws = nullptr;     // (max_goal_batch, T, S) the window rows the second forward of m3pc_goal_step_batch sees
-    int* d_topk = nullptr;        // (1024,) candidate ids of the last top-k
-    float* er_top = nullptr;      // (1024,) their fp32 re-scores
-    float* sa_buf = nullptr;      // (max(max_candidates, max_rescore), h, A) scratch for m3pc_rescore
-    float* sa_chain[2] = {nullptr, nullptr};  // the same for re-scores that run in the chain workspaces (one per slot parity)
-    float* splitk_ws = nullptr;   // raw split-K slabs of the few-row fp32 GEMMs
-    long long splitk_ws_bytes = 0;
-    // Step slots: the per-step state a plan step leaves behind its policy pass (loc / sd of the policy head, the normalised
-    // returns tokens).  A pipelined caller (m3pc_policy_pass of step t+1 on one stream beside m3pc_candidate_pass of step t on
-    // another, the fp32 re-score of step t after it) gives every step in flight its own slot (m3pc_plan_args::slot);
-    // loc / sd / rtok above are VIEWS of the slot bound last (bind_slot).
-    struct Slot {
-        float *loc = nullptr, *sd = nullptr, *rtok = nullptr;
-        bool policy_valid = false;  // loc / sd / rtok hold a single-window policy pass (what m3pc_rescore needs)
-        int n_windows = 0;          // policy heads the slot holds (m3pc_policy_pass: 1, m3pc_policy_pass_batch: E)
-    } slot[M3PC_SLOTS];
-    int cur_slot = 0;
-    // Workspaces.  The pointers above (X ... splitk_ws) are VIEWS of the workspace bound last (bind_ws), re-based per candidate
-    // half by set_view().  `base` is the candidate workspace (max_candidates); the few-row fp32 chains run in two small ones of
-    // their own -- `pchain` the policy pass (batch <= max_batch), `chain` the re-score (<= max_rescore candidates) -- so that a
-    // policy pass, a re-score and a candidate pass of three different steps can be enqueued on three streams at the same time
-    // without sharing a buffer.  There are TWO of each, picked by the parity of the step slot (m3pc_plan_args::slot & 1): the
-    // chains of consecutive steps may then run on two streams at the same time (m3pc_amd/planner.py: the policy pass and the
-    // re-score of a step on the stream of its parity) -- in the pipelined step the re-score chain of one stream was the bottleneck.
-    struct Base {
-        float *X = nullptr, *Y = nullptr, *EncOut = nullptr, *G = nullptr, *cand = nullptr, *pred[2] = {nullptr, nullptr},
-              *qv = nullptr, *splitk_ws = nullptr;
-        char *Hn = nullptr, *QKV = nullptr, *O = nullptr, *F = nullptr, *Z = nullptr;
-        long long splitk_ws_bytes = 0;
-        long long R = 0;       // token rows
-        int max_cand = 0;      // candidates (rows of cand / pred / qv)
-    } base, chain[2], pchain[2];  // chain / pchain: one per step-slot parity (see below)
-    Base* cur = nullptr;
-    bool two_stream = true;       // candidate halves on two streams (M3PC_TWO_STREAM=0: one stream); measured -2.5 % step time on C2
-    bool allow_splitk = true;     // see gemm(): off while sharded candidates are scored
-    double pass_scale = 1.0;      // candidates of the whole plan step / candidates of the launch being enqueued (>= 1; FUSED_MIN_ROWS)
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    const int* score_scatter_index = nullptr;  // set around a pass whose scores also go to scatter_out[index[i]] (score_kernel)
-    float* score_scatter_out = nullptr;
-    std::vector<hipStream_t> auxs;   // auxs[0] == aux
-    std::vector<hipEvent_t> ev_joins;
-    std::vector<int> stream_split;
-    // Deferred joins (M3PC_PLAN_DEFER_JOIN): the parts of a candidate pass that ran on the handle's own streams are joined by
-    // the consumer of the step (m3pc_candidate_join) instead of the caller's stream.  slot_join[s][i]: recorded behind part
-    // i + 1 of the last deferred pass of slot s; aux_unjoined[i]: stream auxs[i] holds candidate-workspace work nobody
-    // waited for on behalf of the workspace (ws_sync); defer_parts: the part sizes of the passes in flight -- a pass with the
-    // same sizes touches, per stream, the very rows that stream's earlier work touched, and needs no cross-stream order.
-    hipEvent_t slot_join[M3PC_SLOTS][3] = {};
-    int slot_join_n[M3PC_SLOTS] = {};
-    hipEvent_t aux_tail[3] = {};
-    bool aux_unjoined[3] = {false, false, false};
-    std::vector<int> defer_parts;
-    std::map<std::string, std::unique_ptr<Plan>> plans;
-    Plan* mask_plan[4][65] = {};  // get_mask_plan cache: [rcbc | fd | pi = gid | fid][idx]
-    // packed MFMA-fragment weight streams of the fused layer tails (block_fused.hip), by block prefix
-    std::map<std::string, bf16_t*> wstream;
-    // packed streams of the fused decoder input (kv_fused_kernel), by key: embedding of key k + K|V rows of decoder layer 0
-    bf16_t* kvstream[4] = {nullptr, nullptr, nullptr, nullptr};
-    // lab: in-kernel phase stamps of one workgroup of every fused-tail launch, as the step runs (m3pc_debug_stamp_log)
-    long long* stamp_log = nullptr;
-    int stamp_cap = 0, stamp_i = 0;
-    // profiling
-    bool prof = false;
-    bool prof_serial = false;     // m3pc_profile_enable(h, 2): the candidate halves run one after the other on the caller's stream
-    std::vector<EventPair> ev;
-    size_t ev_used = 0;
-};
-
-namespace {
-
-template <typename T>
-int dmalloc(T** p, size_t n) {
-    hipError_t e = hipMalloc((void**)p, n * sizeof(T) > 0 ? n * sizeof(T) : 16);
-    if (e != hipSuccess) return fail(M3PC_EHIP, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
-    return 0;
-}
-
-int check_launch(const char* what) {
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(M3PC_EHIP, "kernel launch failed in %s: %s", what, hipGetErrorString(e));
-    return 0;
-}
-
-// Re-base the workspace views at candidate c0 (each candidate owns 2T workspace rows).
-void set_view(m3pc_handle* h, int c0, int /*n*/) {
-    const size_t rows = (size_t)c0 * 2 * h->T, d = (size_t)h->d;
-    const m3pc_handle::Base& b = *h->cur;
-    h->X = b.X + rows * d;
-    h->Y = b.Y + rows * d;
-    h->EncOut = b.EncOut + rows * d;
-    h->G = b.G + rows * d;
-    h->Hn = b.Hn + rows * d * 4;
-    h->QKV = b.QKV + rows * 3 * d * 4;
-    h->O = b.O + rows * d * 4;
-    h->F = b.F + rows * 4 * d * 4;
-    h->Z = b.Z + rows * d * 4;
-    h->cand = b.cand + (size_t)c0 * h->T * h->A;
-    h->pred[0] = b.pred[0] + (size_t)c0 * h->T * 32;
-    h->pred[1] = b.pred[1] + (size_t)c0 * h->T * 32;
-    h->qv = b.qv + (size_t)c0 * h->T;
-    const long long half = b.splitk_ws_bytes / 2;
-    h->splitk_ws = c0 == 0 ? b.splitk_ws : b.splitk_ws + half / 4;
-    h->splitk_ws_bytes = half;
-}
-
-// Bind a workspace (the candidate one or the chain one): every launcher below reads the views.  Host-side state only: what
-// was enqueued before keeps the pointers it was enqueued with.
-void bind_ws(m3pc_handle* h, m3pc_handle::Base* b) {
-    h->cur = b;
-    h->R = b->R;
-    set_view(h, 0, b->max_cand);
-}
-struct WsScope {  // binds a chain workspace for the duration of a few-row fp32 pass
-    m3pc_handle* h;
-    WsScope(m3pc_handle* h_, bool chain, bool policy = false, int slot = 0) : h(h_) {
-        if (chain) bind_ws(h, policy ? &h->pchain[slot & 1] : &h->chain[slot & 1]);
-    }
-    ~WsScope() { bind_ws(h, &h->base); }
-};
-void bind_slot(m3pc_handle* h, int s) {
-    h->cur_slot = s;
-    h->loc = h->slot[s].loc;
-    h->sd = h->slot[s].sd;
-    h->rtok = h->slot[s].rtok;
-}
-
-// Orders `st` behind the deferred parts of earlier candidate passes: every call that touches the candidate workspace
-// in any other shape than those passes starts with it.
-int ws_sync(m3pc_handle* h, hipStream_t st) {
-    for (int i = 0; i < 3; ++i)
-        if (h->aux_unjoined[i]) {
-            HIPCHK(hipStreamWaitEvent(st, h->aux_tail[i], 0));
-            h->aux_unjoined[i] = false;
-        }
-    h->defer_parts.clear();
-    return 0;
-}
-
-int alloc_ws(m3pc_handle* h, m3pc_handle::Base& b, long long R_, int max_cand, long long splitk_bytes) {
-    const size_t R = (size_t)R_, d = (size_t)h->d, T = (size_t)h->T;
-    b.R = R_;
-    b.max_cand = max_cand;
-    CHK(dmalloc(&b.X, R * d));
-    CHK(dmalloc(&b.Y, R * d));
-    CHK(dmalloc(&b.EncOut, R * d));
-    CHK(dmalloc(&b.G, R * d));
-    CHK(dmalloc((float**)&b.Hn, R * d));
-    CHK(dmalloc((float**)&b.QKV, R * 3 * d));
-    CHK(dmalloc((float**)&b.O, R * d));
-    CHK(dmalloc((float**)&b.F, R * 4 * d));
-    CHK(dmalloc((float**)&b.Z, R * d));
-    CHK(dmalloc(&b.cand, (size_t)max_cand * T * h->A));
-    CHK(dmalloc(&b.pred[0], (size_t)max_cand * T * 32));
-    CHK(dmalloc(&b.pred[1], (size_t)max_cand * T * 32));
-    CHK(dmalloc(&b.qv, (size_t)max_cand * T));
-    b.splitk_ws_bytes = splitk_bytes;
-    CHK(dmalloc(&b.splitk_ws, (size_t)(splitk_bytes / 4)));
-    return 0;
-}
-void free_ws(m3pc_handle::Base& b) {
-    void* bufs[] = {b.X, b.Y, b.EncOut, b.G, b.Hn, b.QKV, b.O, b.F, b.Z, b.cand, b.pred[0], b.pred[1], b.qv, b.splitk_ws};
-    for (void* p : bufs)
-        if (p) hipFree(p);
-    b = m3pc_handle::Base();
-}
-
-Tensor& W(m3pc_handle* h, const std::string& n) { return h->w.at(n); }
-const void* Wop(m3pc_handle* h, const std::string& n, int dt) {
-    Tensor& t = h->w.at(n);
-    return dt == DT_BF16 ? (const void*)t.b : (const void*)t.f;
-}
-
-void add_tensor(m3pc_handle* h, const std::string& n, long long numel, bool gemm = false) {
-    Tensor t;
-    t.numel = numel;
-    t.gemm = gemm;
-    h->w[n] = t;
-}
-
-void declare_weights(m3pc_handle* h) {
-    const int d = h->d, ff = h->ff;
-    for (int k = 0; k < 4; ++k) {
-        const std::string kn = KEYN[k];
-        add_tensor(h, "encoder_embed_dict." + kn + ".weight", (long long)d * h->feat[k]);
-        add_tensor(h, "encoder_embed_dict." + kn + ".bias", d);
-        add_tensor(h, "decoder_embed_dict." + kn + ".weight", (long long)d * d, true);
-        add_tensor(h, "decoder_embed_dict." + kn + ".bias", d);
-        add_tensor(h, "mask_token_dict." + kn, d);
-        add_tensor(h, "encoder_per_dim_encoding." + kn, d);
-        add_tensor(h, "decoder_per_dim_encoding." + kn, d);
-        if (k == M3PC_ACTIONS) {
-            add_tensor(h, "output_head_dict.actions.mu.weight", (long long)h->A * d);
-            add_tensor(h, "output_head_dict.actions.mu.bias", h->A);
-            add_tensor(h, "output_head_dict.actions.log_std.weight", (long long)h->A * d);
-            add_tensor(h, "output_head_dict.actions.log_std.bias", h->A);
-        } else {
-            add_tensor(h, "output_head_dict." + kn + ".0.weight", d);
-            add_tensor(h, "output_head_dict." + kn + ".0.bias", d);
-            add_tensor(h, "output_head_dict." + kn + ".1.weight", (long long)d * d, true);
-            add_tensor(h, "output_head_dict." + kn + ".1.bias", d);
-            add_tensor(h, "output_head_dict." + kn + ".3.weight", (long long)h->feat[k] * d);
-            add_tensor(h, "output_head_dict." + kn + ".3.bias", h->feat[k]);
-        }
-    }
-    auto block = [&](const std::string& p) {
-        add_tensor(h, p + ".self_attn.in_proj_weight", 3LL * d * d, true);
-        add_tensor(h, p + ".self_attn.in_proj_bias", 3 * d);
-        add_tensor(h, p + ".self_attn.out_proj.weight", (long long)d * d, true);
-        add_tensor(h, p + ".self_attn.out_proj.bias", d);
-        add_tensor(h, p + ".linear1.weight", (long long)ff * d, true);
-        add_tensor(h, p + ".linear1.bias", ff);
-        add_tensor(h, p + ".linear2.weight", (long long)d * ff, true);
-        add_tensor(h, p + ".linear2.bias", d);
-        add_tensor(h, p + ".norm1.weight", d);
-        add_tensor(h, p + ".norm1.bias", d);
-        add_tensor(h, p + ".norm2.weight", d);
-        add_tensor(h, p + ".norm2.bias", d);
-    };
-    for (int i = 0; i < h->dm.n_enc_layer; ++i) block("encoder.layers." + std::to_string(i));
-    for (int i = 0; i < h->dm.n_dec_layer; ++i) block("decoder.layers." + std::to_string(i));
-    add_tensor(h, "encoder.norm.weight", d);
-    add_tensor(h, "encoder.norm.bias", d);
-    add_tensor(h, "decoder.norm.weight", d);
-    add_tensor(h, "decoder.norm.bias", d);
-    add_tensor(h, "pos_embed", (long long)h->T * d);
-}
-
-// ---------------------------------------------------------------------------------- profiling
-struct GemmTimer {
-    m3pc_handle* h;
-    hipStream_t st;
-    EventPair* e = nullptr;
-    GemmTimer(m3pc_handle* h_, hipStream_t st_, double flops, int dt, int kind = 0) : h(h_), st(st_) {
-        if (!h->prof) return;
-        if (h->ev_used == h->ev.size()) {
-            EventPair n;
-            hipEventCreate(&n.a);
-            hipEventCreate(&n.b);
-            h->ev.push_back(n);
-        }
-        e = &h->ev[h->ev_used++];
-        e->flops = flops;
-        e->dt = dt;
-        e->kind = kind;
-        hipEventRecord(e->a, st);
-    }
-    ~GemmTimer() {
-        if (e) hipEventRecord(e->b, st);
-    }
-};
-
-// returns 1 when the LayerNorm named by p_in.ln_* was fused into the launch (GemmP::ln_g)
-int gemm(m3pc_handle* h, const GemmP& p_in, int dt, hipStream_t st) {
-    GemmP p = p_in;
-    // split-K changes the association of the K sum, so it is only allowed where every rank / shard runs the
-    // same row count (policy pass, generic forward, top-k re-score): sharded candidate scores stay bit-identical
-    p.ws = h->allow_splitk ? h->splitk_ws : nullptr;
-    p.ws_bytes = h->splitk_ws_bytes;
-#ifdef M3PC_LAB  // (the lab build only: an environment variable must not change which kernels the product runs)
-    static const int env_variant = M3PC_ENV("M3PC_GEMM_VARIANT") ? atoi(M3PC_ENV("M3PC_GEMM_VARIANT")) : 0;  // A/B runs
-    if (env_variant) p.variant = env_variant;
-#endif
-    GemmTimer t(h, st, 2.0 * p.M * (double)p.N * p.K, dt);
-    return launch_gemm(p, dt, st);
-}
-
-// Few-row fp32 passes: can the LayerNorm in front of GEMM `p` ride on its operand load (gemm_f32_direct.hip: a_ln_*)?
-// `p` must already read the un-normalised rows (A = X, lda = d) and carry a_ln_g / a_ln_b.
-// Measured on the policy pass: the folded GEMM takes 11-12.5 us where GEMM 6.8 + LayerNorm launch 4.3-5
-// took 11-12 -- every workgroup recomputes its rows' statistics behind a barrier before its K loop starts, which costs what
-// the launch cost.  Neutral, so OFF by default (M3PC_LN_FOLD=1 turns it on for A/B runs); the GPU tests pass either way.
-bool can_fold_ln(m3pc_handle* h, const GemmP& p, int dt) {
-    static const bool on = M3PC_ENV("M3PC_LN_FOLD") != nullptr && M3PC_ENV("M3PC_NO_F32_DIRECT") == nullptr &&
-                           M3PC_ENV("M3PC_GEMM_VARIANT") == nullptr;  // A/B switch
-    return dt == DT_F32 && on && h->allow_splitk && h->splitk_ws && gemm_f32_direct_covers(p);
-}
-
-GemmP gemm_basic(const void* A, int lda, const void* Wp, int ldw, int M, int N, int K, const float* bias) {
-    GemmP p;
-    memset(&p, 0, sizeof(p));
-    p.A = A;
-    p.lda = lda;
-    p.W = Wp;
-    p.ldw = ldw;
-    p.M = M;
-    p.N = N;
-    p.K = K;
-    p.bias = bias;
-    p.rt_mod = 1;
-    // every A operand built here is one of the handle's workspaces (fp32-sized, R rows): a many-row bf16 operand leaves at
-    // least as many bytes behind its last row as it occupies (see GemmP::a_padded)
-    p.a_padded = 1;
-    return p;
-}
-void gemm_out(GemmP& p, int dt_out, void* C, int ldc) {
-    if (dt_out == DT_BF16)
-        p.Cb = (bf16_t*)C;
-    else
-        p.Cf = (float*)C;
-    p.ldc = ldc;
-}
-
-// ---------------------------------------------------------------------------------- plans
-int get_plan(m3pc_handle* h, const unsigned char* const masks[4], Plan** out) {
-    const int T = h->T;
-    std::string key(4 * T, '0');
-    for (int k = 0; k < 4; ++k)
-        for (int t = 0; t < T; ++t) key[k * T + t] = masks[k][t] ? '1' : '0';
-    auto it = h->plans.find(key);
-    if (it != h->plans.end()) {
-        *out = it->second.get();
-        return 0;
-    }
-    std::unique_ptr<Plan> pl(new Plan());
-    pl->key = key;
-    pl->T = T;
-    std::vector<int2> tokmap;
-    pl->dec_src.assign(4 * T, -1);
-    for (int k = 0; k < 4; ++k) {
-        pl->enc_off[k] = (int)tokmap.size();
-        bool seen_zero = false;
-        for (int t = 0; t < T; ++t) {
-            if (masks[k][t]) {
-                if (seen_zero) pl->prefix[k] = false;
-                pl->dec_src[k * T + t] = (int)tokmap.size();
-                tokmap.push_back(make_int2(k, t));
-                pl->kept[k]++;
-            } else {
-                seen_zero = true;
-            }
-        }
-    }
-    pl->Le = (int)tokmap.size();
-    if (pl->Le == 0) return fail(M3PC_EINVAL, "mask keeps no token");
-    std::vector<int> dec_rowsrc(4 * T), masked_rowsrc;
-    for (int i = 0; i < 4 * T; ++i) {
-        if (pl->dec_src[i] >= 0) {
-            dec_rowsrc[i] = pl->dec_src[i];
-        } else {
-            dec_rowsrc[i] = -(i / T) - 1;
-            pl->masked.push_back(i);
-            masked_rowsrc.push_back(-i - 1);
-        }
-    }
-    pl->Lm = (int)pl->masked.size();
-    CHK(dmalloc(&pl->d_tokmap, tokmap.size()));
-    HIPCHK(hipMemcpy(pl->d_tokmap, tokmap.data(), tokmap.size() * sizeof(int2), hipMemcpyHostToDevice));
-    CHK(dmalloc(&pl->d_dec_rowsrc, dec_rowsrc.size()));
-    HIPCHK(hipMemcpy(pl->d_dec_rowsrc, dec_rowsrc.data(), dec_rowsrc.size() * sizeof(int), hipMemcpyHostToDevice));
-    CHK(dmalloc(&pl->d_masked_rowsrc, masked_rowsrc.size() + 1));
-    if (!masked_rowsrc.empty())
-        HIPCHK(hipMemcpy(pl->d_masked_rowsrc, masked_rowsrc.data(), masked_rowsrc.size() * sizeof(int), hipMemcpyHostToDevice));
-    *out = pl.get();
-    h->plans[key] = std::move(pl);
-    return 0;
-}
-
-// The deterministic test-time masks, cached per (kind, idx): kind 0 = rcbc (finetune_omtm/masks.py:7-27: states[:idx+1],
-// actions[:idx], all returns), kind 1 = fd (masks.py:30-44: states[:idx+1], all actions), kind 2 = pi = gid
-// (zeroshot_omtm/masks.py:72-91 / 50-69: all states but idx+1 .. T-2 when idx > 0, actions[:idx]), kind 3 = fid
-// (zeroshot_omtm/masks.py:30-47: all states, actions[:idx]).  No host-side mask work after the first call with a given idx.
-int get_mask_plan(m3pc_handle* h, int kind, int idx, Plan** out) {
-    Plan*& slot = h->mask_plan[kind][idx];
-    if (!slot) {
-        const int T = h->T;
-        std::vector<unsigned char> m[4];
-        for (int k = 0; k < 4; ++k) m[k].assign(T, 0);
-        if (kind <= 1) {
-            for (int t = 0; t <= idx && t < T; ++t) m[M3PC_STATES][t] = 1;
-            for (int t = 0; t < (kind == 0 ? idx : T); ++t) m[M3PC_ACTIONS][t] = 1;
-            if (kind == 0)
-                for (int t = 0; t < T; ++t) m[M3PC_RETURNS][t] = 1;
-        } else {
-            for (int t = 0; t < T; ++t) m[M3PC_STATES][t] = 1;
-            if (kind == 2 && idx > 0)
-                for (int t = idx + 1; t < T - 1; ++t) m[M3PC_STATES][t] = 0;  // state_mask[idx + 1 : -1] = 0
-            for (int t = 0; t < idx; ++t) m[M3PC_ACTIONS][t] = 1;
-        }
-        const unsigned char* mp[4] = {m[0].data(), m[1].data(), m[2].data(), m[3].data()};
-        CHK(get_plan(h, mp, &slot));
-    }
-    *out = slot;
-    return 0;
-}
-
-// Plan::edec_kept: the decoder position table rows of the kept tokens of each key, in encoder order
-int ensure_edec(m3pc_handle* h, Plan* pl, hipStream_t st) {
-    if (pl->edec_valid) return 0;
-    const int T = h->T, d = h->d;
-    for (int k = 0; k < 4; ++k) {
-        if (pl->prefix[k] || pl->kept[k] == 0) {
-            pl->edec_kept[k] = h->Edec[k];
-            continue;
-        }
-        if (!pl->edec_own[k]) CHK(dmalloc(&pl->edec_own[k], (size_t)T * d));
-        int j = 0;
-        for (int t = 0; t < T; ++t)
-            if (pl->dec_src[k * T + t] >= 0) {
-                HIPCHK(hipMemcpyAsync(pl->edec_own[k] + (size_t)j * d, h->Edec[k] + (size_t)t * d, (size_t)d * sizeof(float),
-                                      hipMemcpyDeviceToDevice, st));
-                ++j;
-            }
-        pl->edec_kept[k] = pl->edec_own[k];
-    }
-    pl->edec_valid = true;
-    return 0;
-}
-
-void free_tables(SharedTables& t) {
-    if (t.Yall) hipFree(t.Yall);
-    if (t.QKVm) hipFree(t.QKVm);
-    if (t.QKVq) hipFree(t.QKVq);
-    if (t.Yq) hipFree(t.Yq);
-    if (t.pre_m) hipFree(t.pre_m);
-    if (t.pre_l) hipFree(t.pre_l);
-    if (t.pre_O) hipFree(t.pre_O);
-    t = SharedTables();
-}
-
-void invalidate_tables(m3pc_handle* h) {
-    for (auto& kv : h->plans)
-    {
-        for (int q = 0; q < N_QUERY; ++q)
-            for (int pr = 0; pr < 2; ++pr) kv.second->query[q].tab[pr].valid = false;
-        kv.second->edec_valid = false;
-    }
-}
-
-// ---------------------------------------------------------------------------------- transformer block
-// One pre-LN layer (mtm_model.py:379-409) over `batch` sequences of L rows, in place on X (fp32).
-// next_ln: the LayerNorm that follows this block on X (next block's norm1 or the stack's final norm); when the
-// FFN2 GEMM can apply it in its split-K reduce, *next_ln_done is set and the caller skips that launch.
-// x_dead: nothing reads X after this block except through next_ln (lets the fused tail skip the fp32 store).
-// Xnext / res_nshared (fused tail only): the block output goes to Xnext instead of X, and the first res_nshared rows of
-// every sequence of X are read from sequence 0 (the embedding kernel stored the history rows once, EmbedP::x_first_only).
-// The fused layer tail (block_fused.hip) works in 128-row tiles, one per CU, and a tile takes its ~130-170 us whatever the row
-// count: below ~96 tiles most of the chip idles for that long and the GEMM chain, whose tiles spread over all CUs, is faster
-// (the reference's shipped N=625 / T=8 config, 64 + 40 tiles: 1.13 -> 1.00 ms per closed-loop call).
-// The choice goes by the size of the WHOLE step (m3pc_handle::pass_scale = n_total / candidates of this launch), not by the
-// rows of a shard or a candidate part: a candidate's score must not depend on how the candidates were cut.
-constexpr long long FUSED_MIN_ROWS = 96 * 128;
-// Between 16 and 96 tiles the tail still runs fused, four workgroups per tile (each a quarter of the FFN's hidden units, fp32
-// partials to four slabs in the F buffer) with a row-wise reduce + LayerNorm launch behind it (block_fused_kernel<0, 3>).
-constexpr long long SPLIT_MIN_ROWS = 16 * 128;
-
-// qkv_done: the previous layer's fused tail already wrote this layer's Q|K|V rows; next_qkv: prefix of the layer whose Q|K|V
-// projection this layer's fused tail may compute (-> *next_qkv_done)
-int run_block(m3pc_handle* h, const std::string& pfx, float* X, int batch, int L, int dt, hipStream_t st, bool ln1_done = false,
-              int n_sh = 0, const LnP* next_ln = nullptr, bool* next_ln_done = nullptr, bool x_dead = false,
-              float* Xnext = nullptr, int res_nshared = 0, bool qkv_done = false, const std::string* next_qkv = nullptr,
-              bool* next_qkv_done = nullptr) {
-    const int d = h->d, ff = h->ff;
-    const int rows = batch * L;
-    const int es = (int)dtype_size(dt);
-    (void)es;
-    LnP ln;
-    memset(&ln, 0, sizeof(ln));
-    ln.X = X;
-    ln.ldx = d;
-    ln.rows = rows;
-    ln.d = d;
-    ln.g1 = W(h, pfx + ".norm1.weight").f;
-    ln.b1 = W(h, pfx + ".norm1.bias").f;
-    if (dt == DT_BF16)
-        ln.Yb = (bf16_t*)h->Hn;
-    else
-        ln.Yf = (float*)h->Hn;
-    // norm1 in front of the Q|K|V projection: folded into that GEMM's operand load in the few-row fp32 passes
-    GemmP pqkv = gemm_basic(h->Hn, d, Wop(h, pfx + ".self_attn.in_proj_weight", dt), d, rows, 3 * d, d,
-                            W(h, pfx + ".self_attn.in_proj_bias").f);
-    gemm_out(pqkv, dt, h->QKV, 3 * d);
-    if (!ln1_done && n_sh == 0) {
-        GemmP t = pqkv;
-        t.A = X;
-        t.a_ln_g = ln.g1;
-        t.a_ln_b = ln.b1;
-        if (can_fold_ln(h, t, dt)) {
-            pqkv = t;
-            ln1_done = true;
-        }
-    }
-    if (!ln1_done && !qkv_done) launch_layernorm(ln, st);  // the embedding kernel already wrote norm1(X) of the first layer
-    if (n_sh > 0) {
-        // First layer of a candidate pass: the first n_sh tokens are the same for every candidate (history), so
-        // their norm1 rows and Q|K|V projections exist once (n_sh rows behind the compact per-candidate rows in
-        // Hn / QKV, written by the embedding kernel) and only the L - n_sh candidate-specific rows go through the
-        // big GEMM.  Attention still produces all L output rows per candidate: queries and keys are read from the
-        // two segments (own rows first, then the shared ones; softmax is order-independent up to rounding).
-        const int n_own = L - n_sh;
-        const size_t es2 = dtype_size(dt);
-        char* hn_sh = (char*)h->Hn + (size_t)batch * n_own * d * es2;
-        char* qkv_sh = (char*)h->QKV + (size_t)batch * n_own * 3 * d * es2;
-        {
-            GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".self_attn.in_proj_weight", dt), d, batch * n_own, 3 * d, d,
-                                 W(h, pfx + ".self_attn.in_proj_bias").f);
-            gemm_out(p, dt, h->QKV, 3 * d);
-            gemm(h, p, dt, st);
-        }
-        {
-            GemmP p = gemm_basic(hn_sh, d, Wop(h, pfx + ".self_attn.in_proj_weight", dt), d, n_sh, 3 * d, d,
-                                 W(h, pfx + ".self_attn.in_proj_bias").f);
-            gemm_out(p, dt, qkv_sh, 3 * d);
-            gemm(h, p, dt, st);
-        }
-        AttnP a;
-        memset(&a, 0, sizeof(a));
-        const char* q = (const char*)h->QKV;
-        a.Q = q;
-        a.q_bstride = (long long)n_own * 3 * d;
-        a.ldq = 3 * d;
-        a.Lq = n_own;
-        a.orow1 = n_sh;
-        a.Q2 = qkv_sh;
-        a.ldq2 = 3 * d;
-        a.Lq2 = n_sh;
-        a.orow2 = 0;
-        a.K1 = q + (size_t)d * es2;
-        a.V1 = q + (size_t)2 * d * es2;
-        a.kv1_bstride = (long long)n_own * 3 * d;
-        a.ldkv1 = 3 * d;
-        a.L1 = n_own;
-        a.K2 = qkv_sh + (size_t)d * es2;
-        a.V2 = qkv_sh + (size_t)2 * d * es2;
-        a.ldkv2 = 3 * d;
-        a.L2 = n_sh;
-        a.O = h->O;
-        a.o_bstride = (long long)L * d;
-        a.ldo = d;
-        a.batch = batch;
-        a.n_head = h->nh;
-        a.hd = h->hd;
-        a.scale = 1.0f / sqrtf((float)h->hd);
-        launch_attention(a, dt, st);
-    } else {
-    if (!qkv_done) gemm(h, pqkv, dt, st);
-    {
-        AttnP a;
-        memset(&a, 0, sizeof(a));
-        const char* q = (const char*)h->QKV;
-        a.Q = q;
-        a.q_bstride = (long long)L * 3 * d;
-        a.ldq = 3 * d;
-        a.K1 = q + (size_t)d * dtype_size(dt);
-        a.V1 = q + (size_t)2 * d * dtype_size(dt);
-        a.kv1_bstride = (long long)L * 3 * d;
-        a.ldkv1 = 3 * d;
-        a.L1 = L;
-        a.O = h->O;
-        a.o_bstride = (long long)L * d;
-        a.ldo = d;
-        a.batch = batch;
-        a.n_head = h->nh;
-        a.hd = h->hd;
-        a.Lq = L;
-        a.scale = 1.0f / sqrtf((float)h->hd);
-        launch_attention(a, dt, st);
-    }
-    }
-    // many-row bf16 passes: everything after the attention is one launch (block_fused.hip)
-    static const bool no_fused = M3PC_ENV("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
-    static const bool no_split = M3PC_ENV("M3PC_NO_BLOCK_SPLIT") != nullptr;  // A/B switch
-    const double step_rows = (double)rows * h->pass_scale;
-    if (dt == DT_BF16 && !no_fused && !no_split && step_rows < (double)FUSED_MIN_ROWS && step_rows >= (double)SPLIT_MIN_ROWS &&
-        h->wstream.count(pfx) && !Xnext && !res_nshared && (long long)rows * block_split_n() * d <= h->R * 4LL * d) {
-        // few tiles: four workgroups per tile + the reduce (which also applies the LayerNorm that consumes the block output)
-        BlockP b;
-        memset(&b, 0, sizeof(b));
-        b.O = (const bf16_t*)h->O;
-        b.ldo = d;
-        b.M = rows;
-        b.res = X;
-        b.ldr = d;
-        b.wstream = h->wstream[pfx];
-        b.bo = W(h, pfx + ".self_attn.out_proj.bias").f;
-        b.b1 = W(h, pfx + ".linear1.bias").f;
-        b.b2 = W(h, pfx + ".linear2.bias").f;
-        b.ln2_g = W(h, pfx + ".norm2.weight").f;
-        b.ln2_b = W(h, pfx + ".norm2.bias").f;
-        b.split = 1;
-        b.Xout = (float*)h->F;
-        b.ldx = d;
-        const bool fuse_ln = next_ln && next_ln->Yb && !next_ln->Yf && !next_ln->g2 && next_ln->X == X && next_ln->xmap.rpg == 0 &&
-                             next_ln->rows == rows;
-        bool ok;
-        {
-            GemmTimer t(h, st, 2.0 * rows * ((double)d * d + 2.0 * d * ff), dt, 1);  // (algorithmic: the repeated out-proj is not counted)
-            ok = launch_block_fused(b, st);
-        }
-        if (ok) {
-            SplitReduceP r;
-            memset(&r, 0, sizeof(r));
-            r.slabs = (const float*)h->F;
-            r.M = rows;
-            r.ldx = d;
-            if (!(fuse_ln && x_dead)) r.Xout = X;
-            if (fuse_ln) {
-                r.lnA_g = next_ln->g1;
-                r.lnA_b = next_ln->b1;
-                r.Hout = next_ln->Yb;
-                r.ldh = d;
-            }
-            launch_block_split_reduce(r, st);
-            if (next_ln_done) *next_ln_done = fuse_ln;
-            if (next_qkv_done) *next_qkv_done = false;
-            return check_launch(pfx.c_str());
-        }
-    }
-    if (dt == DT_BF16 && !no_fused && step_rows >= (double)FUSED_MIN_ROWS && h->wstream.count(pfx)) {
-        BlockP b;
-        memset(&b, 0, sizeof(b));
-        b.O = (const bf16_t*)h->O;
-        b.ldo = d;
-        b.M = rows;
-        b.res = X;
-        b.ldr = d;
-        b.wstream = h->wstream[pfx];
-        b.bo = W(h, pfx + ".self_attn.out_proj.bias").f;
-        b.b1 = W(h, pfx + ".linear1.bias").f;
-        b.b2 = W(h, pfx + ".linear2.bias").f;
-        b.ln2_g = W(h, pfx + ".norm2.weight").f;
-        b.ln2_b = W(h, pfx + ".norm2.bias").f;
-        const bool fuse_ln = next_ln && next_ln->Yb && !next_ln->Yf && !next_ln->g2 && next_ln->X == (Xnext ? Xnext : X) &&
-                             next_ln->xmap.rpg == 0 && next_ln->rows == rows;
-        if (res_nshared > 0) {
-            b.res_L = L;
-            b.res_nshared = res_nshared;
-        }
-        static const bool no_qkv_fused = M3PC_ENV("M3PC_NO_QKV_FUSED") != nullptr;  // A/B switch
-        const bool fuse_qkv = fuse_ln && next_qkv && !no_qkv_fused && next_ln->Yb == (bf16_t*)h->Hn &&
-                              (size_t)rows * 3 * d * 2 < 0x7fffffffull;
-        if (fuse_qkv) {  // norm1 of the next layer never leaves the kernel: its Q|K|V rows do
-            b.lnA_g = next_ln->g1;
-            b.lnA_b = next_ln->b1;
-            b.QKVout = (bf16_t*)h->QKV;
-            b.ldq = 3 * d;
-            b.qkv_bytes = (unsigned)((size_t)rows * 3 * d * 2);
-            b.bqkv = W(h, *next_qkv + ".self_attn.in_proj_bias").f;
-        } else if (fuse_ln) {
-            b.lnA_g = next_ln->g1;
-            b.lnA_b = next_ln->b1;
-            b.Hout = next_ln->Yb;
-            b.ldh = d;
-        }
-        if (next_qkv_done) *next_qkv_done = fuse_qkv;
-        if (!(fuse_ln && x_dead)) {
-            b.Xout = Xnext ? Xnext : X;
-            b.ldx = d;
-        }
-        if (h->stamp_log) {
-            b.stamps = h->stamp_log + 64 * (h->stamp_i++ % h->stamp_cap);
-            b.stamp_block = 37;
-        }
-        GemmTimer t(h, st, 2.0 * rows * ((double)d * d + 2.0 * d * ff + (fuse_qkv ? 3.0 * d * d : 0.0)), dt, 1);
-        if (launch_block_fused(b, st)) {
-            if (next_ln_done) *next_ln_done = fuse_ln;
-            return check_launch(pfx.c_str());
-        }
-        if (next_qkv_done) *next_qkv_done = false;
-    }
-    if (Xnext || res_nshared) return fail(M3PC_EINVAL, "%s: the fused layer tail did not take a pass set up for it", pfx.c_str());
-    {
-        GemmP p = gemm_basic(h->O, d, Wop(h, pfx + ".self_attn.out_proj.weight", dt), d, rows, d, d,
-                             W(h, pfx + ".self_attn.out_proj.bias").f);
-        p.res = X;
-        p.ldr = d;
-        gemm_out(p, DT_F32, X, d);
-        ln.g1 = W(h, pfx + ".norm2.weight").f;
-        ln.b1 = W(h, pfx + ".norm2.bias").f;
-        // norm2: folded into linear1's operand load (few-row fp32), else on the split-K reduce of this GEMM, else a launch
-        GemmP p1 = gemm_basic(h->Hn, d, Wop(h, pfx + ".linear1.weight", dt), d, rows, ff, d, W(h, pfx + ".linear1.bias").f);
-        p1.gelu = 1;
-        gemm_out(p1, dt, h->F, ff);
-        GemmP t = p1;
-        t.A = X;
-        t.a_ln_g = ln.g1;
-        t.a_ln_b = ln.b1;
-        if (can_fold_ln(h, t, dt)) {
-            gemm(h, p, dt, st);
-            gemm(h, t, dt, st);
-        } else {
-            if (dt == DT_F32) {
-                p.ln_g = ln.g1;
-                p.ln_b = ln.b1;
-                p.ln_out = ln.Yf;
-            }
-            if (!gemm(h, p, dt, st)) launch_layernorm(ln, st);
-            gemm(h, p1, dt, st);
-        }
-    }
-    {
-        GemmP p = gemm_basic(h->F, ff, Wop(h, pfx + ".linear2.weight", dt), ff, rows, d, ff, W(h, pfx + ".linear2.bias").f);
-        p.res = X;
-        p.ldr = d;
-        gemm_out(p, DT_F32, X, d);
-        if (dt == DT_F32 && next_ln && next_ln->Yf && !next_ln->Yb && !next_ln->g2 && next_ln->X == X && next_ln->xmap.rpg == 0 &&
-            next_ln->rows == rows) {
-            p.ln_g = next_ln->g1;
-            p.ln_b = next_ln->b1;
-            p.ln_out = next_ln->Yf;
-        }
-        const int done = gemm(h, p, dt, st);
-        if (next_ln_done) *next_ln_done = done != 0;
-    }
-    return check_launch(pfx.c_str());
-}
-
-struct TokIn {
-    const float* ptr[4];
-    long long bstride[4];
-    int normalize[4];
-    const int* widx = nullptr;  // optional per-batch-element window index into ptr[k] (stride wstride[k])
-    long long wstride[4] = {0, 0, 0, 0};
-};
-
-// embed + encoder stack + encoder.norm -> EncOut (fp32) [and bf16 copy in Z when dt == bf16 and want_b]
-// n_indep: number of leading encoder tokens that are identical for every batch element (candidate pass: history)
-// layer_from / layer_to / ln_state: the pass can be enqueued in pieces (the embedding goes with layer 0, encoder.norm with the
-// last layer); *ln_state carries "norm1 of the next layer is already in Hn" (ln) / "its Q|K|V rows are already in QKV" (qkv)
-// from one piece to the next
-struct PieceState {
-    bool ln = true, qkv = false;
-};
-int run_encoder(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, int dt, hipStream_t st, bool bf16_out_only = false,
-                int n_indep = 0, int layer_from = 0, int layer_to = 1 << 30, PieceState* ln_state = nullptr) {
-    // first-layer pruning (run_block): whole 32-query tiles of shared tokens, bf16 candidate passes only
-    int n_sh = 0;
-    static const bool no_prune1 = M3PC_ENV("M3PC_NO_PRUNE1") != nullptr;  // A/B switch
-    if (dt == DT_BF16 && batch >= 64 && h->d % 256 == 0 && h->d <= 1024 && n_indep >= 32 && !no_prune1)
-        n_sh = (n_indep / 32) * 32;
-    EmbedP e;
-    memset(&e, 0, sizeof(e));
-    e.n_indep = n_indep;
-    e.n_sh = n_sh;
-    e.Hb_sh = n_sh ? (bf16_t*)((char*)h->Hn + (size_t)batch * (pl->Le - n_sh) * h->d * 2) : nullptr;
-    for (int k = 0; k < 4; ++k) {
-        e.tok[k] = in.ptr[k];
-        e.bstride[k] = in.bstride[k];
-        e.wstride[k] = in.wstride[k];
-        e.normalize[k] = in.normalize[k];
-        e.mean[k] = h->tok_mean[k];
-        e.stdv[k] = h->tok_std[k];
-        e.WT[k] = h->WT[k];
-        e.E[k] = h->Eenc[k];
-        e.feat[k] = h->feat[k];
-    }
-    // history rows of the residual stream stored once (sequence 0) when the first layer's tail is the fused kernel: it reads
-    // them there and writes the layer output to Y, which carries the stream through the remaining layers
-    // (M3PC_SHARED_RES=1; measured on C2: embedding 33 -> 15 us, but every tile of the fused kernel then reads the same 66 KiB
-    // and the step is 0.4 % SLOWER -- off)
-    static const bool shared_res_on = M3PC_ENV("M3PC_SHARED_RES") != nullptr && M3PC_ENV("M3PC_NO_BLOCK_FUSED") == nullptr;
-    const bool shared_res = n_sh > 0 && shared_res_on && (long long)batch * pl->Le >= 512 && h->wstream.count("encoder.layers.0") &&
-                            bf16_out_only;
-    e.x_first_only = shared_res ? 1 : 0;
-    e.widx = in.widx;
-    e.tokmap = pl->d_tokmap;
-    e.batch = batch;
-    e.L = pl->Le;
-    e.d = h->d;
-    e.T = h->T;
-    e.X = h->X;
-    e.ln_g = W(h, "encoder.layers.0.norm1.weight").f;  // first layer's norm1 fused into the embedding
-    e.ln_b = W(h, "encoder.layers.0.norm1.bias").f;
-    if (dt == DT_BF16)
-        e.Hb = (bf16_t*)h->Hn;
-    else
-        e.Hf = (float*)h->Hn;
-    if (layer_from <= 0) launch_embed(e, st);
-    LnP ln;
-    memset(&ln, 0, sizeof(ln));
-    ln.X = h->X;
-    ln.ldx = h->d;
-    ln.rows = batch * pl->Le;
-    ln.d = h->d;
-    ln.g1 = W(h, "encoder.norm.weight").f;
-    ln.b1 = W(h, "encoder.norm.bias").f;
-    if (bf16_out_only)
-        ln.Yb = (bf16_t*)h->Z;  // the candidate pass consumes the encoder output only as a bf16 GEMM operand
-    else
-        ln.Yf = h->EncOut;
-    bool ln_done = layer_from <= 0 || !ln_state ? true : ln_state->ln;  // norm1 of layer 0 comes from the embedding kernel
-    bool qkv_done = layer_from <= 0 || !ln_state ? false : ln_state->qkv;
-    const int nl = h->dm.n_enc_layer;
-    float* Xs = shared_res && layer_from > 0 ? h->Y : h->X;  // where the residual stream lives
-    for (int i = layer_from > 0 ? layer_from : 0; i < nl && i < layer_to; ++i) {
-        float* Xn = shared_res && i == 0 ? h->Y : nullptr;
-        LnP nxt = ln;  // what follows layer i on X: norm1 of layer i+1 (-> Hn) or encoder.norm (-> EncOut / Z)
-        nxt.X = ln.X = Xn ? Xn : Xs;
-        if (i + 1 < nl) {
-            nxt.g1 = W(h, "encoder.layers." + std::to_string(i + 1) + ".norm1.weight").f;
-            nxt.b1 = W(h, "encoder.layers." + std::to_string(i + 1) + ".norm1.bias").f;
-            nxt.Yb = dt == DT_BF16 ? (bf16_t*)h->Hn : nullptr;
-            nxt.Yf = dt == DT_F32 ? (float*)h->Hn : nullptr;
-        }
-        const bool l1 = ln_done;
-        ln_done = false;
-        const std::string nq = "encoder.layers." + std::to_string(i + 1);
-        const bool q1 = qkv_done;
-        qkv_done = false;
-        CHK(run_block(h, "encoder.layers." + std::to_string(i), Xs, batch, pl->Le, dt, st, l1, i == 0 ? n_sh : 0, &nxt, &ln_done,
-                      i + 1 == nl && bf16_out_only, Xn, Xn ? n_indep : 0, q1, i + 1 < nl ? &nq : nullptr, &qkv_done));
-        if (Xn) Xs = Xn;
-    }
-    if (ln_state) {
-        ln_state->ln = ln_done;
-        ln_state->qkv = qkv_done;
-    }
-    if (layer_to < nl) return check_launch("encoder");
-    ln.X = Xs;
-    if (!ln_done) launch_layernorm(ln, st);
-    return check_launch("encoder");
-}
-
-// decoder-embed of rows of one key: Y[cmap rows] = Z[amap rows] W_dec_k^T + E_dec_k[r % mod]
-void dec_embed(m3pc_handle* h, int k, const void* Zop, RowMap amap, float* Yout, RowMap cmap, int M, int mod, int dt,
-               hipStream_t st, const float* table = nullptr) {
-    const int d = h->d;
-    const std::string kn = KEYN[k];
-    GemmP p = gemm_basic(Zop, d, Wop(h, "decoder_embed_dict." + kn + ".weight", dt), d, M, d, d, nullptr);
-    p.amap = amap;
-    p.cmap = cmap;
-    p.rowtab = table ? table : h->Edec[k];
-    p.rt_mod = mod;
-    p.rt_ld = d;
-    gemm_out(p, DT_F32, Yout, d);
-    gemm(h, p, dt, st);
-}
-
-// Full (un-pruned) decoder on `batch` sequences: Z (4T rows each, operand dtype) -> Y (fp32) after all layers.
-int run_decoder_full(m3pc_handle* h, const void* Zop, int batch, int dt, hipStream_t st) {
-    const int T = h->T, d = h->d;
-    bool grouped = false;
-    static const bool no_group = M3PC_ENV("M3PC_NO_GEMM_GROUP") != nullptr || M3PC_ENV("M3PC_NO_F32_DIRECT") != nullptr ||
-                                 M3PC_ENV("M3PC_GEMM_VARIANT") != nullptr;  // A/B switches
-    if (dt == DT_F32 && !no_group && h->allow_splitk) {  // few-row fp32 pass: the four modality GEMMs as one launch
-        GemmP ps[4];
-        for (int k = 0; k < 4; ++k) {
-            RowMap m{T, 4 * T, k * T};
-            ps[k] = gemm_basic(Zop, d, Wop(h, std::string("decoder_embed_dict.") + KEYN[k] + ".weight", dt), d, batch * T, d, d, nullptr);
-            ps[k].amap = m;
-            ps[k].cmap = m;
-            ps[k].rowtab = h->Edec[k];
-            ps[k].rt_mod = T;
-            ps[k].rt_ld = d;
-            gemm_out(ps[k], DT_F32, h->Y, d);
-        }
-        GemmTimer t(h, st, 4 * 2.0 * batch * T * (double)d * d, dt);
-        grouped = launch_gemm_f32_direct_group(ps, 4, st);
-    }
-    for (int k = 0; k < 4 && !grouped; ++k) {
-        RowMap m{T, 4 * T, k * T};
-        dec_embed(h, k, Zop, m, h->Y, m, batch * T, T, dt, st);
-    }
-    for (int i = 0; i < h->dm.n_dec_layer; ++i) CHK(run_block(h, "decoder.layers." + std::to_string(i), h->Y, batch, 4 * T, dt, st));
-    return check_launch("decoder");
-}
-
-int run_head_tail(m3pc_handle* h, int k, const void* ln_rows, int rows, float* out, int ldy, bool detok, int dt, hipStream_t st);
-
-// Output head of key k (not actions) on `rows` logical rows of Ysrc selected by xmap:
-// decoder.norm -> head LN -> Linear+GELU -> Linear(D_k) [-> de-tokenize]
-int run_head(m3pc_handle* h, int k, const float* Ysrc, RowMap xmap, int rows, float* out, int ldy, bool detok, int dt,
-             hipStream_t st) {
-    const int d = h->d;
-    const std::string kn = KEYN[k];
-    LnP ln;
-    memset(&ln, 0, sizeof(ln));
-    ln.X = Ysrc;
-    ln.ldx = d;
-    ln.xmap = xmap;
-    ln.rows = rows;
-    ln.d = d;
-    ln.g1 = W(h, "decoder.norm.weight").f;
-    ln.b1 = W(h, "decoder.norm.bias").f;
-    ln.g2 = W(h, "output_head_dict." + kn + ".0.weight").f;
-    ln.b2 = W(h, "output_head_dict." + kn + ".0.bias").f;
-    if (dt == DT_BF16)
-        ln.Yb = (bf16_t*)h->Hn;
-    else
-        ln.Yf = (float*)h->Hn;
-    launch_layernorm(ln, st);
-    return run_head_tail(h, k, h->Hn, rows, out, ldy, detok, dt, st);
-}
-
-// ... from the head's LayerNorm output (rows, d) in the operand dtype on: Linear+GELU -> Linear(D_k) [-> de-tokenize]
-int run_head_tail(m3pc_handle* h, int k, const void* ln_rows, int rows, float* out, int ldy, bool detok, int dt, hipStream_t st) {
-    const int d = h->d;
-    const std::string kn = KEYN[k];
-    GemmP p = gemm_basic(ln_rows, d, Wop(h, "output_head_dict." + kn + ".1.weight", dt), d, rows, d, d,
-                         W(h, "output_head_dict." + kn + ".1.bias").f);
-    p.gelu = 1;
-    gemm_out(p, DT_F32, h->G, d);
-    gemm(h, p, dt, st);
-    HeadOutP ho;
-    memset(&ho, 0, sizeof(ho));
-    ho.X = h->G;
-    ho.ldx = d;
-    ho.rows = rows;
-    ho.d = d;
-    ho.D = h->feat[k];
-    ho.W = W(h, "output_head_dict." + kn + ".3.weight").f;
-    ho.b = W(h, "output_head_dict." + kn + ".3.bias").f;
-    if (detok && h->tok_norm[k]) {
-        ho.mean = h->tok_mean[k];
-        ho.stdv = h->tok_std[k];
-    }
-    ho.Y = out;
-    ho.ldy = ldy;
-    launch_head_out(ho, st);
-    return check_launch("head");
-}
-
-// Generic forward on `batch` sequences; outputs raw head values (no de-tokenization)
-int forward_impl(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, float* out_states, float* out_rewards,
-                 float* out_returns, float* out_mu, float* out_std, int dt, hipStream_t st) {
-    const int T = h->T, d = h->d;
-    if ((long long)batch * 4 * T > h->R) return fail(M3PC_ENOMEM, "batch %d exceeds workspace (max_batch=%d)", batch, h->dm.max_batch);
-    CHK(run_encoder(h, pl, in, batch, dt, st));
-    GatherP g;
-    memset(&g, 0, sizeof(g));
-    g.Xe = h->EncOut;
-    g.xe_bstride = (long long)pl->Le * d;
-    g.table = h->mask_tokens;
-    g.rowsrc = pl->d_dec_rowsrc;
-    g.rows_per_batch = 4 * T;
-    g.batch = batch;
-    g.d = d;
-    if (dt == DT_BF16)
-        g.outb = (bf16_t*)h->Z;
-    else
-        g.out = (float*)h->Z;
-    launch_gather_rows(g, st);
-    CHK(run_decoder_full(h, h->Z, batch, dt, st));
-    float* outs[4] = {out_states, nullptr, out_rewards, out_returns};
-    for (int k = 0; k < 4; ++k) {
-        if (k == M3PC_ACTIONS || !outs[k]) continue;
-        RowMap m{T, 4 * T, k * T};
-        CHK(run_head(h, k, h->Y, m, batch * T, outs[k], h->feat[k], false, dt, st));
-    }
-    if (out_mu && out_std) {
-        LnP ln;
-        memset(&ln, 0, sizeof(ln));
-        ln.X = h->Y;
-        ln.ldx = d;
-        ln.xmap = RowMap{T, 4 * T, M3PC_ACTIONS * T};
-        ln.rows = batch * T;
-        ln.d = d;
-        ln.g1 = W(h, "decoder.norm.weight").f;
-        ln.b1 = W(h, "decoder.norm.bias").f;
-        ln.Yf = h->G;
-        launch_layernorm(ln, st);
-        ActorP a;
-        memset(&a, 0, sizeof(a));
-        a.X = h->G;
-        a.ldx = d;
-        a.rows = batch * T;
-        a.d = d;
-        a.A = h->A;
-        a.Wmu = W(h, "output_head_dict.actions.mu.weight").f;
-        a.bmu = W(h, "output_head_dict.actions.mu.bias").f;
-        a.Wls = W(h, "output_head_dict.actions.log_std.weight").f;
-        a.bls = W(h, "output_head_dict.actions.log_std.bias").f;
-        a.mu = out_mu;
-        a.sd = out_std;
-        launch_actor_head(a, st);
-    }
-    return check_launch("forward");
-}
-
-// ---------------------------------------------------------------------------------- shared decoder tables
-// toks: the decoder tokens (key * T + t) of the query set, group by group; hh: what the cached set is keyed on
-int build_query_list(m3pc_handle* h, Plan* pl, int qi, int hh, const std::vector<int>& toks, int n_groups, int key0, int key1) {
-    Plan::Query& q = pl->query[qi];
-    if (q.built && q.h == hh) return 0;
-    const int T = h->T;
-    q.h = hh;
-    q.nq = (int)toks.size();
-    q.n_groups = n_groups;
-    q.grp = q.nq / n_groups;
-    q.qkeys[0] = key0;
-    q.qkeys[1] = key1;
-    if (q.nq < 1 || q.nq > 2 * T || q.grp * n_groups != q.nq) return fail(M3PC_EINVAL, "bad query set (%d tokens, %d groups)", q.nq, n_groups);
-    std::vector<int> tab(q.nq), mix(q.nq);
-    q.all_masked = true;
-    for (int j = 0; j < q.nq; ++j) {
-        const int i = toks[j];
-        tab[j] = -i - 1;
-        if (pl->dec_src[i] >= 0) {
-            q.all_masked = false;
-            mix[j] = pl->dec_src[i];
-        } else {
-            mix[j] = -i - 1;
-        }
-    }
-    q.nu = 0;
-    if (!q.all_masked) {
-        int nu = 0;
-        while (nu < q.nq && pl->dec_src[toks[nu]] >= 0) ++nu;
-        bool ok = nu > 0;
-        for (int j = nu; j < q.nq && ok; ++j) ok = pl->dec_src[toks[j]] < 0;                       // a prefix, nothing behind it
-        for (int j = 1; j < nu && ok; ++j)                                                           // consecutive tokens / rows of one key
-            ok = toks[j] == toks[0] + j && toks[j] / T == toks[0] / T && pl->dec_src[toks[j]] == pl->dec_src[toks[0]] + j;
-        if (ok) {
-            q.nu = nu;
-            q.nu_key = toks[0] / T;
-            q.nu_enc0 = pl->dec_src[toks[0]];
-            q.nu_kept0 = q.nu_enc0 - pl->enc_off[q.nu_key];  // index among the key's kept tokens (the compact position table's row)
-        }
-    }
-    if (!q.d_q_rowsrc_tab) {
-        CHK(dmalloc(&q.d_q_rowsrc_tab, (size_t)2 * T));
-        CHK(dmalloc(&q.d_q_rowsrc_mix, (size_t)2 * T));
-    }
-    HIPCHK(hipMemcpy(q.d_q_rowsrc_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(q.d_q_rowsrc_mix, mix.data(), mix.size() * sizeof(int), hipMemcpyHostToDevice));
-    for (int pr = 0; pr < 2; ++pr) q.tab[pr].valid = false;
-    q.built = true;
-    return 0;
-}
-
-// the two scored keys of a plan step at positions idx .. T-1: qi 0 = rtg (rewards, returns), 1 = critic (states, rewards)
-int build_query(m3pc_handle* h, Plan* pl, int qi, int hh) {
-    if (pl->query[qi].built && pl->query[qi].h == hh) return 0;
-    const int T = h->T, idx = T - hh;
-    const int k0 = qi == 0 ? M3PC_REWARDS : M3PC_STATES, k1 = qi == 0 ? M3PC_RETURNS : M3PC_REWARDS;
-    std::vector<int> toks;
-    for (int s = 0; s < 2; ++s)
-        for (int t = 0; t < hh; ++t) toks.push_back((s == 0 ? k0 : k1) * T + idx + t);
-    return build_query_list(h, pl, qi, hh, toks, 2, k0, k1);
-}
-
-// Candidate-independent decoder rows for plan `pl`: run decoder-embed, LN1 and the QKV projection on a
-// single sequence whose un-masked slots are zero (never read) and masked slots hold the mask tokens.
-int build_tables(m3pc_handle* h, Plan* pl, int qi, int dt, hipStream_t st) {
-    Plan::Query& q = pl->query[qi];
-    SharedTables& tb = q.tab[dt];
-    if (tb.valid) return 0;
-    const int T = h->T, d = h->d;
-    const size_t es = dtype_size(dt);
-    if (!tb.Yall) {
-        CHK(dmalloc(&tb.Yall, (size_t)4 * T * d));
-        CHK(dmalloc((char**)&tb.QKVm, (size_t)4 * T * 3 * d * es));
-        CHK(dmalloc((char**)&tb.QKVq, (size_t)2 * T * 3 * d * es));
-        CHK(dmalloc(&tb.Yq, (size_t)2 * T * d));
-    }
-    // Z: mask tokens everywhere (un-masked rows are ignored downstream)
-    std::vector<int> rs(4 * T);
-    for (int i = 0; i < 4 * T; ++i) rs[i] = -(i / T) - 1;
-    int* d_rs = nullptr;
-    CHK(dmalloc(&d_rs, rs.size()));
-    HIPCHK(hipMemcpyAsync(d_rs, rs.data(), rs.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    GatherP g;
-    memset(&g, 0, sizeof(g));
-    g.table = h->mask_tokens;
-    g.rowsrc = d_rs;
-    g.rows_per_batch = 4 * T;
-    g.batch = 1;
-    g.d = d;
-    if (dt == DT_BF16)
-        g.outb = (bf16_t*)h->Z;
-    else
-        g.out = (float*)h->Z;
-    launch_gather_rows(g, st);
-    for (int k = 0; k < 4; ++k) {
-        RowMap m{T, 4 * T, k * T};
-        dec_embed(h, k, h->Z, m, tb.Yall, m, T, T, dt, st);
-    }
-    const std::string pfx = "decoder.layers.0";
-    LnP ln;
-    memset(&ln, 0, sizeof(ln));
-    ln.X = tb.Yall;
-    ln.ldx = d;
-    ln.rows = 4 * T;
-    ln.d = d;
-    ln.g1 = W(h, pfx + ".norm1.weight").f;
-    ln.b1 = W(h, pfx + ".norm1.bias").f;
-    if (dt == DT_BF16)
-        ln.Yb = (bf16_t*)h->Hn;
-    else
-        ln.Yf = (float*)h->Hn;
-    launch_layernorm(ln, st);
-    // full q|k|v rows of the 4T-token sequence go to h->QKV (fp32 copy for the gather), then compacted
-    {
-        GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".self_attn.in_proj_weight", dt), d, 4 * T, 3 * d, d,
-                             W(h, pfx + ".self_attn.in_proj_bias").f);
-        gemm_out(p, DT_F32, h->QKV, 3 * d);
-        gemm(h, p, dt, st);
-    }
-    g.table = (const float*)h->QKV;
-    g.d = 3 * d;
-    g.rowsrc = pl->d_masked_rowsrc;
-    g.rows_per_batch = pl->Lm;
-    g.out = dt == DT_F32 ? (float*)tb.QKVm : nullptr;
-    g.outb = dt == DT_BF16 ? (bf16_t*)tb.QKVm : nullptr;
-    launch_gather_rows(g, st);
-    g.rowsrc = q.d_q_rowsrc_tab;
-    g.rows_per_batch = q.nq;
-    g.out = dt == DT_F32 ? (float*)tb.QKVq : nullptr;
-    g.outb = dt == DT_BF16 ? (bf16_t*)tb.QKVq : nullptr;
-    launch_gather_rows(g, st);
-    g.table = tb.Yall;
-    g.d = d;
-    g.out = tb.Yq;
-    g.outb = nullptr;
-    launch_gather_rows(g, st);
-    static const bool no_prestats = M3PC_ENV("M3PC_NO_PRESTATS") != nullptr;  // A/B switch
-    if (dt == DT_BF16 && q.all_masked && pl->Lm > 0 && pl->Lm <= 256 && !no_prestats) {
-        // queries and masked-token keys are both candidate-independent: reduce that block of the softmax once
-        if (!tb.pre_m) {
-            CHK(dmalloc(&tb.pre_m, (size_t)h->nh * q.nq));
-            CHK(dmalloc(&tb.pre_l, (size_t)h->nh * q.nq));
-            CHK(dmalloc(&tb.pre_O, (size_t)h->nh * q.nq * h->hd));
-        }
-        AttnP at;
-        memset(&at, 0, sizeof(at));
-        at.Q = tb.QKVq;
-        at.ldq = 3 * d;
-        at.Lq = q.nq;
-        at.K2 = (const char*)tb.QKVm + (size_t)d * es;
-        at.V2 = (const char*)tb.QKVm + (size_t)2 * d * es;
-        at.ldkv2 = 3 * d;
-        at.L2 = pl->Lm;
-        at.n_head = h->nh;
-        at.hd = h->hd;
-        at.scale = 1.0f / sqrtf((float)h->hd);
-        launch_attention_prestats(at, tb.pre_m, tb.pre_l, tb.pre_O, st);
-    }
-    HIPCHK(hipStreamSynchronize(st));
-    hipFree(d_rs);
-    tb.valid = true;
-    return check_launch("tables");
-}
-
-enum { TAIL_HEADS = 0, TAIL_X = 1 };
-// The exactly pruned decoder (mtm_model.py:663-716 restricted to what the caller reads) behind an encoder pass over `n`
-// sequences of plan `pl` (encoder output in Z [bf16] / EncOut [fp32]): decoder inputs and K|V of the un-masked tokens,
-// the queries of set `q` (shared table rows when every query token is masked, per-sequence rows else), attention over
-// own + masked keys, out-proj / FFN on the n * nq query rows, then
-//   TAIL_HEADS: decoder.norm + the output head of each group's key -> h->pred[s] (n * grp, D_k) de-tokenised
-//   TAIL_X:     the fp32 block output rows (n * nq, d) -> *xrows (the caller applies decoder.norm / the action head)
-int pruned_decoder(m3pc_handle* h, Plan* pl, Plan::Query& q, SharedTables& tb, int n, int dt, hipStream_t st, int tail,
-                   float** xrows) {
-    const int d = h->d, hh = q.grp, Le = pl->Le, nq = q.nq;
-    const size_t es = dtype_size(dt);
-    CHK(ensure_edec(h, pl, st));
-    float* Y1 = h->EncOut;  // (n*nq, d) decoder residual of the query tokens (EncOut is dead: Z/Y hold its uses)
-    if (xrows) *xrows = Y1;
-    // decoder inputs of the un-masked tokens
-    const void* enc_op = dt == DT_BF16 ? h->Z : (const void*)h->EncOut;
-    const std::string pfx = "decoder.layers.0";
-    LnP ln;
-    memset(&ln, 0, sizeof(ln));
-    ln.X = h->Y;
-    ln.ldx = d;
-    ln.rows = n * Le;
-    ln.d = d;
-    ln.g1 = W(h, pfx + ".norm1.weight").f;
-    ln.b1 = W(h, pfx + ".norm1.bias").f;
-    if (dt == DT_BF16)
-        ln.Yb = (bf16_t*)h->Hn;
-    else
-        ln.Yf = (float*)h->Hn;
-    bool kv_done = false;
-    static const bool no_kv_fused = M3PC_ENV("M3PC_NO_KV_FUSED") != nullptr || M3PC_ENV("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
-    static const bool no_fused_tail = M3PC_ENV("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
-    static const bool no_mix_prefix = M3PC_ENV("M3PC_NO_MIX_PREFIX") != nullptr;   // A/B switch
-    const bool kv_fusable = dt == DT_BF16 && !no_kv_fused && (double)n * Le * h->pass_scale >= 512.0 && h->kvstream[0] &&
-                            (pl->kept[0] || pl->kept[1]) && !pl->kept[2] && !pl->kept[3];
-    // Some query tokens un-masked, as a prefix (Query::nu): the fused decoder input still serves K|V, the nu per-sequence
-    // query rows get their decoder inputs / Q projection from few-row GEMMs of their own, and the fused tail takes their
-    // residual rows from behind the shared table (many-row bf16 passes only: the choice goes by the size of the whole step)
-    const bool mixp = kv_fusable && !q.all_masked && q.nu > 0 && !no_mix_prefix && !no_fused_tail && h->wstream.count(pfx) &&
-                      (double)n * nq * h->pass_scale >= (double)FUSED_MIN_ROWS && (long long)nq + (long long)n * q.nu <= h->R;
-    if (kv_fusable && (q.all_masked || mixp)) {
-        // embedding, norm1 and the K|V projection in one launch (kv_fused_kernel): the fp32 rows Y are consumed by nothing
-        // else when every scored token is masked
-        KvFusedP kp;
-        memset(&kp, 0, sizeof(kp));
-        kp.Z = (const bf16_t*)h->Z;
-        kp.ldz = d;
-        int g = 0;
-        for (int k = 0; k < 2; ++k) {
-            if (!pl->kept[k]) continue;
-            kp.M[g] = n * pl->kept[k];
-            kp.map[g] = RowMap{pl->kept[k], Le, pl->enc_off[k]};
-            kp.rowtab[g] = pl->edec_kept[k];
-            kp.rt_mod[g] = pl->kept[k];
-            kp.wstream[g] = h->kvstream[k];
-            ++g;
-        }
-        kp.ln_g = ln.g1;
-        kp.ln_b = ln.b1;
-        kp.bkv = W(h, pfx + ".self_attn.in_proj_bias").f + d;
-        kp.KV = (bf16_t*)h->QKV;
-        kp.ldkv = 2 * d;
-        kp.kv_bytes = (unsigned)((size_t)n * Le * 2 * d * 2);
-        GemmTimer t(h, st, 2.0 * n * Le * (3.0 * d * d), dt, 2);
-        kv_done = launch_kv_fused(kp, st);
-    }
-    if (!kv_done) {
-    for (int k = 0; k < 4; ++k) {
-        if (!pl->kept[k]) continue;
-        RowMap mm{pl->kept[k], Le, pl->enc_off[k]};
-        dec_embed(h, k, enc_op, mm, h->Y, mm, n * pl->kept[k], pl->kept[k], dt, st, pl->edec_kept[k]);
-    }
-    {  // K|V of the un-masked tokens: in_proj rows [d, 3d); norm1 rides on the operand load in the few-row fp32 pass
-        const char* wkv = (const char*)Wop(h, pfx + ".self_attn.in_proj_weight", dt) + (size_t)d * d * es;
-        GemmP p = gemm_basic(h->Hn, d, wkv, d, n * Le, 2 * d, d, W(h, pfx + ".self_attn.in_proj_bias").f + d);
-        gemm_out(p, dt, h->QKV, 2 * d);
-        GemmP t = p;
-        t.A = h->Y;
-        t.a_ln_g = ln.g1;
-        t.a_ln_b = ln.b1;
-        if (can_fold_ln(h, t, dt)) {
-            p = t;
-        } else {
-            launch_layernorm(ln, st);
-        }
-        gemm(h, p, dt, st);
-    }
-    }
-    // queries
-    const void* Qp;
-    long long q_bstride;
-    int ldq;
-    float* Yq_rows = nullptr;  // per-candidate residual rows (n*nq, d) when some scored token is un-masked
-    char* kvu = (char*)h->QKV;
-    char* qbuf = kvu + (size_t)n * Le * 2 * d * es;  // behind K|V in the same buffer
-    float* Rcomb = nullptr;  // mixp: [shared residual table (nq rows)] [per-sequence residual rows of the nu un-masked queries (n nu)]
-    if (mixp) {
-        const int nu = q.nu, kq = q.nu_key;
-        Rcomb = h->X;  // (the encoder residual stream is dead by now)
-        float* Yu = Rcomb + (size_t)nq * d;
-        HIPCHK(hipMemcpyAsync(Rcomb, tb.Yq, (size_t)nq * d * sizeof(float), hipMemcpyDeviceToDevice, st));
-        // decoder inputs of the nu query tokens of every sequence: Z rows nu_enc0 .. of the sequence, the key's embedding
-        RowMap am{nu, Le, q.nu_enc0};
-        dec_embed(h, kq, enc_op, am, Yu, rowmap_identity(), n * nu, nu, dt, st, pl->edec_kept[kq] + (size_t)q.nu_kept0 * d);
-        ln.X = Yu;
-        ln.rows = n * nu;
-        launch_layernorm(ln, st);
-        GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".self_attn.in_proj_weight", dt), d, n * nu, d, d,
-                             W(h, pfx + ".self_attn.in_proj_bias").f);
-        gemm_out(p, dt, qbuf, d);
-        gemm(h, p, dt, st);
-        Qp = qbuf;
-        q_bstride = (long long)nu * d;
-        ldq = d;
-    } else if (q.all_masked) {
-        Qp = tb.QKVq;
-        q_bstride = 0;
-        ldq = 3 * d;
-    } else {
-        Yq_rows = h->X;  // encoder residual stream is dead by now
-        GatherP g;
-        memset(&g, 0, sizeof(g));
-        g.Xe = h->Y;
-        g.xe_bstride = (long long)Le * d;
-        g.table = tb.Yall;
-        g.rowsrc = q.d_q_rowsrc_mix;
-        g.rows_per_batch = nq;
-        g.batch = n;
-        g.d = d;
-        g.out = Yq_rows;
-        launch_gather_rows(g, st);
-        ln.X = Yq_rows;
-        ln.rows = n * nq;
-        launch_layernorm(ln, st);
-        GemmP p = gemm_basic(h->Hn, d, Wop(h, pfx + ".self_attn.in_proj_weight", dt), d, n * nq, d, d,
-                             W(h, pfx + ".self_attn.in_proj_bias").f);
-        gemm_out(p, dt, qbuf, d);
-        gemm(h, p, dt, st);
-        Qp = qbuf;
-        q_bstride = (long long)nq * d;
-        ldq = d;
-    }
-    {
-        AttnP at;
-        memset(&at, 0, sizeof(at));
-        at.Q = Qp;
-        at.q_bstride = q_bstride;
-        at.ldq = ldq;
-        at.K1 = kvu;
-        at.V1 = kvu + (size_t)d * es;
-        at.kv1_bstride = (long long)Le * 2 * d;
-        at.ldkv1 = 2 * d;
-        at.L1 = Le;
-        at.K2 = (const char*)tb.QKVm + (size_t)d * es;
-        at.V2 = (const char*)tb.QKVm + (size_t)2 * d * es;
-        at.ldkv2 = 3 * d;
-        at.L2 = pl->Lm;
-        at.O = h->O;
-        at.o_bstride = (long long)nq * d;
-        at.ldo = d;
-        at.batch = n;
-        at.n_head = h->nh;
-        at.hd = h->hd;
-        at.Lq = nq;
-        at.scale = 1.0f / sqrtf((float)h->hd);
-        if (mixp) {  // queries [0, nu) per sequence, the others from the shared table behind them
-            at.Lq = q.nu;
-            at.orow1 = 0;
-            if (nq > q.nu) {
-                at.Q2 = (const char*)tb.QKVq + (size_t)q.nu * 3 * d * es;
-                at.ldq2 = 3 * d;
-                at.Lq2 = nq - q.nu;
-                at.orow2 = q.nu;
-            }
-        }
-        if (dt == DT_BF16 && q.all_masked && tb.pre_m) {
-            // the masked tokens' keys meet the same (shared) queries for every candidate: that block of the softmax
-            // was reduced when the tables were built, only the candidate's own Le keys are visited here
-            at.K2 = at.V2 = nullptr;
-            at.L2 = 0;
-            at.pre_m = tb.pre_m;
-            at.pre_l = tb.pre_l;
-            at.pre_O = tb.pre_O;
-        }
-        launch_attention(at, dt, st);
-    }
-    static const bool no_fused = M3PC_ENV("M3PC_NO_BLOCK_FUSED") != nullptr;  // A/B switch
-    bool tail_done = false;
-    static const bool no_split = M3PC_ENV("M3PC_NO_BLOCK_SPLIT") != nullptr;  // A/B switch
-    const double step_rows = (double)n * nq * h->pass_scale;
-    const bool tail_split = !no_split && step_rows < (double)FUSED_MIN_ROWS && step_rows >= (double)SPLIT_MIN_ROWS;  // (run_block)
-    if (dt == DT_BF16 && !no_fused && (step_rows >= (double)FUSED_MIN_ROWS || tail_split) && h->wstream.count(pfx)) {
-        // out-proj, norm2, FFN, decoder.norm and the two heads' LayerNorms in one launch (block_fused.hip): the rows of
-        // head s land in the s-th block of n*h rows of Hn
-        BlockP b;
-        memset(&b, 0, sizeof(b));
-        b.O = (const bf16_t*)h->O;
-        b.ldo = d;
-        b.M = n * nq;
-        if (mixp) {
-            b.rowtab = Rcomb;
-            b.rt_mod = nq;
-            b.res_nu = q.nu;
-        } else if (q.all_masked) {
-            b.rowtab = tb.Yq;
-            b.rt_mod = nq;
-        } else {
-            b.res = Yq_rows;
-            b.ldr = d;
-        }
-        b.wstream = h->wstream[pfx];
-        b.bo = W(h, pfx + ".self_attn.out_proj.bias").f;
-        b.b1 = W(h, pfx + ".linear1.bias").f;
-        b.b2 = W(h, pfx + ".linear2.bias").f;
-        b.ln2_g = W(h, pfx + ".norm2.weight").f;
-        b.ln2_b = W(h, pfx + ".norm2.bias").f;
-        if (tail == TAIL_HEADS) {
-            b.lnA_g = W(h, "decoder.norm.weight").f;
-            b.lnA_b = W(h, "decoder.norm.bias").f;
-            for (int s = 0; s < 2; ++s) {  // (one group: LN_B[0] for every row; the kernel's tables still hold two)
-                const int ks = q.qkeys[s < q.n_groups ? s : 0];
-                b.lnB_g[s] = W(h, std::string("output_head_dict.") + KEYN[ks] + ".0.weight").f;
-                b.lnB_b[s] = W(h, std::string("output_head_dict.") + KEYN[ks] + ".0.bias").f;
-            }
-            if (q.n_groups == 2) {
-                b.out_mod = nq;
-                b.out_grp = hh;
-            }
-        }
-        // both scored keys have scalar heads (rtg_guiding: rewards, returns): the heads run inside the tail, on workgroups
-        // that each own rows of one key; else the heads' LayerNorm rows go to Hn and the heads are launches of their own
-        static const bool no_head_fused = M3PC_ENV("M3PC_NO_HEAD_FUSED") != nullptr;  // A/B switch
-        const bool fuse_heads = tail == TAIL_HEADS && q.n_groups == 2 && !tail_split && !no_head_fused && q.qkeys[0] == M3PC_REWARDS && q.qkeys[1] == M3PC_RETURNS &&
-                                h->feat[M3PC_REWARDS] == 1 && h->feat[M3PC_RETURNS] == 1;
-        if (tail_split) {  // few tiles: four workgroups per tile, the LayerNorms on the reduce of their partials
-            b.split = 1;
-            b.Xout = (float*)h->F;
-            b.ldx = d;
-        } else if (fuse_heads) {
-            for (int s = 0; s < 2; ++s) {
-                const std::string hp = std::string("output_head_dict.") + KEYN[q.qkeys[s]];
-                b.head_out[s] = h->pred[s];
-                b.hb1[s] = W(h, hp + ".1.bias").f;
-                b.hw2[s] = W(h, hp + ".3.weight").f;
-                b.hb2[s] = W(h, hp + ".3.bias").f;
-                if (h->tok_norm[q.qkeys[s]]) {
-                    b.hmean[s] = h->tok_mean[q.qkeys[s]];
-                    b.hstd[s] = h->tok_std[q.qkeys[s]];
-                }
-            }
-        } else if (tail == TAIL_HEADS) {
-            b.Hout = (bf16_t*)h->Hn;
-            b.ldh = d;
-        } else {
-            b.Xout = Y1;
-            b.ldx = d;
-        }
-        if (h->stamp_log) {
-            b.stamps = h->stamp_log + 64 * (h->stamp_i++ % h->stamp_cap);
-            b.stamp_block = 37;
-        }
-        bool ok;
-        {
-            GemmTimer t(h, st, 2.0 * n * nq * ((double)d * d + 2.0 * d * h->ff + (fuse_heads ? (double)d * d : 0.0)), dt, 1);
-            ok = launch_block_fused(b, st);
-        }
-        if (ok && tail_split) {
-            SplitReduceP r;
-            memset(&r, 0, sizeof(r));
-            r.slabs = (const float*)h->F;
-            r.M = n * nq;
-            if (tail == TAIL_HEADS) {
-                r.lnA_g = b.lnA_g;
-                r.lnA_b = b.lnA_b;
-                for (int s = 0; s < 2; ++s) {
-                    r.lnB_g[s] = b.lnB_g[s];
-                    r.lnB_b[s] = b.lnB_b[s];
-                }
-                r.out_mod = b.out_mod;
-                r.out_grp = b.out_grp;
-                r.Hout = (bf16_t*)h->Hn;
-                r.ldh = d;
-            } else {
-                r.Xout = Y1;
-                r.ldx = d;
-            }
-            launch_block_split_reduce(r, st);
-        }
-        if (ok && !fuse_heads && tail == TAIL_HEADS) {
-            for (int s = 0; s < q.n_groups; ++s)
-                CHK(run_head_tail(h, q.qkeys[s], (const char*)h->Hn + (size_t)s * n * hh * d * es, n * hh, h->pred[s],
-                                  h->feat[q.qkeys[s]], true, dt, st));
-        }
-        tail_done = ok;
-    }
-    if (!tail_done && mixp) return fail(M3PC_EINVAL, "pruned_decoder: the fused layer tail did not take a pass set up for it");
-    if (!tail_done) {
-    {
-        GemmP p = gemm_basic(h->O, d, Wop(h, pfx + ".self_attn.out_proj.weight", dt), d, n * nq, d, d,
-                             W(h, pfx + ".self_attn.out_proj.bias").f);
-        if (q.all_masked) {
-            p.rowtab = tb.Yq;
-            p.rt_mod = nq;
-            p.rt_ld = d;
-        } else {
-            p.res = Yq_rows;
-            p.ldr = d;
-        }
-        gemm_out(p, DT_F32, Y1, d);
-        ln.X = Y1;
-        ln.rows = n * nq;
-        ln.g1 = W(h, pfx + ".norm2.weight").f;
-        ln.b1 = W(h, pfx + ".norm2.bias").f;
-        GemmP p1 = gemm_basic(h->Hn, d, Wop(h, pfx + ".linear1.weight", dt), d, n * nq, h->ff, d, W(h, pfx + ".linear1.bias").f);
-        p1.gelu = 1;
-        gemm_out(p1, dt, h->F, h->ff);
-        GemmP t = p1;
-        t.A = Y1;
-        t.a_ln_g = ln.g1;
-        t.a_ln_b = ln.b1;
-        if (can_fold_ln(h, t, dt)) {  // re-score: norm2 rides on linear1's operand load ...
-            gemm(h, p, dt, st);
-            gemm(h, t, dt, st);
-        } else {
-            if (dt == DT_F32) {       // ... or on the split-K reduce when there is one
-                p.ln_g = ln.g1;
-                p.ln_b = ln.b1;
-                p.ln_out = ln.Yf;
-            }
-            if (!gemm(h, p, dt, st)) launch_layernorm(ln, st);
-            gemm(h, p1, dt, st);
-        }
-    }
-    {
-        GemmP p = gemm_basic(h->F, h->ff, Wop(h, pfx + ".linear2.weight", dt), h->ff, n * nq, d, h->ff, W(h, pfx + ".linear2.bias").f);
-        p.res = Y1;
-        p.ldr = d;
-        gemm_out(p, DT_F32, Y1, d);
-        gemm(h, p, dt, st);
-    }
-    // heads of the scored keys -> pred[s] (n*grp, D_k), de-tokenized
-    for (int s = 0; s < q.n_groups && tail == TAIL_HEADS; ++s) {
-        RowMap xm{hh, nq, s * hh};
-        CHK(run_head(h, q.qkeys[s], Y1, xm, n * hh, h->pred[s], h->feat[q.qkeys[s]], true, dt, st));
-    }
-    }
-    return check_launch("pruned_decoder");
-}
-
-// ---------------------------------------------------------------------------------- candidate pass
-// widx (optional, device (n,)): candidate c belongs to history window widx[c] of states (., T, S) / rewards (., T, 1);
-// without it all candidates share window 0 and the history tokens are computed once (first-layer sharing).
-// stage_from / stage_to / ln_state: the pass can be enqueued in pieces -- stage k < n_enc_layer is encoder layer k (the
-// embedding goes with stage 0), stage n_enc_layer everything behind the encoder -- so that the pieces of two candidate halves
-// can be enqueued alternately (m3pc_plan_step)
-int candidate_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* rewards, int n,
-                   const float* sample_actions, float* expect_return, float* pred_rewards, float* pred_boot, int dt,
-                   hipStream_t st, const int* widx = nullptr, int stage_from = 0, int stage_to = 1 << 30, PieceState* ln_state = nullptr) {
-    const int T = h->T, d = h->d, hh = a->horizon, idx = T - hh;
-    const size_t es = dtype_size(dt);
-    struct ScaleScope {
-        m3pc_handle* h;
-        ~ScaleScope() { h->pass_scale = 1.0; }
-    } scale_scope{h};
-    h->pass_scale = !widx && a->n_total > n ? (double)a->n_total / (double)n : 1.0;
-    Plan* pl = nullptr;
-    CHK(get_mask_plan(h, 1, idx, &pl));  // fd mask (finetune_omtm/masks.py:30-44)
-    const int qi = a->mode == M3PC_MODE_RTG ? 0 : 1;
-    CHK(build_query(h, pl, qi, hh));
-    CHK(build_tables(h, pl, qi, dt, st));
-    Plan::Query& q = pl->query[qi];
-    SharedTables& tb = q.tab[dt];
-    const int Le = pl->Le, nq = q.nq;
-    if ((long long)n * Le > h->R || (long long)n * nq > h->R) return fail(M3PC_ENOMEM, "n_count %d exceeds workspace", n);
-
-    TokIn in;
-    memset(&in, 0, sizeof(in));
-    in.ptr[M3PC_STATES] = states;
-    in.normalize[M3PC_STATES] = h->tok_norm[M3PC_STATES];
-    in.ptr[M3PC_ACTIONS] = h->cand;
-    in.bstride[M3PC_ACTIONS] = (long long)T * h->A;
-    in.normalize[M3PC_ACTIONS] = h->tok_norm[M3PC_ACTIONS];
-    in.ptr[M3PC_REWARDS] = rewards;
-    in.ptr[M3PC_RETURNS] = h->rtok;
-    in.widx = widx;
-    in.wstride[M3PC_STATES] = (long long)T * h->S;
-    in.wstride[M3PC_REWARDS] = T;
-    // encoder order is states 0..idx, actions 0..T-1: everything before actions[idx] is history, shared by all candidates
-    // of one window
-    const int nl_enc = h->dm.n_enc_layer;
-    if (stage_from < nl_enc) CHK(run_encoder(h, pl, in, n, dt, st, dt == DT_BF16, widx ? 0 : (idx + 1) + idx, stage_from, stage_to, ln_state));
-    if (stage_to <= nl_enc) return check_launch("candidate_pass");
-
-    CHK(pruned_decoder(h, pl, q, tb, n, dt, st, TAIL_HEADS, nullptr));
-    const float* rw;
-    const float* boot;
-    float boot_scale;
-    if (a->mode == M3PC_MODE_RTG) {
-        rw = h->pred[0];
-        boot = h->pred[1];
-        boot_scale = 1000.0f;  // learner.py:305
-    } else {
-        if (!h->critic_set) return fail(M3PC_ESTATE, "critic weights not set");
-        CriticP c;
-        memset(&c, 0, sizeof(c));
-        c.states = h->pred[0];
-        c.actions = sample_actions;
-        c.rows = n * hh;
-        c.S = h->S;
-        c.A = h->A;
-        c.hidden = h->dm.critic_hidden;
-        c.om = h->c_om;
-        c.os = h->c_os;
-        for (int i = 0; i < 2; ++i) {
-            c.W1T[i] = h->cW1T[i];
-            c.b1[i] = h->cb1[i];
-            c.W2T[i] = h->cW2T[i];
-            c.b2[i] = h->cb2[i];
-            c.W3[i] = h->cW3[i];
-            c.b3[i] = h->cb3[i];
-            c.W1F[i] = h->cW1F[i];
-            c.W2F[i] = h->cW2F[i];
-        }
-        c.q = h->qv;
-        launch_critic(c, st);
-        rw = h->pred[1];
-        boot = h->qv;
-        boot_scale = 1.0f;
-    }
-    ScoreP sc;
-    memset(&sc, 0, sizeof(sc));
-    sc.rewards = rw;
-    sc.boot = boot;
-    sc.n = n;
-    sc.h = hh;
-    sc.boot_scale = boot_scale;
-    sc.gamma = (float)a->discount;
-    sc.lmbda = a->lmbda;
-    sc.expect_return = expect_return;
-    sc.boot_out = pred_boot;
-    sc.scatter_index = h->score_scatter_index;  // (m3pc_rescore_listed: the scores also go straight to their candidates' slots)
-    sc.scatter_out = h->score_scatter_out;
-    launch_score(sc, st);
-    if (pred_rewards) HIPCHK(hipMemcpyAsync(pred_rewards, rw, (size_t)n * hh * sizeof(float), hipMemcpyDeviceToDevice, st));
-    return check_launch("candidate_pass");
-}
 
 int find_tensor(const m3pc_named_tensor* list, int n, const std::string& name) {
     for (int i = 0; i < n; ++i)
@@ -1732,7 +32,9 @@ int find_tensor(const m3pc_named_tensor* list, int n, const std::string& name) {
     return -1;
 }
 
+
 }  // namespace
+
 
 // =====================================================================================================
 static int fill_rtok(m3pc_handle* h, const double* rtg, int n_windows, hipStream_t st);

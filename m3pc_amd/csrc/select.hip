@@ -297,10 +297,12 @@ void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st) {
     }
     int np = 2;
     while (np < n) np <<= 1;
-    static bool attr = false;
-    if (!attr) {
+    static bool attr[64] = {};  // (a per-device opt-in)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr[dev]) {
         (void)hipFuncSetAttribute((const void*)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
-        attr = true;
+        attr[dev] = true;
     }
     hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), (size_t)np * 8, st, v, n, np, k, idx_out);
 }

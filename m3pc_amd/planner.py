@@ -33,7 +33,9 @@ import numpy as np
 import torch
 
 from . import capi, dist as mdist
-from .certificate import RACE_MAX, _TicketOps, _WindowOps, resolve as _resolve_certificate
+from .certificate import RACE_MAX, _TicketOps, resolve as _resolve_certificate
+from .goal import GoalMixin
+from .lockstep import LockstepMixin
 from .tokenizers import ContinuousTokenizer, DataStatistics, SquashedNormal, TokenizerManager
 
 KEYS = capi.KEYS
@@ -122,7 +124,7 @@ class PlanTicket:
         return ev if self.eval else sa
 
 
-class HipPlanner:
+class HipPlanner(GoalMixin, LockstepMixin):
     def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], tokenizer_manager, q_state_dict=None,
                  obs_mean=None, obs_std=None, n_embd: int = 512, n_head: int = 4, n_enc_layer: int = 2,
                  n_dec_layer: int = 1, precision: str = "fp32", rescore_topk: int = 16, device: Optional[int] = None,
@@ -722,165 +724,6 @@ class HipPlanner:
         eval_action = dist_.mean[0, T - h]
         return sample_action, eval_action
 
-    # ---------------------------------------------------------------------------------------- zero-shot
-    def assemble_goal_window(self, sequence_history, rtg=None, percentage=1.0):
-        """research/zeroshot_omtm/learner.py:164-223: the history window, with the observation rows of the
-        WHOLE window taken from the buffer (future rows are way-points), shortened near the 1000-step end."""
-        dev, (horizon, return_to_go) = self._stage_copy(lambda flat: self._goal_window_host(sequence_history, rtg, percentage, flat))
-        states, actions, rewards = self._blocks(dev)
-        return states, actions, rewards, horizon, return_to_go
-
-    def _goal_window_host(self, sequence_history, rtg, percentage, flat):
-        """Host half of ``assemble_goal_window``: fills the flat window buffer and returns (horizon, rtg)."""
-        T = self.T
-        horizon = int(self.cfg.horizon)
-        end_idx = int(sequence_history["path_length"])
-        if end_idx + horizon < T:
-            horizon = T - end_idx
-        smart = T
-        if end_idx + horizon > 1000:
-            smart = smart - (end_idx + horizon - 1000)
-        hl = T - horizon + 1
-        flat[:] = 0.0
-        bs, ba, br = self._blocks(flat)
-        lo = end_idx - hl + 1
-        ba[:hl] = sequence_history["actions"][lo : end_idx + 1]
-        br[:hl] = np.asarray(sequence_history["rewards"][lo : end_idx + 1]).reshape(hl, 1)
-        bs[:hl] = sequence_history["observations"][lo : end_idx + 1]
-        bs[:smart] = sequence_history["observations"][lo : lo + T]
-        return horizon, self._rtg_value(rtg, percentage)
-
-    def _goal_tokens(self, states, actions, rewards, rtg):
-        T = self.T
-        ret = torch.full((1, T, 1), rtg, dtype=torch.float64, device=self.device)
-        return [self.handle.tokenize(capi.STATES, states[None]), actions[None].contiguous(),
-                self.handle.tokenize(capi.REWARDS, rewards[None]), self.handle.tokenize(capi.RETURNS, ret)]
-
-    def _policy_from(self, toks, masks, h, eval):
-        from .masks import mask_rows
-        mu, sd = self.handle.forward(toks, mask_rows(masks), want=("actions",))["actions"]
-        self._mark_main()
-        dist_ = SquashedNormal(mu.unsqueeze(2), sd.unsqueeze(2))
-        if eval:
-            return dist_.mean[0, self.T - h]
-        return dist_.sample(eps=self._eps(tuple(dist_.loc.shape)))[0, self.T - h]
-
-    @torch.no_grad()
-    def action_id_sample(self, sequence_history, percentage=1.0, horizon=4, plan=True, eval=False, rtg=None):
-        """zeroshot learner.py:60-149: one forward under the goal inverse-dynamics mask."""
-        if eval:
-            assert rtg is not None
-        from .masks import create_gid_mask
-        s, a, r, h, rtg_v = self.assemble_goal_window(sequence_history, rtg, percentage)
-        toks = self._goal_tokens(s, a, r, rtg_v)
-        return self._policy_from(toks, create_gid_mask(self.T, "cpu", self.T - h), h, eval)
-
-    @torch.no_grad()
-    def action_piid_sample(self, sequence_history, percentage=1.0, horizon=4, plan=True, eval=False, rtg=None):
-        """zeroshot learner.py:151-261: path inference (pi mask) -> write the inferred states into the
-        window -> inverse dynamics (fid mask) -> action at T-h."""
-        if eval:
-            assert rtg is not None
-        from .masks import create_fid_mask, create_pi_mask, mask_rows
-        T = self.T
-        s, a, r, h, rtg_v = self.assemble_goal_window(sequence_history, rtg, percentage)
-        idx = T - h
-        self._drain()  # (m3pc_goal_step runs in the policy workspace: no pipelined plan step may still be using it)
-        # both forwards and the hand-over between them in one library call on the raw window (m3pc_goal_step)
-        mu, sd, inferred, window = self.handle.goal_step(s[None], a[None], r[None], [rtg_v], mask_rows(create_pi_mask(T, "cpu", idx)),
-                                                         mask_rows(create_fid_mask(T, "cpu", idx)), idx)
-        self._mark_main()
-        self.last = dict(state_inference=inferred, window_states=window[0])
-        dist_ = SquashedNormal(mu.unsqueeze(2), sd.unsqueeze(2))
-        if eval:
-            return dist_.mean[0, idx]
-        return dist_.sample(eps=self._eps(tuple(dist_.loc.shape)))[0, idx]
-
-    @torch.no_grad()
-    def action_piid_list_sample(self, sequence_history, percentage=1.0, horizon=4, plan=True, eval=False, rtg=None):
-        """zeroshot learner.py:263-370 (goal_mask "piid_allout", unseen.py:146-148): the piid arithmetic, but the result --
-        always the MEAN of the action distribution at T-h, eval or not -- is left in ``self.action_list`` (one entry: the
-        reference's further entries are commented out at 366-370) for the rollout loop to pop (learner.py:559-568).
-        Returns None, as the reference does."""
-        if eval:
-            assert rtg is not None
-        self.action_list = [self.action_piid_sample(sequence_history, percentage, horizon, plan, eval=True,
-                                                    rtg=self._rtg_value(rtg, percentage))]
-        return None
-
-    @torch.no_grad()
-    def goal_actions(self, states, actions, horizon: int, eval: bool = True, goal_mask: str = "piid", precision: Optional[str] = None,
-                     want_window: bool = False):
-        """The zero-shot action of E windows that are on the device already: states (E,T,S), actions (E,T,A) raw, one effective
-        horizon for all of them (BASELINE config 5: thousands of goal-reaching windows per GPU).  Exactly pruned many-window path
-        (m3pc_goal_step_batch): path inference reads the states head at the rows the overlay uses only, inverse dynamics reads
-        ONE action token (zeroshot learner.py:240-256).  goal_mask "piid" (action_piid_sample) or "id" (action_id_sample).
-        precision: "bf16" / "fp32"; default the planner's.  Returns (E, A): tanh(loc) when eval, a sample else."""
-        prec = self.precision if precision is None else {"fp32": capi.PREC_FP32, "bf16": capi.PREC_BF16}[precision]
-        idx = self.T - int(horizon)
-        self._drain()  # (m3pc_goal_step_batch runs in the candidate workspace)
-        res = self.handle.goal_step_batch(states, actions, idx, capi.GOAL_PIID if goal_mask == "piid" else capi.GOAL_ID, prec,
-                                          want_window=want_window)
-        mu, sd = res[0], res[1]
-        if want_window:
-            self.last = dict(window_states=res[2], loc=mu, std=sd)
-        if eval:
-            return torch.tanh(mu)
-        # SquashedNormal.sample (mtm_model.py:263-269): the variates of the whole (E,T,1,A) distribution are drawn, as the
-        # reference draws them, and the token's are used
-        eps = self._eps((mu.shape[0], self.T, 1, self.A))[:, idx, 0]
-        return torch.tanh(eps * sd + mu)
-
-    @torch.no_grad()
-    def action_piid_sample_batch(self, sequence_histories, percentage=1.0, eval=True, rtg=None, pruned: Optional[bool] = None):
-        """E independent goal-reaching windows per launch (BASELINE config 5 / SURVEY §8 f1): the reference plans one
-        env per call (zeroshot learner.py:151-261, unseen.py rollout loop); here the windows that share a horizon go
-        through the pi and fid forwards as ONE batch of the same kernels.  Per window the arithmetic is that of
-        ``action_piid_sample``.  Returns (E, A).
-        pruned=False (default up to 64 windows): the fp32 few-row kernels of ``action_piid_sample`` on the whole batch
-        (``max_batch >= E``; ``last["state_inference"]`` holds every window's full states head).
-        pruned=True (default beyond, needs ``goal_batch >= E``): the exactly pruned many-window path in the planner's
-        precision (``goal_actions``)."""
-        if eval:
-            assert rtg is not None
-        from .masks import create_fid_mask, create_pi_mask, mask_rows
-        T, E = self.T, len(sequence_histories)
-        S, A = self.S, self.A
-        if pruned is None:
-            pruned = E > 64 or E > self._max_batch
-        if pruned and E > self._goal_batch:
-            raise ValueError(f"{E} windows through the pruned path need HipPlanner(..., goal_batch >= {E})")
-        host = np.empty((E, T * (S + A + 1)), dtype=np.float32)
-        meta = [self._goal_window_host(hst, rtg, percentage, host[i]) for i, hst in enumerate(sequence_histories)]
-        dev = torch.from_numpy(host).to(self.device)  # one packed H2D copy for all windows
-        out = torch.empty((E, self.A), dtype=torch.float32, device=self.device)
-        infer = [None] * E
-        self._drain()
-        for h in sorted({m[0] for m in meta}):
-            ids = [i for i, m in enumerate(meta) if m[0] == h]
-            idx = T - h
-            sel = dev if len(ids) == E else dev[torch.tensor(ids, device=self.device)]
-            s = sel[:, : T * S].reshape(-1, T, S).contiguous()
-            a = sel[:, T * S : T * (S + A)].reshape(-1, T, A).contiguous()
-            if pruned:
-                act = self.goal_actions(s, a, h, eval=eval)
-                if len(ids) == E:
-                    out = act
-                else:
-                    out[torch.tensor(ids, device=self.device)] = act
-                continue
-            r = sel[:, T * (S + A) :].reshape(-1, T, 1).contiguous()
-            mu, sd, inferred, _ = self.handle.goal_step(s, a, r, [meta[i][1] for i in ids], mask_rows(create_pi_mask(T, "cpu", idx)),
-                                                        mask_rows(create_fid_mask(T, "cpu", idx)), idx)
-            dist_ = SquashedNormal(mu.unsqueeze(2), sd.unsqueeze(2))
-            act = dist_.mean if eval else dist_.sample(eps=self._eps(tuple(dist_.loc.shape)))
-            out[torch.tensor(ids, device=self.device)] = act[:, idx, 0]
-            for j, i in enumerate(ids):
-                infer[i] = inferred[j]
-        self._mark_main()
-        self.last = dict(state_inference=infer)
-        return out
-
     # ---------------------------------------------------------------------------------------- batched planning
     @torch.no_grad()
     def plan_async(self, sequence_history, percentage=1.0, eval=False, rtg=None) -> "PlanTicket":
@@ -958,175 +801,6 @@ class HipPlanner:
             resolve()
         self.last = dict(windows=info, delta=self._delta)
         return out
-
-    def _action_sample_lockstep(self, sequence_histories, percentage=1.0, eval=False, rtg=None, onepass: bool = False):
-        self._drain()
-        cfg = self.cfg
-        guidance = cfg.plan_guidance
-        assert guidance in _MODES, guidance
-        mode = _MODES[guidance]
-        lmbda = 0.6 if guidance == "rtg_guiding" else float(cfg.lmbda)  # learner.py:405-407
-        E, T, S, A, N = len(sequence_histories), self.T, self.S, self.A, int(cfg.action_samples)
-        rtgs = [rtg] * E if (rtg is None or np.isscalar(rtg)) else list(rtg)
-        if eval:
-            assert all(r is not None for r in rtgs)
-        host = np.empty((E, T * (S + A + 1)), dtype=np.float32)
-        meta = []
-        for i, hst in enumerate(sequence_histories):
-            meta.append(self._window_host(hst, rtgs[i], percentage, host[i]))
-        dev = torch.from_numpy(host).to(self.device)  # one packed H2D copy for all windows
-        out = torch.empty((E, A), dtype=torch.float32, device=self.device)
-        info = [None] * E
-        groups = []
-        for h in sorted({m[0] for m in meta}):  # windows of one effective horizon, at most max_batch of them per group
-            same = [i for i, m in enumerate(meta) if m[0] == h]
-            groups += [(h, same[c0 : c0 + self._max_batch]) for c0 in range(0, len(same), self._max_batch)]
-        for h, ids in groups:
-            sel = dev if len(ids) == E else dev[torch.tensor(ids, device=self.device)]
-            s = sel[:, : T * S].reshape(-1, T, S).contiguous()
-            a = sel[:, T * S : T * (S + A)].reshape(-1, T, A).contiguous()
-            r = sel[:, T * (S + A) :].reshape(-1, T, 1).contiguous()
-            Eg = len(ids)
-            eps = self._eps((Eg, N, h, A)) if mode == capi.MODE_NOISE else self._eps((Eg, N, T, A))
-            if onepass:
-                res = self.handle.plan_step_batch(mode, s, a, r, [meta[i][1] for i in ids], eps, h, lmbda, float(cfg.discount), N,
-                                                  precision=self.precision)
-            else:
-                # ONE policy pass at batch Eg, then every window's own candidate pass (first-layer history sharing and the two
-                # candidate halves as in the single-window step), back to back: the caller's stream joins the halves once, at the end
-                f32 = dict(dtype=torch.float32, device=self.device)
-                res = dict(expect_return=torch.empty((Eg, N), **f32), sample_actions=torch.empty((Eg, N, h, A), **f32),
-                           loc=torch.empty((Eg, T, A), **f32), std=torch.empty((Eg, T, A), **f32))
-                self.handle.policy_pass_batch(mode, s, a, r, h, [meta[i][1] for i in ids], slot=0)
-                for w in range(Eg):
-                    self.handle.candidate_pass(mode, s[w], a[w], r[w], eps[w], h, lmbda, float(cfg.discount), N, precision=self.precision,
-                                               slot=0, window=w, defer_join=True,
-                                               out={k: v[w] for k, v in res.items()})
-                self.handle.candidate_join(0)
-            er, acts = res["expect_return"], res["sample_actions"]
-            stats_h = None
-            merged = [er[w] for w in range(Eg)]
-            # the multinomial's exponentials of every window (the same order of draws as before the race lists needed them early)
-            expos = [torch.empty((N,), dtype=torch.float32, device=self.device).exponential_(1, generator=self.generator)
-                     for _ in range(Eg)]
-            temp = float(cfg.temperature)
-            bound = self.rescore == "bound"
-            if self.rescore != "none":
-                smode = capi.MODE_RTG if mode == capi.MODE_RTG else capi.MODE_CRITIC
-                R = self._R if bound else 0
-                if bound:
-                    if self._delta is None:  # calibrate on window 0 of the group: all of its candidates in fp32
-                        f32 = self.handle.score_actions(smode, s[0], a[0], r[0], acts[0], None, h, lmbda, float(cfg.discount))
-                        d = er[0] - f32
-                        self._delta = max(self.calibration_factor * float((d - d.median()).abs().max()), 1e-6 * float(f32.abs().max()),
-                                          1e-30)
-                    # The certified re-score of certificate.py, for all windows of the group at once: the kmin best candidates
-                    # by score and the rfirst best by race key of every window in ONE fp32 pass, merge + select enqueued for
-                    # every window, THEN one host read of the certificates; windows that ask for more get passes of their own.
-                    kmax = max(min(self.rescore_max, N - 1 if N > 1 else 1), 1)
-                    rfirst = max(min(self.race_min, R), 1) if R > 0 else 0
-                    kmin = max(min(self.rescore_min - rfirst, N, kmax), 1)  # (the race entries share the floor of the first pass)
-                    lsts, blst = [], []
-                    for w in range(Eg):
-                        bt = torch.empty((R + kmax + 1,), dtype=torch.float32, device=self.device)
-                        if R > 0:
-                            lsts.append(self.handle.topk_race_window(er[w], expos[w], temp, kmax, kmin, R, list_scores=bt)[0])
-                        else:
-                            lsts.append(self.handle.topk_window(er[w], kmax, kmin, 0.0, top_scores=bt)[0])
-                        blst.append(bt)
-                else:
-                    kmax = kmin = min(self.rescore_topk, N)
-                    rfirst = 0
-                    lsts = [torch.topk(er[w], kmin).indices.to(torch.int32) for w in range(Eg)]
-                    blst = [er[w][lsts[w].long()].contiguous() for w in range(Eg)]
-                delta = float(self._delta) if bound else 0.0
-                m0 = rfirst + kmin
-                pick = torch.cat([lsts[w][R - rfirst : R + kmin].long() for w in range(Eg)])
-                wsel = torch.arange(Eg, dtype=torch.int32, device=self.device).repeat_interleave(m0)
-                f32 = self.handle.score_actions(smode, s, a, r, acts[wsel.long(), pick], wsel, h, lmbda, float(cfg.discount))
-                flst, mstats = [], []
-                for w in range(Eg):  # fp32 scores for the sets, shift-corrected bf16 scores for the rest (m3pc_rescore_merge[_race])
-                    fl = torch.empty_like(blst[w])
-                    fl[R - rfirst : R + kmin] = f32[w * m0 : (w + 1) * m0]
-                    flst.append(fl)
-                    o = R - rfirst
-                    if bound and R > 0:
-                        merged[w], st_w = self.handle.rescore_merge_race(er[w], expos[w], temp, lsts[w][o:], rfirst, kmin, blst[w][o:],
-                                                                        fl[o:], delta=delta)
-                    else:
-                        merged[w], st_w = self.handle.rescore_merge(er[w], lsts[w], kmin, blst[w], fl, delta=delta)
-                    mstats.append(st_w)
-            sels = [self.handle.select(merged[j], acts[j, :, 0], temp, expos[j]) for j in range(Eg)]
-            certs = [None] * Eg
-            counts = [kmin if self.rescore != "none" else 0] * Eg
-            if bound:
-                stats_h = torch.stack(mstats).cpu()  # the one host read of the group: the certificates' statistics per window
-                ctx = types.SimpleNamespace(hdl=self.handle, cap=max(self.handle.max_rescore, 1), disc=float(cfg.discount),
-                                            temp=temp, stats_h=stats_h, smode=smode, s=s, a=a, r=r, acts=acts, h=h,
-                                            lmbda=lmbda, N=N, er=er, lsts=lsts, blst=blst, flst=flst, merged=merged, sels=sels,
-                                            expos=expos, R=R, wset=[None] * Eg, nd=[kmin] * Eg, rd=[rfirst] * Eg)
-                delta_first = delta
-                for w in range(Eg):
-                    ops_w = _WindowOps(ctx, w)
-                    if delta > delta_first:  # an earlier window of the group raised the bound: this window's certificate again, under it
-                        ops_w.merge_select(ctx.nd[w], ctx.rd[w], delta)
-                    certs[w] = _resolve_certificate(self, N, kmax, R, ctx.nd[w], ctx.rd[w], delta, ops_w)
-                    if certs[w]["delta"] > delta:  # this window saw a larger deviation than the bound: raised for everybody from here on
-                        delta = self._delta = certs[w]["delta"]
-                    counts[w] = certs[w]["n_rescored"]
-            for j, i in enumerate(ids):
-                p, ev, am, si, sa = sels[j]
-                out[i] = ev if eval else sa[0]
-                info[i] = dict(expect_return=merged[j], argmax=am, sample_idx=si, eval_action=ev, sample_action=sa, horizon=h,
-                               n_rescored=None if certs[j] is None else counts[j],
-                               n_race=None if certs[j] is None else certs[j]["n_race"],
-                               min_margin_outside=None if certs[j] is None else certs[j]["min_margin_outside"],
-                               saturated=None if certs[j] is None else certs[j]["saturated"],
-                               delta=self._delta)
-        self._mark_main()
-        self.last = dict(windows=info, delta=self._delta)
-        return out
-
-    # ---------------------------------------------------------------------------------------- CEM refinement
-    @torch.no_grad()
-    def cem_guiding(self, trajectory: Dict[str, torch.Tensor], h: int, iterations: int = 2, top_k: int = 128, init_std: float = 0.1,
-                    noise=None):
-        """Cross-entropy refinement of the plan (the legacy ``sample_action_cem`` of
-        research/omtm/datasets/sequence_dataset.py:919-1000 -- N=1024, top_k=128, 2 iterations -- restated on this model's
-        plan step: that function predates the four-key omtm model and cannot run on it, so parity is pinned on the oracle's
-        restatement of the same algorithm (tests/test_batch_gpu.py), not on the reference).
-          candidates_0 = clamp(tanh(policy loc) + init_std * noise_0, -1, 1) over the last h steps
-          repeat: score (TD(lambda) as rtg_guiding / critic_lambda_guiding) -> top_k -> mean / std per (t, a)
-                  candidates = clamp(mean + std * noise_i, -1, 1)
-        Returns (sample_action (1,A): first action of candidate 0 after the last refit, as the legacy code returns;
-                 eval_action (A,): first action of the final mean).  ``noise``: optional (iterations+1, N, h, A) normals."""
-        self._drain()
-        s, a, r, rtg, ret = self._split(trajectory)
-        cfg = self.cfg
-        N, T, A = int(cfg.action_samples), self.T, self.A
-        mode = capi.MODE_CRITIC if cfg.plan_guidance == "critic_lambda_guiding" else capi.MODE_RTG
-        lmbda = 0.6 if mode == capi.MODE_RTG else float(cfg.lmbda)
-        toks = [self.handle.tokenize(capi.STATES, s[None]), a[None], None, self._returns_tokens(rtg, ret)]
-        from .masks import create_rcbc_mask, mask_rows
-        mu, _ = self.handle.forward(toks, mask_rows(create_rcbc_mask(T, "cpu", T - h)), want=("actions",))["actions"]
-        mean = torch.tanh(mu[0, T - h :])  # (h, A)
-        std = torch.full_like(mean, float(init_std))
-        if noise is None:
-            noise = self._eps((iterations + 1, N, h, A))
-        k = min(int(top_k), N)
-        cand = torch.clamp(mean[None] + std[None] * noise[0], -1.0, 1.0)
-        trace = []
-        for it in range(iterations):
-            er = self.handle.score_actions(mode, s, a, r, cand, None, h, lmbda, float(cfg.discount), precision=self.precision)
-            top = torch.topk(er, k).indices
-            elite = cand[top]
-            mean = elite.mean(dim=0)
-            std = elite.std(dim=0) if k > 1 else torch.zeros_like(mean)
-            trace.append(dict(expect_return=er, top=top, mean=mean, std=std))
-            cand = torch.clamp(mean[None] + std[None] * noise[it + 1], -1.0, 1.0)
-        self._mark_main()
-        self.last = dict(cem=trace, candidates=cand)
-        return cand[0, 0][None], mean[0]
 
     @torch.no_grad()
     def action_sample(self, sequence_history, percentage=1.0, horizon=4, plan=True, eval=False, rtg=None):
