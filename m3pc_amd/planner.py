@@ -131,24 +131,25 @@ class HipPlanner(GoalMixin, LockstepMixin):
                  group=None, generator: Optional[torch.Generator] = None, max_batch: int = 1,
                  rescore: str = "bound", rescore_min: int = 8, rescore_max: int = 128, rescore_delta: Optional[float] = None,
                  max_windows: int = 1, pipeline_depth: int = 3, chain_priority: int = -1, tail_stream: bool = True,
-                 defer_join: bool = True, goal_batch: int = 0, race_min: int = 2, calibration_windows: int = 3, certify_sample: bool = True,
+                 defer_join: bool = True, goal_batch: int = 0, race_min: int = 2, calibration_windows: Optional[int] = None, certify_sample: bool = True,
                  chain_mode: str = "alternate"):
         """cfg: any object with traj_length, action_samples, horizon, discount, temperature, lmbda,
         plan_guidance (finetune.py RunConfig fields read at learner.py:276,319,342).
         tokenizer_manager: a TokenizerManager (this package's) or {key: {"mean","std","min","max"}}.
         precision: "fp32" (reference-accurate) or "bf16" (bf16 MFMA candidate pass followed by an fp32 re-score of the
         candidates that can still be the arg-max, so that the arg-max does not depend on bf16 rounding):
-          rescore="bound" (default): a CERTIFIED re-score.  Model: bf16 score b_j = f_j + c + e_j with a common shift c and a
-            deviation |e_j| <= delta.  The ``rescore_min`` best candidates by bf16 score are re-scored in fp32; from them the
-            library takes c = median(b - f) and f* = the best fp32 score, and counts need = #{j : b_j > f* + c - delta} -- the
-            only candidates that can still beat f* (m3pc_rescore_merge).  need <= what was re-scored certifies the arg-max; else
-            the candidates up to ``need`` are re-scored too (a second pass, at most ``rescore_max`` through the list; beyond
-            that the whole set goes through a chunked slow path with a warning, ``last["saturated"]``).  delta is calibrated
-            per weight load on 256 candidates scored in both arithmetics (1.5 x the largest deviation from the median), checked
-            on every step's re-scored set and raised when 1.5 x what that step saw is more (``delta_grown``), or fixed by
-            ``rescore_delta``.  ``planner.last`` reports n_rescored, n_in_window (the first certificate's count),
-            min_margin_outside (the threshold's margin over the best bf16 score NOT re-scored, >= 0 when certified), shift,
-            deviation and delta.  One 16-byte device-to-host read per step, after the select has been enqueued.
+          rescore="bound" (default): a CERTIFIED re-score (m3pc_amd/certificate.py).  Model: bf16 score b_j = f_j + c + e_j with
+            a common shift c and a deviation |e_j| <= delta.  Two lists are re-scored in fp32 -- the best candidates by bf16
+            score (the arg-max / eval action) and the best by race key tau b_j - log q_j (the multinomial draw / sampled action,
+            ``certify_sample``) -- and the library counts who can still beat the best re-scored fp32 score (``need``) or win the
+            draw (``need_race``); a certificate that asks for more gets a second pass (at most ``rescore_max`` / 32 through the
+            lists; beyond that the whole set goes through a slow path with a warning, ``last["saturated"]``).  delta is
+            calibrated per weight load on FULL fp32 candidate passes over the first few steps (``calibration_windows``, default:
+            enough for ~4096 candidates; 1.6 x the largest deviation from the median over all of them), checked on every step's
+            re-scored set and raised when 1.5 x what that step saw is more (``delta_grown``), or fixed by ``rescore_delta``.
+            ``planner.last`` reports n_rescored / n_race (score / race entries re-scored), n_in_window / need_race (what the
+            first certificates asked for), min_margin_outside, shift, deviation and delta.  One 32-byte device-to-host read per
+            step, after the select has been enqueued.
           rescore="topk": the fixed ``rescore_topk`` best candidates (round-1 behaviour, no certificate, no host read).
           Either way the select runs on the MERGED vector: fp32 scores for the re-scored candidates, bf16 scores minus the
           estimated shift for the rest, so an un-re-scored candidate cannot win the arg-max through a constant bf16 offset.
@@ -192,9 +193,12 @@ class HipPlanner(GoalMixin, LockstepMixin):
         # exactly the steps that are certain to be resolved when step t is issued (its slot's previous owner is step
         # t - SLOTS) -- whatever has been resolved since.  _delta0: the calibrated bound; _hist[t] = (deviation, need) of step t.
         self._delta0: Optional[float] = self._delta_fixed
-        self._cal_windows = max(1, int(calibration_windows))
+        # full-pass calibrations behind a weight load: enough windows for ~4096 candidates in all (r5 long sweep, 3 windows x 1.5:
+        # the largest deviation of any candidate of 1200 later steps reached 0.98 of the bound at N = 1024 and 1.03 at N = 625),
+        # at least 3, at most 16
+        self._cal_windows = max(1, int(calibration_windows)) if calibration_windows is not None else max(3, min(16, -(-4096 // max(N, 1))))
         self._cal_left = self._cal_windows  # full-pass calibrations still to run behind the last weight load
-        self.calibration_factor = 1.5
+        self.calibration_factor = 1.6
         self._hist: Dict[int, tuple] = {}
         self._step_index = 0
         self.generator = generator
@@ -651,7 +655,7 @@ class HipPlanner(GoalMixin, LockstepMixin):
 
     def _calibrate(self, tk) -> float:
         """delta of the certified re-score from ONE FULL fp32 candidate pass over this step's candidates (the same on every
-        rank): 1.5 x the largest deviation of (bf16 - fp32) from its median over all N.  Run on each of the first
+        rank): calibration_factor (1.6) x the largest deviation of (bf16 - fp32) from its median over all N.  Run on each of the first
         ``calibration_windows`` steps behind a weight load (the bound is their maximum) -- per-weight-load setup like the
         weight re-pack, ~10 ms each at N = 1024: the device is synchronised around the pass, which runs in the candidate
         workspace.  (Round 4 calibrated on 256 candidates of one window: a sample maximum of 256 under-estimates the maximum

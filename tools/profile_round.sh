@@ -1,10 +1,10 @@
 #!/bin/bash
 # The rocprofv3 passes whose summaries are committed under profiles/ (run on the GPU box through gpurun):
 #   kernel trace + stats (as the timed region runs), FETCH_SIZE, WRITE_SIZE (separate passes: TCC slots), SQ counters,
-#   the serial-order kernel trace (every launch alone: the `alone` durations) and the config-5 leg.  usage: tools/profile_round.sh r04
+#   the serial-order kernel trace (every launch alone: the `alone` durations) and the config-5 leg.  usage: tools/profile_round.sh r05
 set -euo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}"
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 B="python3 bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline --no-alone-pass"
@@ -22,6 +22,10 @@ rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_trace_serial -o kt --outpu
 python3 tools/step_timeline.py gpurun_out/${TAG}_trace_serial gpurun_out/${TAG}_step_timeline.txt > /dev/null
 python3 tools/timeline_window.py gpurun_out/${TAG}_trace gpurun_out/${TAG}_pipeline_timeline.txt 2
 echo "serial done"
+# every launch ALONE on the chip: serial order AND the two candidate halves one after the other on one stream -- the arrangement of
+# bench.py's roofline.frac (6 x the fused tail's average here must fit inside ms_per_step)
+rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_trace_alone -o kt --output-format csv -- $B --depth 0 --serial-halves > gpurun_out/${TAG}_trace_alone.log 2>&1
+echo "alone done"
 # BASELINE config 5: 8192 zero-shot windows per call
 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_trace_c5 -o kt --output-format csv -- python3 bench.py --config c5 --steps 10 --warmup 2 --no-extras > gpurun_out/${TAG}_trace_c5.log 2>&1
 echo "c5 done"
