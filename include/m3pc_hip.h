@@ -122,6 +122,12 @@ typedef struct m3pc_plan_args {
  * parts that ran elsewhere are complete only behind m3pc_candidate_join(h, slot, stream), and the caller's stream is
  * free to start the next step's first part while the last part of this one still runs (no idle tail per step). */
 #define M3PC_PLAN_DEFER_JOIN 1
+/* M3PC_PLAN_PRUNED_POLICY (m3pc_policy_pass only, with loc == std == NULL): the policy head is computed at the h action tokens
+ * t >= T - h alone -- the rows a plan step samples its candidates from (learner.py:285-287 reads sample((N,))[:, 0, T-h:]) -- through
+ * the exactly pruned decoder (those tokens are masked under the rcbc mask: shared query rows and masked-token K|V from the plan
+ * tables, the kept tokens alone through decoder-embed / K|V, out-proj / FFN / actor head on h rows instead of 4T).  Rows t < T - h of
+ * the slot's loc / std (what m3pc_candidate_pass copies out) are zero.  Same arithmetic per computed row up to fp32 re-association. */
+#define M3PC_PLAN_PRUNED_POLICY 2
 
 const char* m3pc_last_error(void);
 int m3pc_abi_version(void);

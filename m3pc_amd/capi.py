@@ -55,6 +55,7 @@ class PlanArgs(C.Structure):
 
 
 PLAN_DEFER_JOIN = 1
+PLAN_PRUNED_POLICY = 2
 
 
 class M3pcError(RuntimeError):
@@ -341,10 +342,14 @@ class Handle:
         return a
 
     def policy_pass(self, mode: int, states, actions, rewards, horizon: int, rtg: float, slot: int = 0, returns=None,
-                    loc=None, std=None):
+                    loc=None, std=None, pruned: bool = False):
         """PASS 1 of a plan step on the current stream (chain workspace): leaves the policy head in ``slot``.
-        returns: optional (T,) device row of raw returns (float32 / float64) instead of the constant ``rtg``."""
+        returns: optional (T,) device row of raw returns (float32 / float64) instead of the constant ``rtg``.
+        pruned (with loc = std = None): the head at the h action tokens the candidates are sampled from only, through the
+        exactly pruned decoder (M3PC_PLAN_PRUNED_POLICY); rows t < T - h of the slot's loc / std are zero."""
         args = self._args(mode, PREC_FP32, horizon, 1, 0, 1, 0.0, 0.0, rtg, slot, returns)
+        if pruned and loc is None and std is None:
+            args.flags = PLAN_PRUNED_POLICY
         check(self.lib.m3pc_policy_pass(self._h, C.byref(args), _ptr(self._f32(states)), _ptr(self._f32(actions)),
                                         _ptr(self._f32(rewards)), _ptr(loc), _ptr(std), _stream(self.device)))
 

@@ -655,7 +655,7 @@ static int plan_check(m3pc_handle* h, const m3pc_plan_args* a, bool need_critic)
     if (a->mode < 0 || a->mode > 2) return fail(M3PC_EINVAL, "bad mode %d", a->mode);
     if (a->precision != M3PC_PREC_FP32 && a->precision != M3PC_PREC_BF16) return fail(M3PC_EINVAL, "bad precision");
     if (a->slot < 0 || a->slot >= M3PC_SLOTS) return fail(M3PC_EINVAL, "slot %d outside [0, %d)", a->slot, M3PC_SLOTS);
-    if (a->flags & ~M3PC_PLAN_DEFER_JOIN)  // (also what a caller built against the shorter ABI v2 structure would hand over)
+    if (a->flags & ~(M3PC_PLAN_DEFER_JOIN | M3PC_PLAN_PRUNED_POLICY))  // (also what a caller built against the shorter ABI v2 structure would hand over)
         return fail(M3PC_EINVAL, "unknown m3pc_plan_args::flags 0x%x (is the caller's structure the ABI v%d one?)", a->flags, M3PC_ABI_VERSION);
     if (need_critic && a->mode != M3PC_MODE_RTG && !h->critic_set) return fail(M3PC_ESTATE, "critic weights not set");
     HIPCHK(hipSetDevice(h->device));
@@ -696,7 +696,48 @@ int m3pc_policy_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* state
     in.ptr[M3PC_RETURNS] = h->rtok;
     h->allow_splitk = true;
     int rc;
-    {
+    if ((a->flags & M3PC_PLAN_PRUNED_POLICY) && !loc && !std_ && idx > 0) {
+        // the policy head at the action tokens idx .. T-1 only (masked under the rcbc mask for idx > 0): query set 4 of the plan
+        WsScope ws(h, true, true, a->slot);
+        std::vector<int> toks;
+        for (int t = idx; t < T; ++t) toks.push_back(M3PC_ACTIONS * T + t);
+        rc = build_query_list(h, pl, 4, hh, toks, 1, M3PC_ACTIONS, 0);
+        if (!rc) rc = build_tables(h, pl, 4, DT_F32, st);
+        if (!rc && !pl->query[4].all_masked) rc = fail(M3PC_EINVAL, "policy pass: an action token at t >= idx is not masked");
+        if (!rc) rc = run_encoder(h, pl, in, 1, DT_F32, st, false, 0);
+        float* xr = nullptr;
+        if (!rc) rc = pruned_decoder(h, pl, pl->query[4], pl->query[4].tab[DT_F32], 1, DT_F32, st, TAIL_X, &xr);
+        if (!rc) {  // decoder.norm of the h query rows, then the action head (mtm_model.py:705, 313-321)
+            const int d = h->d;
+            LnP ln;
+            memset(&ln, 0, sizeof(ln));
+            ln.X = xr;
+            ln.ldx = d;
+            ln.rows = hh;
+            ln.d = d;
+            ln.g1 = W(h, "decoder.norm.weight").f;
+            ln.b1 = W(h, "decoder.norm.bias").f;
+            ln.Yf = h->G;
+            launch_layernorm(ln, st);
+            ActorP ac;
+            memset(&ac, 0, sizeof(ac));
+            ac.X = h->G;
+            ac.ldx = d;
+            ac.rows = hh;
+            ac.d = d;
+            ac.A = h->A;
+            ac.Wmu = W(h, "output_head_dict.actions.mu.weight").f;
+            ac.bmu = W(h, "output_head_dict.actions.mu.bias").f;
+            ac.Wls = W(h, "output_head_dict.actions.log_std.weight").f;
+            ac.bls = W(h, "output_head_dict.actions.log_std.bias").f;
+            ac.mu = h->loc + (size_t)idx * h->A;
+            ac.sd = h->sd + (size_t)idx * h->A;
+            launch_actor_head(ac, st);
+            if (hipMemsetAsync(h->loc, 0, (size_t)idx * h->A * sizeof(float), st) != hipSuccess ||
+                hipMemsetAsync(h->sd, 0, (size_t)idx * h->A * sizeof(float), st) != hipSuccess)
+                rc = fail(M3PC_EHIP, "hipMemsetAsync failed in the pruned policy pass");
+        }
+    } else {
         WsScope ws(h, true, true, a->slot);
         rc = forward_impl(h, pl, in, 1, nullptr, nullptr, nullptr, h->loc, h->sd, DT_F32, st);
     }

@@ -59,7 +59,7 @@ struct SharedTables {  // candidate-independent decoder quantities of one plan, 
     float *pre_m = nullptr, *pre_l = nullptr, *pre_O = nullptr;
 };
 
-constexpr int N_QUERY = 4;
+constexpr int N_QUERY = 5;
 struct Plan {
     std::string key;
     int T = 0, Le = 0, Lm = 0;
@@ -91,7 +91,7 @@ struct Plan {
         int* d_q_rowsrc_mix = nullptr;  // (nq): enc row or -(i)-1 rows of Yall
         SharedTables tab[2];
     } query[N_QUERY];  // index: 0 rtg (rewards, returns), 1 critic (states, rewards), 2 goal path inference (the state rows the
-                       // overlay reads), 3 goal inverse dynamics (the action token at idx)
+                       // overlay reads), 3 goal inverse dynamics (the action token at idx), 4 policy pass (the action tokens idx .. T-1)
 };
 
 struct EventPair {

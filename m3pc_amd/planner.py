@@ -132,7 +132,7 @@ class HipPlanner(GoalMixin, LockstepMixin):
                  rescore: str = "bound", rescore_min: int = 8, rescore_max: int = 128, rescore_delta: Optional[float] = None,
                  max_windows: int = 1, pipeline_depth: int = 3, chain_priority: int = -1, tail_stream: bool = True,
                  defer_join: bool = True, goal_batch: int = 0, race_min: int = 2, calibration_windows: Optional[int] = None, certify_sample: bool = True,
-                 chain_mode: str = "alternate"):
+                 chain_mode: str = "alternate", policy_head: str = "full"):
         """cfg: any object with traj_length, action_samples, horizon, discount, temperature, lmbda,
         plan_guidance (finetune.py RunConfig fields read at learner.py:276,319,342).
         tokenizer_manager: a TokenizerManager (this package's) or {key: {"mean","std","min","max"}}.
@@ -234,6 +234,14 @@ class HipPlanner(GoalMixin, LockstepMixin):
         #     stream back to back, and that stream -- not the candidate passes (1.04 ms + gaps) -- set the step rate.
         assert chain_mode in ("alternate", "split")
         self._alternate = chain_mode == "alternate"
+        # "full" (default): the policy pass returns every row of the policy head, as omtm.forward does.  "pruned": it computes the head
+        # at the h action tokens the candidates are sampled from only (learner.py:285-287 reads [T-h:] of the distribution) through
+        # the exactly pruned decoder -- out-proj / FFN / actor head on h rows instead of 4T; last["loc"] / ["std"] are zero below
+        # T - h.  Measured (r5, same box, three runs each): one step alone 1.715-1.723 ms pruned against 1.702-1.709 full, pipelined
+        # 844-852 against 848-856 plan-steps/s -- the batch-1 chain is bound by its ~30 dependent launches, not by its rows, and the
+        # pruned decoder has as many; kept as an option (tests/test_policy_pruned_gpu.py), not the default.
+        assert policy_head in ("pruned", "full")
+        self._policy_pruned = policy_head == "pruned"
         self._warned_saturated = False
         self.delta_grown = 0        # how often the per-step deviation check raised delta since the last weight load
         self.action_list = []       # zero-shot "piid_allout" (action_piid_list_sample)
@@ -447,7 +455,7 @@ class HipPlanner(GoalMixin, LockstepMixin):
                 if self._ev_main is not None:
                     chain.wait_event(self._ev_main)  # (_mark_main: the caller's stream was in the policy workspace)
             # the policy pass consumes no variate: its ~30 launches go out first, the draws are enqueued while the device runs them
-            hd.policy_pass(mode, states, actions, rewards, h, tk.rtg, slot=sl.i, returns=returns)
+            hd.policy_pass(mode, states, actions, rewards, h, tk.rtg, slot=sl.i, returns=returns, pruned=self._policy_pruned)
             if eps is None:
                 eps = self._draw_eps(mode, h, sl.eps_buf if chain is not None else None)
             tk.eps = eps = eps.reshape(N, -1, A)
