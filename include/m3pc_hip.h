@@ -346,7 +346,8 @@ int m3pc_rescore_merge(m3pc_handle* h, const float* scores, int n_total, const i
  * so "the r best racers and the n best scorers" is list[rmax - r .. rmax + n): one m3pc_rescore call, one merge.
  *   expo         device (n_total,) the Exp(1) variates m3pc_select will draw with
  *   list_scores  device out (rmax + kmax + 1,), optional: expect_return[list[i]]
- *   stats / host_stats / seq as m3pc_topk_window (of the score part).  rmax <= min(64, n_total). */
+ *   stats / host_stats / seq as m3pc_topk_window (of the score part); stats may be NULL (one launch fewer up to 2048 candidates:
+ *   the ranking kernel writes list_scores itself).  rmax <= min(64, n_total). */
 int m3pc_topk_race_window(m3pc_handle* h, const float* expect_return, const float* expo, float temperature, int n_total, int kmax,
                           int kmin, int rmax, int* list, float* stats, float* list_scores, float* host_stats, float seq, void* stream);
 /* m3pc_rescore_merge over such a list: `list` = r race entries followed by n score entries (a slice of the list above),
@@ -360,6 +361,13 @@ int m3pc_topk_race_window(m3pc_handle* h, const float* expect_return, const floa
 int m3pc_rescore_merge_race(m3pc_handle* h, const float* scores, const float* expo, float temperature, int n_total, const int* list,
                             int r, int n, const float* list_scores, const float* list_rescored, float delta, float* merged,
                             float* stats, float* host_stats, float seq, void* stream);
+/* m3pc_rescore_merge_race followed by m3pc_select on the merged vector (with the same expo / temperature), in ONE launch: both are
+ * one workgroup over the whole vector, and the re-score's tail is a chain of dependent launches.  The certificate's statistics
+ * reach host_stats before the select part runs.  Arguments as the two calls. */
+int m3pc_merge_race_select(m3pc_handle* h, const float* scores, const float* expo, float temperature, int n_total, const int* list,
+                           int r, int n, const float* list_scores, const float* list_rescored, float delta, float* merged,
+                           float* stats, float* host_stats, float seq, const float* a0, long long a0_stride, float* p,
+                           float* eval_action, int* argmax, int* sample_idx, float* sample_action, void* stream);
 /* m3pc_rescore of the n listed candidates (device int32 ids), written back into the full score vector in place. */
 int m3pc_rescore_listed(m3pc_handle* h, const m3pc_plan_args* args, const float* states, const float* actions,
                         const float* rewards, const float* eps, const int* index, int n, float* expect_return,

@@ -31,7 +31,7 @@ EXPORTS = (
     "m3pc_goal_step_batch",
     "m3pc_policy_pass", "m3pc_candidate_pass", "m3pc_candidate_join", "m3pc_policy_pass_batch",
     "m3pc_plan_step", "m3pc_plan_step_batch", "m3pc_score_actions", "m3pc_rescore", "m3pc_rescore_topk", "m3pc_topk_window",
-    "m3pc_rescore_listed", "m3pc_rescore_merge", "m3pc_topk_race_window", "m3pc_rescore_merge_race", "m3pc_select",
+    "m3pc_rescore_listed", "m3pc_rescore_merge", "m3pc_topk_race_window", "m3pc_rescore_merge_race", "m3pc_merge_race_select", "m3pc_select",
     "m3pc_profile_enable",
     "m3pc_profile_read",
 )
@@ -104,6 +104,7 @@ def load_library(path: Optional[str] = None):
         "m3pc_rescore_merge": [vp, vp, i, vp, i, vp, vp, f, vp, vp, vp, f, vp],
         "m3pc_topk_race_window": [vp, vp, vp, f, i, i, i, i, vp, vp, vp, vp, f, vp],
         "m3pc_rescore_merge_race": [vp, vp, vp, f, i, vp, i, i, vp, vp, f, vp, vp, vp, f, vp],
+        "m3pc_merge_race_select": [vp, vp, vp, f, i, vp, i, i, vp, vp, f, vp, vp, vp, f, vp, ll, vp, vp, vp, vp, vp, vp],
         "m3pc_rescore_listed": [vp, C.POINTER(PlanArgs), vp, vp, vp, vp, vp, i, vp, vp],
         "m3pc_select": [vp, vp, vp, ll, i, f, vp, vp, vp, vp, vp, vp, vp],
         "m3pc_profile_enable": [vp, i],
@@ -553,7 +554,7 @@ class Handle:
 
     def topk_race_window(self, expect_return: torch.Tensor, expo: torch.Tensor, temperature: float, kmax: int, kmin: int, rmax: int,
                          lst: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None,
-                         list_scores: Optional[torch.Tensor] = None):
+                         list_scores: Optional[torch.Tensor] = None, want_stats: bool = True):
         """``topk_window`` plus the rmax best candidates by race key temperature * E - log expo (the multinomial draw's race),
         in one list: lst[rmax + i] = i-th best by score (i <= kmax), lst[rmax - 1 - i] = i-th best racer.  Returns (lst, stats)."""
         n = expect_return.numel()
@@ -561,7 +562,7 @@ class Handle:
         assert expo.is_contiguous() and expo.dtype == torch.float32 and expo.numel() == n
         if lst is None:
             lst = torch.empty((rmax + kmax + 1,), dtype=torch.int32, device=self.device)
-        if stats is None:
+        if stats is None and want_stats:
             stats = torch.empty((4,), dtype=torch.float32, device=self.device)
         assert lst.numel() >= rmax + min(kmax + 1, n)
         check(self.lib.m3pc_topk_race_window(self._h, _ptr(expect_return), _ptr(expo), float(temperature), n, int(kmax), int(kmin),
@@ -585,6 +586,28 @@ class Handle:
                                                None if host_stats is None else C.c_void_p(host_stats.data_ptr()), float(seq),
                                                _stream(self.device)))
         return merged, stats
+
+    def merge_race_select(self, scores: torch.Tensor, expo: torch.Tensor, temperature: float, lst: torch.Tensor, r: int, n: int,
+                          list_scores: torch.Tensor, list_rescored: torch.Tensor, a0: torch.Tensor, delta: float = 0.0,
+                          merged: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, host_stats=None, seq: float = 0.0,
+                          out=None):
+        """``rescore_merge_race`` + ``select`` on the merged vector in one launch.  Returns (merged, stats, (p, eval_action, argmax,
+        sample_idx, sample_action))."""
+        nt = scores.numel()
+        assert scores.is_contiguous() and scores.dtype == torch.float32 and lst.dtype == torch.int32
+        assert lst.numel() >= r + n and list_scores.numel() >= r + n and list_rescored.numel() >= r + n
+        assert a0.shape[0] == nt and a0.stride(-1) == 1 and expo.numel() == nt and expo.is_contiguous()
+        if merged is None:
+            merged = torch.empty_like(scores)
+        if stats is None:
+            stats = torch.empty((8,), dtype=torch.float32, device=self.device)
+        p, ev, am, si, sa = out if out is not None else self.select_buffers(nt)
+        check(self.lib.m3pc_merge_race_select(self._h, _ptr(scores), _ptr(expo), float(temperature), nt, _ptr(lst), int(r), int(n),
+                                              _ptr(list_scores), _ptr(list_rescored), float(delta), _ptr(merged), _ptr(stats),
+                                              None if host_stats is None else C.c_void_p(host_stats.data_ptr()), float(seq),
+                                              _ptr(a0), a0.stride(0), _ptr(p), _ptr(ev), _ptr(am), _ptr(si), _ptr(sa),
+                                              _stream(self.device)))
+        return merged, stats, (p, ev, am, si, sa)
 
     def select_buffers(self, n: int):
         """Output tensors of ``select`` (p, eval_action, argmax, sample_idx, sample_action), allocated on the current stream."""

@@ -72,8 +72,7 @@ class _TicketOps:
         pl, tk = self.planner, self.tk
         tk.delta = delta
         with pl._on(tk):
-            pl._merge(tk, n, r)
-            tk.sel = pl.handle.select(tk.er, tk.a0, float(pl.cfg.temperature), tk.expo, out=tk.outbuf)
+            pl._merge(tk, n, r, select=True)
             if tk.tchain is not None:
                 tk.slot.ev_done.record(tk.tchain)
 

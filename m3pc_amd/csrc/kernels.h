@@ -383,8 +383,10 @@ void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st);
 // max, raw count over all n_total entries}; top_scores (optional) = v[idx[i]] for i in [-rr, kk): rr race entries sit in front of idx
 void launch_window_stats(const float* v, int n_total, const int* idx, int kk, int kmin, int kmax, float window, float* stats,
                          float* host_stats, float seq, float* top_scores, hipStream_t st, int rr = 0);
-// list[rmax + i] = the i-th best entry of v (i < kk); list[rmax - 1 - i] = the i-th best by race key tau v - log expo (i < rr)
-void launch_topk_race(const float* v, const float* expo, float tau, int n, int kk, int rr, int rmax, int* list, hipStream_t st);
+// list[rmax + i] = the i-th best entry of v (i < kk); list[rmax - 1 - i] = the i-th best by race key tau v - log expo (i < rr);
+// list_scores (optional, same layout) = v[list[i]]: returns true when the launch wrote them itself (n <= 2048)
+bool launch_topk_race(const float* v, const float* expo, float tau, int n, int kk, int rr, int rmax, int* list, float* list_scores,
+                      hipStream_t st);
 // list = r race entries then n score entries (the n best of b, best first), list_scores = b[list[i]], f = their fp32 re-scores:
 // out = b - median(list_scores - f), listed entries replaced by f;  stats (8 floats) = {shift, max deviation,
 // need = #{b > best f + shift - delta}, margin of that threshold over the best un-listed b, -, need_race (expo given: the number
@@ -392,6 +394,10 @@ void launch_topk_race(const float* v, const float* expo, float tau, int n, int k
 void launch_rescore_merge(const float* b, int n_total, const int* list, int r, int n, const float* list_scores, const float* f,
                           float delta, const float* expo, float tau, float* out, float* stats, float* host_stats, float seq,
                           hipStream_t st);
+// launch_rescore_merge + launch_select in ONE launch (the select runs on `out`)
+void launch_merge_select(const float* b, int n_total, const int* list, int r, int n, const float* list_scores, const float* f,
+                         float delta, const float* expo, float tau, float* out, float* stats, float* host_stats, float seq,
+                         const SelectP& sp, hipStream_t st);
 // dst[index[i]] = src[i]
 void launch_scatter(const float* src, const int* index, int n, float* dst, int* index_copy, hipStream_t st);  // + index_copy[i] = index[i]
 

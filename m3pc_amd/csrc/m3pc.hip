@@ -1097,16 +1097,22 @@ int m3pc_topk_window(m3pc_handle* h, const float* expect_return, int n_total, in
 
 int m3pc_topk_race_window(m3pc_handle* h, const float* expect_return, const float* expo, float temperature, int n_total, int kmax,
                           int kmin, int rmax, int* list, float* stats, float* list_scores, float* host_stats, float seq, void* stream) {
-    if (!h || !expect_return || !expo || !list || !stats) return fail(M3PC_EINVAL, "null argument");
+    if (!h || !expect_return || !expo || !list) return fail(M3PC_EINVAL, "null argument");
     if (n_total < 1 || n_total > 16384) return fail(M3PC_EINVAL, "top-k supports n_total <= 16384");
     if (kmax < 1 || kmax > 1023 || kmin < 1 || kmin > kmax) return fail(M3PC_EINVAL, "bad kmin/kmax");
+    if (!stats && host_stats) return fail(M3PC_EINVAL, "host_stats needs stats");
     if (rmax < 1 || rmax > 64 || rmax > n_total) return fail(M3PC_EINVAL, "rmax %d outside [1, min(64, n_total)]", rmax);
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->device));
     const int kk = kmax + 1 < n_total ? kmax + 1 : n_total;
-    launch_topk_race(expect_return, expo, temperature, n_total, kk, rmax, rmax, list, st);
-    launch_window_stats(expect_return, n_total, list + rmax, kk, kmin, kmax, 0.f, stats, host_stats, seq,
-                        list_scores ? list_scores + rmax : nullptr, st, rmax);
+    const bool scored = launch_topk_race(expect_return, expo, temperature, n_total, kk, rmax, rmax, list, list_scores, st);
+    // the statistics of the score part (and, beyond 2048 candidates, the listed scores) are a launch of their own: skipped when the
+    // caller wants neither (the planner's certificate works on the merge's statistics)
+    if (stats || (list_scores && !scored)) {
+        if (!stats) stats = h->sel_scratch;
+        launch_window_stats(expect_return, n_total, list + rmax, kk, kmin, kmax, 0.f, stats, host_stats, seq,
+                            list_scores ? list_scores + rmax : nullptr, st, rmax);
+    }
     return check_launch("topk_race_window");
 }
 
@@ -1133,6 +1139,35 @@ int m3pc_rescore_merge_race(m3pc_handle* h, const float* scores, const float* ex
     launch_rescore_merge(scores, n_total, list, r, n, list_scores, list_rescored, delta, expo, temperature, merged, stats, host_stats,
                          seq, (hipStream_t)stream);
     return check_launch("rescore_merge_race");
+}
+
+int m3pc_merge_race_select(m3pc_handle* h, const float* scores, const float* expo, float temperature, int n_total, const int* list,
+                           int r, int n, const float* list_scores, const float* list_rescored, float delta, float* merged,
+                           float* stats, float* host_stats, float seq, const float* a0, long long a0_stride, float* p,
+                           float* eval_action, int* argmax, int* sample_idx, float* sample_action, void* stream) {
+    if (!h || !scores || !expo || !list || !list_scores || !list_rescored || !merged || !stats) return fail(M3PC_EINVAL, "null argument");
+    if (n_total < 1 || n < 1 || r < 0 || r + n > 1024 || n > n_total || r > n_total)
+        return fail(M3PC_EINVAL, "r %d + n %d outside [1, 1024] / n_total %d", r, n, n_total);
+    if (!(delta >= 0.f)) return fail(M3PC_EINVAL, "delta must be >= 0");
+    if ((eval_action || sample_action) && !a0) return fail(M3PC_EINVAL, "eval_action / sample_action need a0");
+    HIPCHK(hipSetDevice(h->device));
+    SelectP s;
+    memset(&s, 0, sizeof(s));
+    s.er = merged;
+    s.a0 = a0;
+    s.a0_stride = a0_stride;
+    s.n = n_total;
+    s.A = h->A;
+    s.temperature = temperature;
+    s.expo = expo;
+    s.p = p;
+    s.eval_action = eval_action;
+    s.argmax = argmax;
+    s.sample_idx = sample_idx;
+    s.sample_action = sample_action;
+    launch_merge_select(scores, n_total, list, r, n, list_scores, list_rescored, delta, expo, temperature, merged, stats, host_stats,
+                        seq, s, (hipStream_t)stream);
+    return check_launch("merge_race_select");
 }
 
 int m3pc_rescore_listed(m3pc_handle* h, const m3pc_plan_args* a, const float* states, const float* actions, const float* rewards,

@@ -586,7 +586,30 @@ int pruned_decoder(m3pc_handle* h, Plan* pl, Plan::Query& q, SharedTables& tb, i
         kv_done = launch_kv_fused(kp, st);
     }
     if (!kv_done) {
-    for (int k = 0; k < 4; ++k) {
+    bool grouped = false;
+    {   // few-row fp32 pass (re-score, pruned policy pass): the decoder-embedding GEMMs of the kept keys as ONE launch
+        static const bool no_group = M3PC_ENV("M3PC_NO_GEMM_GROUP") != nullptr || M3PC_ENV("M3PC_NO_F32_DIRECT") != nullptr ||
+                                     M3PC_ENV("M3PC_GEMM_VARIANT") != nullptr;  // A/B switches
+        int nk = 0;
+        GemmP ps[4];
+        for (int k = 0; k < 4; ++k) {
+            if (!pl->kept[k]) continue;
+            RowMap mm{pl->kept[k], Le, pl->enc_off[k]};
+            GemmP& g = ps[nk++];
+            g = gemm_basic(enc_op, d, Wop(h, std::string("decoder_embed_dict.") + KEYN[k] + ".weight", dt), d, n * pl->kept[k], d, d, nullptr);
+            g.amap = mm;
+            g.cmap = mm;
+            g.rowtab = pl->edec_kept[k] ? pl->edec_kept[k] : h->Edec[k];
+            g.rt_mod = pl->kept[k];
+            g.rt_ld = d;
+            gemm_out(g, DT_F32, h->Y, d);
+        }
+        if (dt == DT_F32 && !no_group && h->allow_splitk && nk >= 2) {
+            GemmTimer t(h, st, 2.0 * n * Le * (double)d * d, dt);
+            grouped = launch_gemm_f32_direct_group(ps, nk, st);
+        }
+    }
+    for (int k = 0; k < 4 && !grouped; ++k) {
         if (!pl->kept[k]) continue;
         RowMap mm{pl->kept[k], Le, pl->enc_off[k]};
         dec_embed(h, k, enc_op, mm, h->Y, mm, n * pl->kept[k], pl->kept[k], dt, st, pl->edec_kept[k]);

@@ -49,9 +49,7 @@ __device__ __forceinline__ float block_sum(float v, float* sv) {
 }
 
 // p = exp(T (E - max E)) / sum;  eval = sum p a0 / sum p;  argmax E;  sample = argmax p / expo
-__global__ __launch_bounds__(1024) void select_kernel(SelectP p) {
-    __shared__ float sv[16];
-    __shared__ int si[16];
+__device__ __forceinline__ void select_body(const SelectP& p, float* sv, int* si) {
     const int tid = threadIdx.x;
     ArgMax am{-INFINITY, 0x7fffffff};
     for (int i = tid; i < p.n; i += 1024) am = better(am, ArgMax{p.er[i], i});
@@ -87,6 +85,11 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectP p) {
         }
     }
 }
+__global__ __launch_bounds__(1024) void select_kernel(SelectP p) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    select_body(p, sv, si);
+}
 void launch_select(const SelectP& p, hipStream_t st) {
     if (p.n <= 0) return;
     hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, st, p);
@@ -113,6 +116,7 @@ struct TopSrc {
     int k;
     int* out;
     int out_stride;
+    float* scores_out;  // optional: v[winner] beside its index, same stride (rank-by-counting kernels only)
 };
 __device__ __forceinline__ float src_value(const TopSrc& s, int e) { return s.expo ? race_key(s.tau, s.v[e], s.expo[e]) : s.v[e]; }
 
@@ -247,7 +251,10 @@ __global__ __launch_bounds__(256) void topk_rank_blocks2_kernel(TopSrc s0, TopSr
     __syncthreads();
     if (q == 0 && e < n) {
         rank = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
-        if (rank < s.k) s.out[rank * s.out_stride] = e;
+        if (rank < s.k) {
+            s.out[rank * s.out_stride] = e;
+            if (s.scores_out) s.scores_out[rank * s.out_stride] = s.v[e];
+        }
     }
 }
 
@@ -292,7 +299,7 @@ void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st) {
         return;
     }
     if (k <= 64 && n <= 16384) {
-        hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(1024), 0, st, TopSrc{v, nullptr, 0.f, k, idx_out, 1}, n);
+        hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(1024), 0, st, TopSrc{v, nullptr, 0.f, k, idx_out, 1, nullptr}, n);
         return;
     }
     int np = 2;
@@ -310,16 +317,19 @@ void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st) {
 // The two candidate lists of the certified re-score in one buffer (m3pc_topk_race_window): list[rmax + i] = the i-th best
 // entry of v (i <= kk - 1), list[rmax - 1 - i] = the i-th best entry by race key (i < rr): the r best racers and the n best
 // scorers are the contiguous slice [rmax - r, rmax + n).
-void launch_topk_race(const float* v, const float* expo, float tau, int n, int kk, int rr, int rmax, int* list, hipStream_t st) {
-    if (n <= 0 || kk <= 0) return;
-    const TopSrc s0{v, nullptr, 0.f, kk, list + rmax, 1};
-    const TopSrc s1{v, expo, tau, rr, list + rmax - 1, -1};
-    if (n <= 2048) {
+bool launch_topk_race(const float* v, const float* expo, float tau, int n, int kk, int rr, int rmax, int* list, float* list_scores,
+                      hipStream_t st) {
+    if (n <= 0 || kk <= 0) return true;
+    const bool one = n <= 2048;  // rank by counting: every element knows its value and its rank -- the scores go out with the ids
+    const TopSrc s0{v, nullptr, 0.f, kk, list + rmax, 1, one && list_scores ? list_scores + rmax : nullptr};
+    const TopSrc s1{v, expo, tau, rr, list + rmax - 1, -1, one && list_scores ? list_scores + rmax - 1 : nullptr};
+    if (one) {
         hipLaunchKernelGGL(topk_rank_blocks2_kernel, dim3((n + 63) / 64, rr > 0 ? 2 : 1), dim3(256), 0, st, s0, s1, n);
-        return;
+        return true;  // (list_scores written)
     }
     launch_topk(v, n, kk, list + rmax, st);
     if (rr > 0) hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(1024), 0, st, s1, n);  // (rr <= 64, n <= 16384)
+    return false;     // (the caller still has to gather list_scores: launch_window_stats)
 }
 
 // idx: the kk best entries of v, best first.  n = clamp(#{i < kk: v[idx[i]] >= v[idx[0]] - window}, kmin, kmax) and the
@@ -383,10 +393,7 @@ void launch_window_stats(const float* v, int n_total, const int* idx, int kk, in
 // still have to be re-scored.
 //   stats = {c, max_i |d_i - c|, need, (f* + c - delta) - (largest un-listed b) [inf when everything is listed], -, need_race,
 //            K*, K* + tau (c - delta)}   (slot 4 of the host copy carries the sequence number)
-__global__ __launch_bounds__(1024) void rescore_merge_kernel(const float* b, int n_total, const int* list, int r, int n,
-                                                             const float* list_scores, const float* f, float delta, const float* expo,
-                                                             float tau, float* out, float* stats, float* host_stats, float seq,
-                                                             int nstats) {
+__device__ __forceinline__ void rescore_merge_body(const float* b, int n_total, const int* list, int r, int n, const float* list_scores, const float* f, float delta, const float* expo, float tau, float* out, float* stats, float* host_stats, float seq, int nstats) {
     __shared__ float d[1024];
     __shared__ int ids[1024];
     __shared__ float c_sh;
@@ -479,11 +486,29 @@ __global__ __launch_bounds__(1024) void rescore_merge_kernel(const float* b, int
         }
     }
 }
+__global__ __launch_bounds__(1024) void rescore_merge_kernel(const float* b, int n_total, const int* list, int r, int n, const float* list_scores, const float* f, float delta, const float* expo, float tau, float* out, float* stats, float* host_stats, float seq, int nstats) {
+    rescore_merge_body(b, n_total, list, r, n, list_scores, f, delta, expo, tau, out, stats, host_stats, seq, nstats);
+}
+// merge + select in one launch (both are one workgroup over the whole vector): the select reads the merged vector the
+// workgroup itself has just written (workgroup-scope visibility behind __syncthreads)
+__global__ __launch_bounds__(1024) void merge_select_kernel(const float* b, int n_total, const int* list, int r, int n, const float* list_scores, const float* f, float delta, const float* expo, float tau, float* out, float* stats, float* host_stats, float seq, int nstats, SelectP sp) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    rescore_merge_body(b, n_total, list, r, n, list_scores, f, delta, expo, tau, out, stats, host_stats, seq, nstats);
+    __syncthreads();
+    select_body(sp, sv, si);
+}
 void launch_rescore_merge(const float* b, int n_total, const int* list, int r, int n, const float* list_scores, const float* f,
                           float delta, const float* expo, float tau, float* out, float* stats, float* host_stats, float seq,
                           hipStream_t st) {
     hipLaunchKernelGGL(rescore_merge_kernel, dim3(1), dim3(1024), 0, st, b, n_total, list, r, n, list_scores, f, delta, expo, tau, out,
                        stats, host_stats, seq, expo ? 8 : 4);
+}
+void launch_merge_select(const float* b, int n_total, const int* list, int r, int n, const float* list_scores, const float* f,
+                         float delta, const float* expo, float tau, float* out, float* stats, float* host_stats, float seq,
+                         const SelectP& sp, hipStream_t st) {
+    hipLaunchKernelGGL(merge_select_kernel, dim3(1), dim3(1024), 0, st, b, n_total, list, r, n, list_scores, f, delta, expo, tau, out,
+                       stats, host_stats, seq, expo ? 8 : 4, sp);
 }
 
 __global__ void scatter_kernel(const float* src, const int* index, int n, float* dst, int* index_copy) {

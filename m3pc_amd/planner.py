@@ -517,6 +517,7 @@ class HipPlanner(GoalMixin, LockstepMixin):
                 hd.candidate_join(sl.i)
             if self.rescore == "none":
                 tk.er = tk.er_b
+                tk.sel = hd.select(tk.er, tk.a0, float(cfg.temperature), tk.expo, out=tk.outbuf)
             else:
                 rs, tail = self._rescore_args(tk)
                 if self.rescore == "bound":
@@ -540,34 +541,42 @@ class HipPlanner(GoalMixin, LockstepMixin):
                 R = tk.R
                 if self.rescore == "bound" and R > 0:
                     rfirst = max(min(tk.rfirst_in, R), 1)
-                    hd.topk_race_window(tk.er_b, tk.expo, float(cfg.temperature), kmax, kmin, R, lst=tk.lst, stats=sl.stats,
-                                        list_scores=sl.b_lst)
+                    hd.topk_race_window(tk.er_b, tk.expo, float(cfg.temperature), kmax, kmin, R, lst=tk.lst, list_scores=sl.b_lst,
+                                        want_stats=False)  # (the certificates come from the merge: no window statistics launch)
                 else:
                     rfirst = 0
                     hd.topk_window(tk.er_b, kmax, kmin, 0.0, top=tk.top, stats=sl.stats, top_scores=sl.b_top)
                 hd.rescore(*rs, tk.lst[R - rfirst : R + kmin], *tail, N, slot=sl.i, out=sl.f_lst[R - rfirst : R + kmin],
                            want_actions=False)
                 tk.n_done, tk.r_done = kmin, rfirst
-                self._merge(tk, kmin, rfirst)
-            tk.sel = hd.select(tk.er, tk.a0, float(cfg.temperature), tk.expo, out=tk.outbuf)
+                self._merge(tk, kmin, rfirst, select=True)
             if tk.tchain is not None:
                 sl.ev_done.record(tk.tchain)
 
-    def _merge(self, tk, n, r=0):
+    def _merge(self, tk, n, r=0, select=False):
         """Merge + certificates over the r race entries and n score entries re-scored so far (score entries: the step's list
-        buffer, or the window-set path's own tensors ``tk.wset`` behind the buffer's race entries)."""
+        buffer, or the window-set path's own tensors ``tk.wset`` behind the buffer's race entries).  select: the select on the
+        merged vector too (-> tk.sel) -- with the race certificate in the same launch (m3pc_merge_race_select)."""
         sl = tk.slot
         tk.seq_mrg = sl.hs_mrg.next_seq()
         o = tk.R - r
         lists = (tk.lst[o:], sl.b_lst[o:], sl.f_lst[o:])
         if tk.wset is not None:
             tk.keep = lists = tuple(torch.cat([a[:r], b]).contiguous() for a, b in zip(lists, tk.wset))
+        temp = float(self.cfg.temperature)
         if self.rescore == "bound" and tk.R > 0:
-            self.handle.rescore_merge_race(tk.er_b, tk.expo, float(self.cfg.temperature), lists[0], r, n, lists[1], lists[2],
+            if select:
+                _, _, tk.sel = self.handle.merge_race_select(tk.er_b, tk.expo, temp, lists[0], r, n, lists[1], lists[2], tk.a0,
+                                                             delta=tk.delta, merged=tk.er, stats=sl.mstats,
+                                                             host_stats=sl.hs_mrg.buf, seq=tk.seq_mrg, out=tk.outbuf)
+                return
+            self.handle.rescore_merge_race(tk.er_b, tk.expo, temp, lists[0], r, n, lists[1], lists[2],
                                            delta=tk.delta, merged=tk.er, stats=sl.mstats, host_stats=sl.hs_mrg.buf, seq=tk.seq_mrg)
         else:
             self.handle.rescore_merge(tk.er_b, lists[0], n, lists[1], lists[2], delta=tk.delta, merged=tk.er, stats=sl.mstats,
                                       host_stats=sl.hs_mrg.buf, seq=tk.seq_mrg)
+        if select:
+            tk.sel = self.handle.select(tk.er, tk.a0, temp, tk.expo, out=tk.outbuf)
 
     def _finish(self, tk):
         """Resolve a ticket: enqueue what is still missing, read the re-score's certificate, finish the re-score if it asks

@@ -52,6 +52,11 @@ def test_topk_race_window_lists_against_torch(n, tau, kmax, rmax):
             assert a == b or abs(float(kd[a] - kd[b])) <= 4e-6 * max(1.0, abs(float(kd[a]))), (a, b)
     assert torch.equal(scores[rmax - rmax : rmax + kk], er[lst[: rmax + kk].long()])
     assert float(stats[2]) == float(er.max())
+    # without the window statistics (what the planner asks for): up to 2048 candidates the ranking launch writes the listed scores itself
+    scores2 = torch.full((rmax + kmax + 1,), float("nan"), device="cuda")
+    lst2, st2 = h.topk_race_window(er, expo, tau, kmax, kmin, rmax, list_scores=scores2, want_stats=False)
+    torch.cuda.synchronize()
+    assert st2 is None and torch.equal(lst2[: rmax + kk], lst[: rmax + kk]) and torch.equal(scores2[: rmax + kk], scores[: rmax + kk])
     h.close()
 
 
