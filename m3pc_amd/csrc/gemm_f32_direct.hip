@@ -170,6 +170,171 @@ __global__ __launch_bounds__(1024) void gemm_f32_direct_group_kernel(GemmGroupP 
     gemm_f32_direct_body<1, 16>(p, blockIdx.x, part, lnst);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The scalar output heads of a few-row fp32 pass (the re-score's rewards / returns heads, mtm_model.py:428-433) in ONE launch:
+//   y[r] = w2 . gelu(W1 LN_head(LN_dec(x_r)) + b1) + b2   [de-tokenised]
+// for up to two heads (blockIdx.y) over `rows` rows each.  Replaces, per head, a double-LayerNorm launch, a 512 x 512 GEMM launch
+// and the Linear(512, 1) launch -- six dependent launches of a chain that is bound by its launches.
+// The product runs as gemm_f32_direct_body does (32 x 32 tile per 16-wave workgroup, K split 16 ways inside it, operands global ->
+// registers in MFMA fragment order); the two LayerNorms ride on the operand load (every workgroup computes the statistics of its 32
+// rows: layernorm_vec_kernel's arithmetic, twice); the epilogue multiplies the gelu'd tile by its 32 entries of w2 and sums them per
+// row; the N / 32 partial sums of a row meet in `part`, and the LAST workgroup of a row tile (an atomic ticket) adds them in tile
+// order -- a fixed order, so the result does not depend on which workgroup came last.
+template <int D>
+__global__ __launch_bounds__(1024) void head_f32_fused_kernel(HeadFusedP hp) {
+    __shared__ float part[16 * 1024];
+    __shared__ float lnst[32][4];
+    __shared__ int last_sh;
+    const int hs = blockIdx.y;
+    // (per-head pointers picked with selects: a run-time index into the by-value parameter struct would copy it to scratch)
+    const float* const hW1 = hs ? hp.W1[1] : hp.W1[0];
+    const float* const hb1 = hs ? hp.b1[1] : hp.b1[0];
+    const float* const hw2 = hs ? hp.w2[1] : hp.w2[0];
+    const float* const hb2 = hs ? hp.b2[1] : hp.b2[0];
+    const float* const hgB = hs ? hp.gB[1] : hp.gB[0];
+    const float* const hbB = hs ? hp.bB[1] : hp.bB[0];
+    const float* const hmean = hs ? hp.mean[1] : hp.mean[0];
+    const float* const hstdv = hs ? hp.stdv[1] : hp.stdv[0];
+    float* const hout = hs ? hp.out[1] : hp.out[0];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    constexpr int K = D, N = D, ntn = N / 32;
+    const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
+    constexpr int kslice = K / 16;
+    const int ks = wid;
+    auto phys = [&](int r) { return (long long)((r / hp.grp) * hp.row_mod + hs * hp.grp + r % hp.grp); };
+    int gr = tm * 32 + l31;
+    if (gr >= hp.rows) gr = hp.rows - 1;
+    const float* a = hp.X + phys(gr) * hp.ldx + ks * kslice + 4 * lh;
+    const float* w = hW1 + (long long)(tn * 32 + l31) * K + ks * kslice + 4 * lh;
+    // statistics of the two LayerNorms of tile rows 2 wid, 2 wid + 1 (decoder.norm, then the head's own)
+    {
+        constexpr int nsl = K >> 8;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            int r = tm * 32 + 2 * wid + rr;
+            if (r >= hp.rows) r = hp.rows - 1;
+            const float* x = hp.X + phys(r) * hp.ldx;
+            f32x4 v[nsl];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < nsl; ++i) {
+                    v[i] = *(const f32x4*)(x + i * 256 + lane * 4);
+                    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+                }
+            const float inv_d = 1.0f / (float)K;
+            const float m1 = wave_sum_d(s) * inv_d;
+            float qq = 0.f;
+#pragma unroll
+            for (int i = 0; i < nsl; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float c = v[i][e] - m1;
+                        qq += c * c;
+                    }
+            const float rs1 = rsqrtf(wave_sum_d(qq) * inv_d + 1e-5f);
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < nsl; ++i) {
+                    const f32x4 g = *(const f32x4*)(hp.gA + i * 256 + lane * 4), b = *(const f32x4*)(hp.bA + i * 256 + lane * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - m1) * rs1 * g[e] + b[e];
+                    s2 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+                }
+            const float m2 = wave_sum_d(s2) * inv_d;
+            float q2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < nsl; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float c = v[i][e] - m2;
+                        q2 += c * c;
+                    }
+            const float rs2 = rsqrtf(wave_sum_d(q2) * inv_d + 1e-5f);
+            if (lane == 0) {
+                lnst[2 * wid + rr][0] = m1;
+                lnst[2 * wid + rr][1] = rs1;
+                lnst[2 * wid + rr][2] = m2;
+                lnst[2 * wid + rr][3] = rs2;
+            }
+        }
+        __syncthreads();
+    }
+    const float m1 = lnst[l31][0], rs1 = lnst[l31][1], m2 = lnst[l31][2], rs2 = lnst[l31][3];
+    const float* gA = hp.gA + ks * kslice + 4 * lh;
+    const float* bA = hp.bA + ks * kslice + 4 * lh;
+    const float* gB = hgB + ks * kslice + 4 * lh;
+    const float* bB = hbB + ks * kslice + 4 * lh;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    // (one 8-value step at a time: 16 waves per workgroup leave 128 registers per wave, and a batch of four steps with its four
+    // LayerNorm parameter vectors per operand load spilled)
+#pragma unroll 2
+    for (int o = 0; o < kslice; o += 8) {
+        f32x4 fa = *(const f32x4*)(a + o);
+        const f32x4 fw = *(const f32x4*)(w + o);
+        const f32x4 g1 = *(const f32x4*)(gA + o), b1 = *(const f32x4*)(bA + o), g2 = *(const f32x4*)(gB + o), b2 = *(const f32x4*)(bB + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float y = (fa[e] - m1) * rs1 * g1[e] + b1[e];
+            fa[e] = (y - m2) * rs2 * g2[e] + b2[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fw[e], acc, 0, 0, 0);
+    }
+    float* mine = part + ks * 1024;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) mine[reg * 64 + lane] = acc[reg];
+    __syncthreads();
+    {
+        const int reg = tid >> 6, ln = tid & 63;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += part[k * 1024 + tid];
+        const int r = tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5);
+        const int c = tn * 32 + (ln & 31);
+        v = gelu_exact_d(v + hb1[c]) * hw2[c];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);  // over the tile's 32 columns (one half wave per row)
+        // (agent-scope atomic store: written through to where every XCD sees it -- no fence, hence no L2 write-back, needed)
+        if ((ln & 31) == 0 && r < hp.rows) __hip_atomic_store(hp.part + ((long long)hs * hp.rows + r) * ntn + tn, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the last workgroup of this row tile adds the N / 32 partial sums of each of its rows, in tile order.  Ordering without a
+    // device-scope fence (an agent-scope release fence writes the XCD's whole L2 back: measured 350 us per launch with
+    // __threadfence() here): the partial sums are agent-scope atomic stores, every wave waits for its own to be acknowledged
+    // (vmcnt), the workgroup barrier orders them before the ticket, and the reader uses agent-scope atomic loads
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const int t = __hip_atomic_fetch_add(hp.ticket + hs * ((hp.rows + 31) / 32) + tm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_sh = t == ntn - 1;
+        if (last_sh) __hip_atomic_store(hp.ticket + hs * ((hp.rows + 31) / 32) + tm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (ready for the next launch)
+    }
+    __syncthreads();
+    if (!last_sh) return;
+    if (tid < 32) {
+        const int r = tm * 32 + tid;
+        if (r < hp.rows) {
+            const float* pr = hp.part + ((long long)hs * hp.rows + r) * ntn;
+            float y = 0.f;
+            for (int t = 0; t < ntn; ++t) y += __hip_atomic_load(pr + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            y += hb2[0];
+            if (hmean) y = __fadd_rn(__fmul_rn(y, hstdv[0]), hmean[0]);  // de-tokenise (continuous.py:86-94)
+            hout[r] = y;
+        }
+    }
+}
+
+bool launch_head_f32_fused(const HeadFusedP& p, hipStream_t st) {
+    if (p.n_heads < 1 || p.n_heads > 2 || p.rows < 1 || p.rows > 4096 || p.d != 512) return false;
+    if (((uintptr_t)p.X & 15) || (p.ldx % 4) || !p.part || !p.ticket || p.grp < 1 || p.row_mod < p.grp * p.n_heads) return false;
+    for (int s = 0; s < p.n_heads; ++s)
+        if (!p.W1[s] || !p.b1[s] || !p.w2[s] || !p.b2[s] || !p.gB[s] || !p.bB[s] || !p.out[s] || ((uintptr_t)p.W1[s] & 15)) return false;
+    hipLaunchKernelGGL((head_f32_fused_kernel<512>), dim3(((p.rows + 31) / 32) * (p.d / 32), p.n_heads), dim3(1024), 0, st, p);
+    return true;
+}
+
 bool gemm_f32_direct_covers(const GemmP& p) {
     if (!p.Cf || p.Cb || p.M > 1024 || p.M < 1) return false;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || (p.lda % 4) || (p.ldw % 4)) return false;

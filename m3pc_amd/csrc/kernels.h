@@ -67,6 +67,24 @@ struct GemmP {
     const float* a_ln_g;
     const float* a_ln_b;
 };
+// The scalar output heads (D_k == 1) of a few-row fp32 pass in one launch (gemm_f32_direct.hip: head_f32_fused_kernel):
+// out[s][r] = w2[s] . gelu(W1[s] LN_B[s](LN_A(x)) + b1[s]) + b2[s] [* stdv + mean], x = row (r / grp) * row_mod + s * grp + r % grp of X
+struct HeadFusedP {
+    const float* X;
+    int ldx;
+    int rows, d;          // rows per head; d = model width (512)
+    int n_heads;          // 1 or 2 (blockIdx.y)
+    int grp, row_mod;     // physical row of (head s, row r): (r / grp) * row_mod + s * grp + r % grp
+    const float *gA, *bA; // decoder.norm
+    const float *gB[2], *bB[2];  // the head's LayerNorm
+    const float *W1[2], *b1[2];  // Linear(d, d)
+    const float *w2[2], *b2[2];  // Linear(d, 1)
+    const float *mean[2], *stdv[2];  // optional: de-tokenise
+    float* out[2];        // (rows,)
+    float* part;          // scratch: n_heads * rows * (d / 32) floats
+    int* ticket;          // scratch: n_heads * ceil(rows / 32) ints, zero before the first launch (the kernel leaves them zero)
+};
+bool launch_head_f32_fused(const HeadFusedP& p, hipStream_t st);  // false: not covered
 int launch_gemm(const GemmP& p, int dtype, hipStream_t st);
 bool gemm_f32_direct_covers(const GemmP& p);             // would launch_gemm_f32_direct take this problem (incl. a_ln_*)?
 bool launch_gemm_f32_direct_group(const GemmP* ps, int n, hipStream_t st);  // n <= 4 covered problems in ONE launch

@@ -163,6 +163,9 @@ struct m3pc_handle {
               *qv = nullptr, *splitk_ws = nullptr;
         char *Hn = nullptr, *QKV = nullptr, *O = nullptr, *F = nullptr, *Z = nullptr;
         long long splitk_ws_bytes = 0;
+        float* head_part = nullptr;   // scratch of the fused fp32 scalar heads (launch_head_f32_fused): 2 * head_rows * 64 floats
+        int* head_ticket = nullptr;   // its row-tile tickets (zero between launches)
+        int head_rows = 0;            // rows per head the scratch holds
         long long R = 0;       // token rows
         int max_cand = 0;      // candidates (rows of cand / pred / qv)
     } base, chain[2], pchain[2];  // chain / pchain: one per step-slot parity (see below)
@@ -293,10 +296,16 @@ inline int alloc_ws(m3pc_handle* h, m3pc_handle::Base& b, long long R_, int max_
     CHK(dmalloc(&b.qv, (size_t)max_cand * T));
     b.splitk_ws_bytes = splitk_bytes;
     CHK(dmalloc(&b.splitk_ws, (size_t)(splitk_bytes / 4)));
+    if (max_cand <= 4096) {  // (the few-row workspaces: the fused fp32 heads of a re-score; at most T scored rows per candidate and head)
+        b.head_rows = (int)((long long)max_cand * h->T < 4096 ? (long long)max_cand * h->T : 4096);
+        CHK(dmalloc(&b.head_part, (size_t)2 * b.head_rows * 64));
+        CHK(dmalloc(&b.head_ticket, (size_t)2 * ((b.head_rows + 31) / 32)));
+        HIPCHK(hipMemset(b.head_ticket, 0, (size_t)2 * ((b.head_rows + 31) / 32) * sizeof(int)));
+    }
     return 0;
 }
 inline void free_ws(m3pc_handle::Base& b) {
-    void* bufs[] = {b.X, b.Y, b.EncOut, b.G, b.Hn, b.QKV, b.O, b.F, b.Z, b.cand, b.pred[0], b.pred[1], b.qv, b.splitk_ws};
+    void* bufs[] = {b.X, b.Y, b.EncOut, b.G, b.Hn, b.QKV, b.O, b.F, b.Z, b.cand, b.pred[0], b.pred[1], b.qv, b.splitk_ws, b.head_part, b.head_ticket};
     for (void* p : bufs)
         if (p) hipFree(p);
     b = m3pc_handle::Base();

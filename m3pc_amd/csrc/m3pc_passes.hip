@@ -883,7 +883,45 @@ int pruned_decoder(m3pc_handle* h, Plan* pl, Plan::Query& q, SharedTables& tb, i
         gemm(h, p, dt, st);
     }
     // heads of the scored keys -> pred[s] (n*grp, D_k), de-tokenized
-    for (int s = 0; s < q.n_groups && tail == TAIL_HEADS; ++s) {
+    bool heads_done = false;
+    {   // few-row fp32 pass with scalar heads only (the re-score of an rtg_guiding step): both heads in ONE launch
+        static const bool no_head_f32 = M3PC_ENV("M3PC_NO_HEAD_F32_FUSED") != nullptr || M3PC_ENV("M3PC_NO_F32_DIRECT") != nullptr;  // A/B switch
+        bool scalar = tail == TAIL_HEADS && dt == DT_F32 && h->allow_splitk && !no_head_f32 && h->cur && h->cur->head_part &&
+                      n * hh <= h->cur->head_rows && q.n_groups >= 1 && q.n_groups <= 2;
+        for (int s = 0; s < q.n_groups && scalar; ++s) scalar = h->feat[q.qkeys[s]] == 1 && q.qkeys[s] != M3PC_ACTIONS;
+        if (scalar) {
+            HeadFusedP hp;
+            memset(&hp, 0, sizeof(hp));
+            hp.X = Y1;
+            hp.ldx = d;
+            hp.rows = n * hh;
+            hp.d = d;
+            hp.n_heads = q.n_groups;
+            hp.grp = hh;
+            hp.row_mod = nq;
+            hp.gA = W(h, "decoder.norm.weight").f;
+            hp.bA = W(h, "decoder.norm.bias").f;
+            for (int s = 0; s < q.n_groups; ++s) {
+                const std::string hn = std::string("output_head_dict.") + KEYN[q.qkeys[s]];
+                hp.gB[s] = W(h, hn + ".0.weight").f;
+                hp.bB[s] = W(h, hn + ".0.bias").f;
+                hp.W1[s] = W(h, hn + ".1.weight").f;
+                hp.b1[s] = W(h, hn + ".1.bias").f;
+                hp.w2[s] = W(h, hn + ".3.weight").f;
+                hp.b2[s] = W(h, hn + ".3.bias").f;
+                if (h->tok_norm[q.qkeys[s]]) {
+                    hp.mean[s] = h->tok_mean[q.qkeys[s]];
+                    hp.stdv[s] = h->tok_std[q.qkeys[s]];
+                }
+                hp.out[s] = h->pred[s];
+            }
+            hp.part = h->cur->head_part;
+            hp.ticket = h->cur->head_ticket;
+            GemmTimer t(h, st, q.n_groups * 2.0 * n * hh * (double)d * d, dt);
+            heads_done = launch_head_f32_fused(hp, st);
+        }
+    }
+    for (int s = 0; s < q.n_groups && tail == TAIL_HEADS && !heads_done; ++s) {
         RowMap xm{hh, nq, s * hh};
         CHK(run_head(h, q.qkeys[s], Y1, xm, n * hh, h->pred[s], h->feat[q.qkeys[s]], true, dt, st));
     }
