@@ -16,7 +16,8 @@ def main():
     f = glob.glob(src + "/**/*kernel_trace.csv", recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    ends = [i for i, r in enumerate(rows) if "::select_kernel" in r["Kernel_Name"]]  # (not topk_select_kernel)
+    # a step ends with its select: a launch of its own, or (round 5) the second half of merge_select_kernel (not topk_select_kernel)
+    ends = [i for i, r in enumerate(rows) if "::select_kernel" in r["Kernel_Name"] or "merge_select_kernel" in r["Kernel_Name"]]
     k = len(ends) // 5  # bench.py runs warmup, timed, latency and instrumented passes: this one is inside the timed region
     a, b = ends[k] + 1, ends[k + 1] + 1
     step = rows[a:b]
