@@ -271,6 +271,7 @@ def main():
     ap.add_argument("--chain-mode", default="alternate", choices=["alternate", "split"],
                     help="pipelined steps: a step's policy pass and re-score on the chain stream of its parity (alternate), or all "
                          "policy passes on one stream and all re-scores on the other (split, rounds 3-4)")
+    ap.add_argument("--chain-priority", type=int, default=-1, help="stream priority of the two chain streams (-1: high, the default; 0: normal)")
     ap.add_argument("--policy-head", default="full", choices=["pruned", "full"],
                     help="policy pass: every row of the policy head (default) or the h sampled action tokens only, through the pruned decoder")
     ap.add_argument("--race-min", type=int, default=0, help="race entries of a first re-score pass (0: the planner's default)")
@@ -339,7 +340,7 @@ def main():
                          precision=args.precision, rescore_topk=args.rescore_topk, device=local_rank, generator=gen,
                          rescore=args.rescore, **({"rescore_min": args.rescore_min} if args.rescore_min else {}), group=group,
                          certify_sample=not args.no_certify_sample, **({"race_min": args.race_min} if args.race_min else {}),
-                         chain_mode=args.chain_mode, policy_head=args.policy_head,
+                         chain_mode=args.chain_mode, policy_head=args.policy_head, chain_priority=args.chain_priority,
                          pipeline_depth=max(1, min(args.depth, capi.SLOTS - 1)))
     hist = synth.make_history(dims, 0 if (shard_cand or world == 1) else rank)  # env sharding: every rank its own environment
     hist["path_length"] = 500
