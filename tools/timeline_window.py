@@ -13,7 +13,7 @@ def main():
     f = glob.glob(src + "/**/*kernel_trace.csv", recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    ends = [i for i, r in enumerate(rows) if "::select_kernel" in r["Kernel_Name"]]
+    ends = [i for i, r in enumerate(rows) if "::select_kernel" in r["Kernel_Name"] or "merge_select_kernel" in r["Kernel_Name"]]
     k = len(ends) // 2
     a, b = ends[k] + 1, ends[k + n] + 1
     step = rows[a:b]
