@@ -197,3 +197,45 @@ def test_deferred_join_orders_other_users_of_the_candidate_workspace():
         assert torch.equal(res["expect_return"], want_er)
         assert torch.equal(got_fwd[0], want_fwd[0]) and torch.equal(got_fwd[1], want_fwd[1])
     hd.close()
+
+
+@pytest.mark.parametrize("guidance,N,T,H", [("rtg_guiding", 1024, 32, 16), ("critic_lambda_guiding", 512, 32, 16), ("rtg_guiding", 625, 8, 4)])
+def test_chain_modes_and_options_give_the_same_bits(guidance, N, T, H):
+    """Round 5: `chain_mode="alternate"` (a step's policy pass and re-score on the chain stream of its slot's parity, two chain
+    workspaces per kind in the library, the tail of step t enqueued behind the policy pass of step t + 2) against "split" (rounds
+    3-4: every policy pass on one stream, every re-score on the other) and against the serial order: 14 windows, three in flight --
+    every step's scores, certificates' outcomes (arg-max, multinomial index) and actions bit for bit, and the same number of
+    candidates re-scored (the adaptive first pass is lagged by the slot count precisely so that it does not depend on the order)."""
+    S, A = (11, 3) if guidance == "rtg_guiding" else (17, 6)
+    dims = synth.Dims(S, A, T)
+    wins = _windows(dims, 14)
+
+    def run(**kw):
+        p = _planner(dims, N, H, guidance, "bf16", pipeline_depth=3, **kw)
+        flight, out = [], []
+        for i, w in enumerate(wins):
+            flight.append(p.plan_async(w, eval=bool(i % 2), rtg=3.0))
+            if len(flight) > 3:
+                tk = flight.pop(0)
+                res = tk.result().clone()
+                out.append((_snap(tk.info), res, tk.info["n_rescored"], tk.info["n_race"]))
+        while flight:
+            tk = flight.pop(0)
+            res = tk.result().clone()
+            out.append((_snap(tk.info), res, tk.info["n_rescored"], tk.info["n_race"]))
+        torch.cuda.synchronize()
+        p.handle.close()
+        return out
+
+    ps = _planner(dims, N, H, guidance, "bf16")
+    serial = []
+    for i, w in enumerate(wins):
+        res = ps.action_sample(w, plan=True, eval=bool(i % 2), rtg=3.0).clone()
+        serial.append((_snap(ps.last), res, ps.last["n_rescored"], ps.last["n_race"]))
+    ps.handle.close()
+    for name, got in (("alternate", run(chain_mode="alternate")), ("split", run(chain_mode="split")),
+                      ("alternate, one chain stream", run(chain_mode="alternate", tail_stream=False))):
+        for i, ((g, res, nr, nc), (s, res_s, nr_s, nc_s)) in enumerate(zip(got, serial)):
+            for k in KEYS:
+                assert torch.equal(g[k], s[k]), (name, i, k)
+            assert torch.equal(res, res_s) and (nr, nc) == (nr_s, nc_s), (name, i, nr, nr_s, nc, nc_s)
