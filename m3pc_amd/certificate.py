@@ -23,8 +23,6 @@ import warnings
 
 import torch
 
-from . import capi
-
 RACE_MAX = 32  # race entries a step may list (m3pc_topk_race_window rmax); beyond: the whole-set fp32 slow path
 
 

@@ -17,8 +17,12 @@ Pipelining (``plan_async`` / ``PlanTicket.result``, ``action_sample_batch``, ``r
 plans one window per call and reads the action back before the next one (replay_buffer.py:204-232, learner.py:645-741).
 For INDEPENDENT windows (several environments, evaluation episodes) the three parts of a plan step need not wait for each
 other across steps: the candidate passes run back to back on the caller's stream, while the latency-bound fp32 chains --
-step t+1's policy pass, step t's re-score + select -- run on a second ("chain") stream in the library's chain workspace.
-Every step owns a slot (policy head, returns tokens, re-score scratch); its results are bit-identical to the serial order.
+the policy passes and the re-scores + selects of the neighbouring steps -- run on two more ("chain") streams in the library's
+chain workspaces (``chain_mode``: a step's two chains on the stream of its slot's parity).  Every step owns a slot (policy head,
+returns tokens, re-score scratch); its results are bit-identical to the serial order.
+
+This file is the step pipeline (``HipPlanner``, ``PlanTicket``, ``attach``); the certified re-score's protocol lives in
+``certificate.py``, the zero-shot calls and CEM in ``goal.py``, environments that step together in ``lockstep.py``.
 """
 from __future__ import annotations
 
@@ -26,7 +30,6 @@ import types
 from typing import Dict, Optional
 
 import contextlib
-import warnings
 
 import numpy as np
 
