@@ -509,7 +509,81 @@ void launch_head_out(const HeadOutP& p, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------ actor head
+// One wave per row.  Optional LayerNorm of the row first (ln_g / ln_b: decoder.norm, mtm_model.py:705 -- layernorm_vec_kernel's
+// arithmetic, so the pair "LayerNorm launch + actor launch" of a batch-1 policy pass is one launch); the row and the weight rows
+// are read 16 bytes per lane, and the 2 A dot products are independent chains reduced by one batch of butterflies (the kernel
+// is pure latency: 128 rows, a few KB of weights).
+template <int AMAX>
 __global__ __launch_bounds__(256) void actor_head_kernel(ActorP p) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.rows) return;
+    const float* x = p.X + (long long)map_row(p.xmap, r) * p.ldx;
+    const int n = p.d >> 8;  // slabs of 256 columns (<= 4)
+    f32x4v v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < n) {
+            v[i] = *(const f32x4v*)(x + i * 256 + lane * 4);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    if (p.ln_g) {
+        const float inv_d = 1.0f / (float)p.d;
+        const float mean = wave_sum(s) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float c = v[i][e] - mean;
+                    q += c * c;
+                }
+        const float rstd = rsqrtf(wave_sum(q) * inv_d + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n) {
+                const f32x4v g = *(const f32x4v*)(p.ln_g + i * 256 + lane * 4);
+                const f32x4v b = *(const f32x4v*)(p.ln_b + i * 256 + lane * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            }
+    }
+    float s1[AMAX], s2[AMAX];
+#pragma unroll
+    for (int f = 0; f < AMAX; ++f) {
+        s1[f] = 0.f;
+        s2[f] = 0.f;
+        const int ff = f < p.A ? f : p.A - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n) {
+                const f32x4v wm = *(const f32x4v*)(p.Wmu + (long long)ff * p.d + i * 256 + lane * 4);
+                const f32x4v wl = *(const f32x4v*)(p.Wls + (long long)ff * p.d + i * 256 + lane * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1[f] = fmaf(v[i][e], wm[e], s1[f]);
+                    s2[f] = fmaf(v[i][e], wl[e], s2[f]);
+                }
+            }
+    }
+#pragma unroll
+    for (int f = 0; f < AMAX; ++f) {
+        s1[f] = wave_sum(s1[f]);
+        s2[f] = wave_sum(s2[f]);
+    }
+#pragma unroll
+    for (int f = 0; f < AMAX; ++f)
+        if (f < p.A && lane == f) {  // (one lane per feature: the tanh / exp of the features run side by side)
+            p.mu[(long long)r * p.A + f] = s1[f] + p.bmu[f];
+            float ls = tanhf(s2[f] + p.bls[f]);
+            ls = -5.0f + 0.5f * (2.0f - (-5.0f)) * (ls + 1.0f);
+            p.sd[(long long)r * p.A + f] = expf(ls);
+        }
+}
+// d not a multiple of 256 (the tiny test configurations): the row 4 bytes per lane, no LayerNorm
+__global__ __launch_bounds__(256) void actor_head_small_kernel(ActorP p) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= p.rows) return;
@@ -519,42 +593,34 @@ __global__ __launch_bounds__(256) void actor_head_kernel(ActorP p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i)
         if (i < n) v[i] = x[i * 64 + lane];
-    // four features at a time: their 2 x 4 dot products and butterflies are independent chains, so the weight
-    // loads and the shuffles of one feature hide behind the others (this kernel is pure latency)
-    for (int f0 = 0; f0 < p.A; f0 += 4) {
-        float s1[4], s2[4];
+    for (int f = 0; f < p.A; ++f) {
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int f = f0 + k < p.A ? f0 + k : p.A - 1;
-            s1[k] = 0.f;
-            s2[k] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (i < n) {
-                    s1[k] = fmaf(v[i], p.Wmu[(long long)f * p.d + i * 64 + lane], s1[k]);
-                    s2[k] = fmaf(v[i], p.Wls[(long long)f * p.d + i * 64 + lane], s2[k]);
-                }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            s1[k] = wave_sum(s1[k]);
-            s2[k] = wave_sum(s2[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int f = f0 + k;
-            if (f < p.A && lane == 0) {
-                p.mu[(long long)r * p.A + f] = s1[k] + p.bmu[f];
-                float ls = tanhf(s2[k] + p.bls[f]);
-                ls = -5.0f + 0.5f * (2.0f - (-5.0f)) * (ls + 1.0f);
-                p.sd[(long long)r * p.A + f] = expf(ls);
+        for (int i = 0; i < 16; ++i)
+            if (i < n) {
+                s1 = fmaf(v[i], p.Wmu[(long long)f * p.d + i * 64 + lane], s1);
+                s2 = fmaf(v[i], p.Wls[(long long)f * p.d + i * 64 + lane], s2);
             }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) {
+            p.mu[(long long)r * p.A + f] = s1 + p.bmu[f];
+            float ls = tanhf(s2 + p.bls[f]);
+            ls = -5.0f + 0.5f * (2.0f - (-5.0f)) * (ls + 1.0f);
+            p.sd[(long long)r * p.A + f] = expf(ls);
         }
     }
 }
+bool actor_head_fuses_ln(int d, int A) { return d % 256 == 0 && d <= 1024 && A <= 8; }
 void launch_actor_head(const ActorP& p, hipStream_t st) {
     if (p.rows <= 0) return;
-    hipLaunchKernelGGL(actor_head_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, st, p);
+    const dim3 grid((p.rows + 3) / 4), block(256);
+    if (actor_head_fuses_ln(p.d, p.A)) {
+        if (p.A <= 4) hipLaunchKernelGGL((actor_head_kernel<4>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((actor_head_kernel<8>), grid, block, 0, st, p);
+    } else {
+        hipLaunchKernelGGL(actor_head_small_kernel, grid, block, 0, st, p);  // (ln_g must be null: callers ask actor_head_fuses_ln)
+    }
 }
 
 // ------------------------------------------------------------------------------------------ sampling

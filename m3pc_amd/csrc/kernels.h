@@ -321,8 +321,11 @@ struct ActorP {
     const float* bls;
     float* mu;   // (rows, A)
     float* sd;   // (rows, A)
+    const float* ln_g;  // optional: LayerNorm of the row first (decoder.norm); only when actor_head_fuses_ln(d, A)
+    const float* ln_b;
 };
 void launch_actor_head(const ActorP& p, hipStream_t st);
+bool actor_head_fuses_ln(int d, int A);
 
 // Candidate construction (learner.py:285-288 / 156-168): cand[n, t, :] = hist actions for t < idx,
 // tanh(loc + std * eps) for t >= idx (mode 0) or clamp(tanh(loc) + 0.09 * eps, +-0.99999) (mode 1).

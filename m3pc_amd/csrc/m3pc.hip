@@ -593,19 +593,26 @@ int m3pc_goal_step_batch(m3pc_handle* h, int batch, const float* states, const f
         float* xr = nullptr;
         CHK(goal_forward(h, goal_mode == M3PC_GOAL_PIID ? 3 : 2, 3, idx, second, ac_p, cnt, dt, s, TAIL_X, &xr));
         // decoder.norm of the one query row per window, then the action head (mtm_model.py:705, 313-321), fp32
-        LnP ln;
-        memset(&ln, 0, sizeof(ln));
-        ln.X = xr;
-        ln.ldx = d;
-        ln.rows = cnt;
-        ln.d = d;
-        ln.g1 = W(h, "decoder.norm.weight").f;
-        ln.b1 = W(h, "decoder.norm.bias").f;
-        ln.Yf = h->G;
-        launch_layernorm(ln, s);
+        const bool fuse_ln = actor_head_fuses_ln(d, h->A);  // (the head kernel normalises its rows itself: one launch fewer)
+        if (!fuse_ln) {
+            LnP ln;
+            memset(&ln, 0, sizeof(ln));
+            ln.X = xr;
+            ln.ldx = d;
+            ln.rows = cnt;
+            ln.d = d;
+            ln.g1 = W(h, "decoder.norm.weight").f;
+            ln.b1 = W(h, "decoder.norm.bias").f;
+            ln.Yf = h->G;
+            launch_layernorm(ln, s);
+        }
         ActorP ac;
         memset(&ac, 0, sizeof(ac));
-        ac.X = h->G;
+        ac.X = fuse_ln ? xr : h->G;
+        if (fuse_ln) {
+            ac.ln_g = W(h, "decoder.norm.weight").f;
+            ac.ln_b = W(h, "decoder.norm.bias").f;
+        }
         ac.ldx = d;
         ac.rows = cnt;
         ac.d = d;
@@ -709,19 +716,26 @@ int m3pc_policy_pass(m3pc_handle* h, const m3pc_plan_args* a, const float* state
         if (!rc) rc = pruned_decoder(h, pl, pl->query[4], pl->query[4].tab[DT_F32], 1, DT_F32, st, TAIL_X, &xr);
         if (!rc) {  // decoder.norm of the h query rows, then the action head (mtm_model.py:705, 313-321)
             const int d = h->d;
-            LnP ln;
-            memset(&ln, 0, sizeof(ln));
-            ln.X = xr;
-            ln.ldx = d;
-            ln.rows = hh;
-            ln.d = d;
-            ln.g1 = W(h, "decoder.norm.weight").f;
-            ln.b1 = W(h, "decoder.norm.bias").f;
-            ln.Yf = h->G;
-            launch_layernorm(ln, st);
+            const bool fuse_ln = actor_head_fuses_ln(d, h->A);
+            if (!fuse_ln) {
+                LnP ln;
+                memset(&ln, 0, sizeof(ln));
+                ln.X = xr;
+                ln.ldx = d;
+                ln.rows = hh;
+                ln.d = d;
+                ln.g1 = W(h, "decoder.norm.weight").f;
+                ln.b1 = W(h, "decoder.norm.bias").f;
+                ln.Yf = h->G;
+                launch_layernorm(ln, st);
+            }
             ActorP ac;
             memset(&ac, 0, sizeof(ac));
-            ac.X = h->G;
+            ac.X = fuse_ln ? xr : h->G;
+            if (fuse_ln) {
+                ac.ln_g = W(h, "decoder.norm.weight").f;
+                ac.ln_b = W(h, "decoder.norm.bias").f;
+            }
             ac.ldx = d;
             ac.rows = hh;
             ac.d = d;

@@ -485,21 +485,30 @@ int forward_impl(m3pc_handle* h, Plan* pl, const TokIn& in, int batch, float* ou
         CHK(run_head(h, k, h->Y, m, batch * T, outs[k], h->feat[k], false, dt, st));
     }
     if (out_mu && out_std) {
-        LnP ln;
-        memset(&ln, 0, sizeof(ln));
-        ln.X = h->Y;
-        ln.ldx = d;
-        ln.xmap = RowMap{T, 4 * T, M3PC_ACTIONS * T};
-        ln.rows = batch * T;
-        ln.d = d;
-        ln.g1 = W(h, "decoder.norm.weight").f;
-        ln.b1 = W(h, "decoder.norm.bias").f;
-        ln.Yf = h->G;
-        launch_layernorm(ln, st);
+        // decoder.norm of the action rows, then the actor head: one launch when the head kernel can normalise its rows itself
+        const bool fuse = actor_head_fuses_ln(d, h->A);
+        if (!fuse) {
+            LnP ln;
+            memset(&ln, 0, sizeof(ln));
+            ln.X = h->Y;
+            ln.ldx = d;
+            ln.xmap = RowMap{T, 4 * T, M3PC_ACTIONS * T};
+            ln.rows = batch * T;
+            ln.d = d;
+            ln.g1 = W(h, "decoder.norm.weight").f;
+            ln.b1 = W(h, "decoder.norm.bias").f;
+            ln.Yf = h->G;
+            launch_layernorm(ln, st);
+        }
         ActorP a;
         memset(&a, 0, sizeof(a));
-        a.X = h->G;
+        a.X = fuse ? h->Y : h->G;
         a.ldx = d;
+        if (fuse) {
+            a.xmap = RowMap{T, 4 * T, M3PC_ACTIONS * T};
+            a.ln_g = W(h, "decoder.norm.weight").f;
+            a.ln_b = W(h, "decoder.norm.bias").f;
+        }
         a.rows = batch * T;
         a.d = d;
         a.A = h->A;
