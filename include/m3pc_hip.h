@@ -31,7 +31,8 @@
  * the re-score workspace (m3pc_rescore* / fp32 m3pc_score_actions of <= max_rescore candidates).  Calls
  * that use the SAME workspace must be ordered on the device (same stream, or events); calls on different
  * workspaces may run on different streams at
- * the same time.  m3pc_amd/planner.py (plan_async) is the reference user: candidate passes back to back
+ * the same time.  ABI v5: there are TWO policy workspaces and TWO re-score workspaces, picked by the parity of the step slot
+ * (slot & 1): the policy passes / re-scores of two steps whose slots differ in parity may run on two streams at the same time.  m3pc_amd/planner.py (plan_async) is the reference user: candidate passes back to back
  * on the caller's stream, the policy passes and the re-scores of the neighbouring steps on two more.
  */
 #ifndef M3PC_HIP_H
@@ -41,6 +42,10 @@
 extern "C" {
 #endif
 
+/* ABI history.  v5 (round 5): m3pc_topk_race_window, m3pc_rescore_merge_race, m3pc_merge_race_select (the certified multinomial
+ * draw of the bf16 plan step); M3PC_PLAN_PRUNED_POLICY; m3pc_profile_enable(h, 3); the handle holds two chain workspaces per kind,
+ * picked by the parity of m3pc_plan_args::slot.  v4: m3pc_goal_step_batch, m3pc_dims::max_goal_batch.  v3: M3PC_PLAN_DEFER_JOIN,
+ * m3pc_candidate_join.  No structure changed layout in v5. */
 #define M3PC_ABI_VERSION 5
 
 #define M3PC_OK 0
