@@ -159,3 +159,27 @@ def test_bf16_sample_index_is_the_fp32_planners(env, guidance, tau, N, T, H):
         assert torch.equal(sab, saf)
     pb.handle.close()
     pf.handle.close()
+
+
+def test_noise_adding_lambda_in_bf16_returns_the_fp32_planners_actions():
+    """noise_adding_lambda (learner.py:142-208: mean + 0.09 randn candidates, critic scoring, temperature 1) through the certified
+    bf16 step: both planners draw the same variates from equally seeded generators; arg-max, multinomial index and both returned
+    actions equal the fp32 planner's."""
+    dims = synth.Dims(17, 6, 16)
+    qsd, om, os_ = synth.make_critic(dims, 0)
+    mk = lambda prec: HipPlanner(_cfg(16, 512, 8, 1.0, "noise_adding_lambda"), synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0),
+                                 qsd, om, os_, precision=prec, generator=torch.Generator(device="cuda").manual_seed(17))
+    pb, pf = mk("bf16"), mk("fp32")
+    for t in range(6):
+        hist = synth.make_history(dims, t)
+        hist["path_length"] = [300, 12, 640, 997, 55, 4][t]
+        for ev in (True, False):
+            ab = pb.action_sample(hist, plan=True, eval=ev, rtg=3.0)
+            af = pf.action_sample(hist, plan=True, eval=ev, rtg=3.0)
+            assert torch.equal(pb.last["argmax"], pf.last["argmax"]) and torch.equal(pb.last["sample_idx"], pf.last["sample_idx"]), (t, ev)
+            if ev:
+                assert float((ab - af).abs().max()) <= 2e-2
+            else:
+                assert torch.equal(ab, af)
+    pb.handle.close()
+    pf.handle.close()
