@@ -258,6 +258,38 @@ __global__ __launch_bounds__(256) void topk_rank_blocks2_kernel(TopSrc s0, TopSr
     }
 }
 
+// The same two rankings for 2048 < n <= 16384 (config 3's 4096 candidates, the gathered scores of a candidate-sharded config 4):
+// the keys of ALL n elements in dynamic LDS (8 n bytes: 32 KB at 4096, 128 KB at 16384), 64 elements per block ranked by 256
+// threads, a quarter of the keys each.  One launch of ~10-20 us where the selection kernel needs k rounds of butterflies in a
+// single workgroup (~60 us for the 32 racers) and the 129 best by score a whole bitonic sort.
+__global__ __launch_bounds__(256) void topk_rank_blocks2_dyn_kernel(TopSrc s0, TopSrc s1, int n, int n4) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long dkeys[];  // 4 * n4 entries
+    __shared__ int part[4][64];
+    const TopSrc s = blockIdx.y ? s1 : s0;
+    const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+    for (int e = tid; e < 4 * n4; e += 256) dkeys[e] = e < n ? ((unsigned long long)orderable(src_value(s, e)) << 32) | (unsigned int)(~e) : 0ull;
+    __syncthreads();
+    const int e = blockIdx.x * 64 + lane;
+    const unsigned long long mine = e < n ? dkeys[e] : 0ull;
+    int rank = 0;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const int j0 = q * n4, j1 = j0 + n4;
+#pragma unroll 8
+    for (int j = j0; j < j1; j += 2) {
+        const u64x2 kj = *(const u64x2*)&dkeys[j];
+        rank += (kj.x > mine) + (kj.y > mine);
+    }
+    part[q][lane] = rank;
+    __syncthreads();
+    if (q == 0 && e < n) {
+        rank = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+        if (rank < s.k) {
+            s.out[rank * s.out_stride] = e;
+            if (s.scores_out) s.scores_out[rank * s.out_stride] = s.v[e];
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void topk_rank_kernel(const float* v, int n, int k, int* idx_out) {
     __shared__ __attribute__((aligned(16))) unsigned long long keys[2048];
     const int tid = threadIdx.x;
@@ -320,15 +352,31 @@ void launch_topk(const float* v, int n, int k, int* idx_out, hipStream_t st) {
 bool launch_topk_race(const float* v, const float* expo, float tau, int n, int kk, int rr, int rmax, int* list, float* list_scores,
                       hipStream_t st) {
     if (n <= 0 || kk <= 0) return true;
-    const bool one = n <= 2048;  // rank by counting: every element knows its value and its rank -- the scores go out with the ids
+    const bool one = n <= 16384;  // rank by counting: every element knows its value and its rank -- the scores go out with the ids
     const TopSrc s0{v, nullptr, 0.f, kk, list + rmax, 1, one && list_scores ? list_scores + rmax : nullptr};
     const TopSrc s1{v, expo, tau, rr, list + rmax - 1, -1, one && list_scores ? list_scores + rmax - 1 : nullptr};
-    if (one) {
+    if (n <= 2048) {
         hipLaunchKernelGGL(topk_rank_blocks2_kernel, dim3((n + 63) / 64, rr > 0 ? 2 : 1), dim3(256), 0, st, s0, s1, n);
         return true;  // (list_scores written)
     }
+    if (one) {  // n <= 16384: the keys in dynamic LDS
+        const int n4 = (((n + 3) / 4) + 1) & ~1;
+        const size_t lds = (size_t)4 * n4 * sizeof(unsigned long long);
+        static bool attr[64] = {};  // (> 64 KiB of dynamic LDS is a per-device opt-in)
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !attr[dev]) {
+            attr[dev] = hipFuncSetAttribute((const void*)topk_rank_blocks2_dyn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024) == hipSuccess;
+        }
+        if (dev >= 0 && dev < 64 && attr[dev]) {
+            hipLaunchKernelGGL(topk_rank_blocks2_dyn_kernel, dim3((n + 63) / 64, rr > 0 ? 2 : 1), dim3(256), lds, st, s0, s1, n, n4);
+            return true;
+        }
+    }
+    // (the opt-in was refused: the selection kernels, no scores)
+    const TopSrc t1{v, expo, tau, rr, list + rmax - 1, -1, nullptr};
     launch_topk(v, n, kk, list + rmax, st);
-    if (rr > 0) hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(1024), 0, st, s1, n);  // (rr <= 64, n <= 16384)
+    if (rr > 0) hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(1024), 0, st, t1, n);  // (rr <= 64, n <= 16384)
     return false;     // (the caller still has to gather list_scores: launch_window_stats)
 }
 
