@@ -333,7 +333,9 @@ int m3pc_topk_window(m3pc_handle* h, const float* expect_return, int n_total, in
  *   certifies arg-max(merged) = the fp32 arg-max; otherwise re-score entries n .. need-1 of the order and merge again
  *   (need can only shrink).
  *   stats device out float[4] = {c, max_i |top_scores[i] - top_rescored[i] - c|, need, threshold - best un-listed score};
- *   host_stats / seq as for m3pc_topk_window.  `merged` may alias `scores`. */
+ *   host_stats / seq as for m3pc_topk_window, except that host_stats must hold 8 floats here: slots 5..7 are written as zeros,
+ *   so that a reader of the 8-float layout of m3pc_rescore_merge_race never sees an earlier race merge's values on the same
+ *   buffer.  `merged` may alias `scores`. */
 int m3pc_rescore_merge(m3pc_handle* h, const float* scores, int n_total, const int* index, int n, const float* top_scores,
                        const float* top_rescored, float delta, float* merged, float* stats, float* host_stats, float seq,
                        void* stream);

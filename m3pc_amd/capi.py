@@ -444,9 +444,11 @@ class Handle:
         return dict(loc=loc, std=std, sample_actions=acts, expect_return=er, window_index=widx)
 
     def score_actions(self, mode: int, states, actions, rewards, cand: torch.Tensor, window_index: Optional[torch.Tensor],
-                      horizon: int, lmbda: float, discount: float, precision: int = PREC_FP32, want_debug: bool = False):
+                      horizon: int, lmbda: float, discount: float, precision: int = PREC_FP32, want_debug: bool = False,
+                      slot: int = 0):
         """TD(lambda) scores of caller-supplied candidates cand (n,h,A); states/actions/rewards (E,T,.) or (T,.) windows,
-        window_index (n,) int32 (None: one window)."""
+        window_index (n,) int32 (None: one window).  slot: whose returns tokens (and, for few-row fp32 calls, which of the two
+        chain workspaces: slot & 1) the pass uses."""
         dev = self.device
         n = cand.shape[0]
         ins = [self._f32(t) for t in (states, actions, rewards, cand)]
@@ -455,7 +457,7 @@ class Handle:
         pr = torch.empty((n, horizon), dtype=torch.float32, device=dev) if want_debug else None
         pb = torch.empty((n, horizon), dtype=torch.float32, device=dev) if want_debug else None
         wi = None if window_index is None else window_index.to(torch.int32).contiguous()
-        args = self._args(mode, precision, horizon, n, 0, n, lmbda, discount, 0.0)
+        args = self._args(mode, precision, horizon, n, 0, n, lmbda, discount, 0.0, slot)
         check(self.lib.m3pc_score_actions(self._h, C.byref(args), E, _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), _ptr(ins[3]),
                                           _ptr(wi), _ptr(er), _ptr(pr), _ptr(pb), _stream(dev)))
         return (er, pr, pb) if want_debug else er

@@ -175,7 +175,13 @@ def resolve(planner, N, kmax, rmax, n_done, r_done, delta, ops):
         if everything or n_done >= N:
             break
         if not redo:
-            if need > n_done and not saturated:
+            if need > n_done and saturated:
+                # the window set was re-scored and its certificate STILL asks for more (the median shift is taken over the new
+                # list, so the threshold moves): nothing short of every candidate in fp32 settles it
+                n_done = ops.window_set(N, delta, everything=True)
+                everything = True
+                continue
+            if need > n_done:
                 if need <= kmax:
                     ops.extend(n_done, need)
                     n_done = need
@@ -207,5 +213,8 @@ def resolve(planner, N, kmax, rmax, n_done, r_done, delta, ops):
         if not redo:
             break
         ops.merge_select(n_done, r_done, delta)
+    # certified: the loop ended on satisfied certificates (or on fp32 scores for every candidate) -- it cannot end otherwise,
+    # the record says so for callers and tests
+    certified = bool(everything or n_done >= N or (need <= n_done and need_race <= r_done))
     return dict(n_rescored=n_done, n_in_window=first_need, min_margin_outside=float(margin), delta=delta, saturated=saturated,
-                shift=shift, deviation=dev, n_race=r_done, need_race=first_race)
+                shift=shift, deviation=dev, n_race=r_done, need_race=first_race, certified=certified)

@@ -303,7 +303,15 @@ __global__ __launch_bounds__(1024) void head_f32_fused_kernel(HeadFusedP hp) {
     // the last workgroup of this row tile adds the N / 32 partial sums of each of its rows, in tile order.  Ordering without a
     // device-scope fence (an agent-scope release fence writes the XCD's whole L2 back: measured 350 us per launch with
     // __threadfence() here): the partial sums are agent-scope atomic stores, every wave waits for its own to be acknowledged
-    // (vmcnt), the workgroup barrier orders them before the ticket, and the reader uses agent-scope atomic loads
+    // (vmcnt), the workgroup barrier orders them before the ticket, and the reader uses agent-scope atomic loads.
+    // What this rests on is the gfx950 ISA, not the HIP memory model: (1) an agent-scope atomic store is emitted as a
+    // write-through store with sc1 set -- it bypasses / writes through the issuing XCD's non-coherent L2 to the memory-side
+    // cache every XCD shares; (2) vmcnt counts a store down when that write is acknowledged, so after `s_waitcnt vmcnt(0)` +
+    // s_barrier every partial sum of this workgroup is visible chip-wide before thread 0's ticket RMW (an L2-bypassing atomic
+    // executed at the same memory-side point) is issued; (3) the last workgroup's agent-scope atomic loads (sc1) miss its own
+    // L2 by construction.  No other data is handed over.  tests/test_rescore_gpu.py::test_fused_heads_ticket_stress holds the
+    // launch to the un-fused chain bit for bit over thousands of launches on two streams; the pass zeroes the tickets again
+    // whenever it ends in an error (m3pc_passes.hip:pruned_decoder), so a failed launch cannot leave a count behind.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {

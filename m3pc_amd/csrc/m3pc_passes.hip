@@ -935,7 +935,10 @@ int pruned_decoder(m3pc_handle* h, Plan* pl, Plan::Query& q, SharedTables& tb, i
         CHK(run_head(h, q.qkeys[s], Y1, xm, n * hh, h->pred[s], h->feat[q.qkeys[s]], true, dt, st));
     }
     }
-    return check_launch("pruned_decoder");
+    const int rc = check_launch("pruned_decoder");
+    if (rc != 0 && h->cur && h->cur->head_ticket)  // (an error behind the fused heads' launch: no count may survive in its tickets)
+        (void)hipMemsetAsync(h->cur->head_ticket, 0, (size_t)2 * ((h->cur->head_rows + 31) / 32) * sizeof(int), st);
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------- candidate pass

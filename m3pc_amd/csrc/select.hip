@@ -1,6 +1,7 @@
 // The cross-candidate tail of a plan step (learner.py:318-325) and the top-k used by the fp32 re-score.
 // Everything here is one workgroup: N <= 16384 scores live in registers / LDS, reductions are 64-lane
 // shuffles + one LDS hop.
+#include <atomic>
 #include <stdlib.h>
 
 #include "kernels.h"
@@ -362,13 +363,23 @@ bool launch_topk_race(const float* v, const float* expo, float tau, int n, int k
     if (one) {  // n <= 16384: the keys in dynamic LDS
         const int n4 = (((n + 3) / 4) + 1) & ~1;
         const size_t lds = (size_t)4 * n4 * sizeof(unsigned long long);
-        static bool attr[64] = {};  // (> 64 KiB of dynamic LDS is a per-device opt-in)
+        // > 64 KiB of dynamic LDS is a per-device opt-in, asked for ONCE per device and only when the launch needs it (n > 8192);
+        // a refusal is remembered and its error cleared, so that the fallback below is not reported as a failed launch by the
+        // caller's hipGetLastError (the same pattern as lds_opt_in in attn_bf16.hip)
+        static std::atomic<int> state[64] = {};  // 0: not asked, 1: granted, 2: refused
         int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev >= 0 && dev < 64 && !attr[dev]) {
-            attr[dev] = hipFuncSetAttribute((const void*)topk_rank_blocks2_dyn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024) == hipSuccess;
+        const bool dev_ok = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+        bool fits = lds <= 64 * 1024;
+        if (!fits && dev_ok) {
+            int stt = state[dev].load(std::memory_order_acquire);
+            if (stt == 0) {
+                stt = hipFuncSetAttribute((const void*)topk_rank_blocks2_dyn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024) == hipSuccess ? 1 : 2;
+                if (stt == 2) (void)hipGetLastError();
+                state[dev].store(stt, std::memory_order_release);
+            }
+            fits = stt == 1;
         }
-        if (dev >= 0 && dev < 64 && attr[dev]) {
+        if (fits) {
             hipLaunchKernelGGL(topk_rank_blocks2_dyn_kernel, dim3((n + 63) / 64, rr > 0 ? 2 : 1), dim3(256), lds, st, s0, s1, n, n4);
             return true;
         }
@@ -527,8 +538,10 @@ __device__ __forceinline__ void rescore_merge_body(const float* b, int n_total, 
         const float st8[8] = {c, devmax, (float)need, margin, 0.f, (float)need_r, kbest, thr_r};
         for (int i = 0; i < nstats; ++i) stats[i] = st8[i];
         if (host_stats) {
-            for (int i = 0; i < nstats; ++i)
-                if (i != 4) host_stats[i] = st8[i];
+            // all 8 host slots on every merge: a four-statistics merge (no race list) leaves zeros at 5..7 instead of the
+            // previous race merge's need_race / K* / threshold on the same slot
+            for (int i = 0; i < 8; ++i)
+                if (i != 4) host_stats[i] = i < nstats ? st8[i] : 0.f;
             __threadfence_system();
             __hip_atomic_store(host_stats + 4, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }

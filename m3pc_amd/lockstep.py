@@ -80,7 +80,7 @@ class LockstepMixin:
                     # The certified re-score of certificate.py, for all windows of the group at once: the kmin best candidates
                     # by score and the rfirst best by race key of every window in ONE fp32 pass, merge + select enqueued for
                     # every window, THEN one host read of the certificates; windows that ask for more get passes of their own.
-                    kmax = max(min(self.rescore_max, N - 1 if N > 1 else 1), 1)
+                    kmax = max(min(self.rescore_max, N - 1 if N > 1 else 1, 1024 - self._R - 1), 1)  # (merge kernels: r + n <= 1024)
                     rfirst = max(min(self.race_min, R), 1) if R > 0 else 0
                     kmin = max(min(self.rescore_min - rfirst, N, kmax), 1)  # (the race entries share the floor of the first pass)
                     lsts, blst = [], []

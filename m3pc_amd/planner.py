@@ -260,7 +260,13 @@ class HipPlanner(GoalMixin, LockstepMixin):
         for tk in [sl.owner for sl in getattr(self, "_slots", []) if sl.owner is not None]:
             self._finish(tk)  # steps in flight were issued against the old weights: resolve them first
         self.handle.load_weights(state_dict)
-        self._delta0 = getattr(self, "_delta_fixed", None)  # the bf16 error bound belongs to the weights: re-calibrate
+        self._reset_calibration()
+
+    def _reset_calibration(self):
+        """The bf16 error bound delta belongs to the weights it was measured on -- the model's AND, under critic guidance, the Q
+        networks' (the deviation contains min(q1, q2) evaluated on bf16-decoded states, learner.py:250-252, and fine-tuning
+        updates them between rollouts, finetune.py:288-290): the next steps run the full-pass calibrations again."""
+        self._delta0 = getattr(self, "_delta_fixed", None)
         self._cal_left = getattr(self, "_cal_windows", 3)
         self._hist = {}
         self.delta_grown = 0
@@ -297,7 +303,12 @@ class HipPlanner(GoalMixin, LockstepMixin):
         return grow, max(total - rfirst, 1), rfirst
 
     def load_critic(self, q_state_dict, obs_mean, obs_std):
+        """TwinQ weights + observation statistics (model.py:157-161).  Steps in flight were issued against the old Q networks:
+        they are resolved first; the calibrated bound of the certified re-score is reset like after a model weight load."""
+        for tk in [sl.owner for sl in getattr(self, "_slots", []) if sl.owner is not None]:
+            self._finish(tk)
         self.handle.set_critic(q_state_dict, obs_mean, obs_std)
+        self._reset_calibration()
 
     # ---------------------------------------------------------------------------------------- window
     def _blocks(self, flat):
@@ -528,7 +539,8 @@ class HipPlanner(GoalMixin, LockstepMixin):
                         self._cal_left -= 1
                         d = self._calibrate(tk)
                         self._delta0 = d if self._delta0 is None else max(self._delta0, d)
-                    kmax = max(min(self.rescore_max, N - 1 if N > 1 else 1), 1)
+                    # (the merge kernels list r + n <= 1024 entries: a larger rescore_max takes the window-set path instead)
+                    kmax = max(min(self.rescore_max, N - 1 if N > 1 else 1, 1024 - self._R - 1), 1)
                     kmin = max(min(tk.kfirst_in, N, kmax), 1)
                     tk.delta = max(self._delta0, tk.grow_in)
                 else:

@@ -116,6 +116,30 @@ def make_state_dict(dims: Dims, seed: int = 0) -> Dict[str, torch.Tensor]:
     return sd
 
 
+def trained_like(sd: Dict[str, torch.Tensor], stats, seed: int = 0, linear_scale: float = 2.0, gain_lo: float = 0.5,
+                 gain_hi: float = 2.0, returns_std_scale: float = 1.0):
+    """A perturbation family of the recipe above that moves it towards what training does to a model (the
+    certificate's statistics -- the bf16 deviation delta against the score spread sigma -- are properties of the weight
+    distribution they were measured on): every Linear weight x ``linear_scale`` (larger pre-activations: sharper attention,
+    more gelu curvature, a wider range in front of the x 1000 returns term of learner.py:305), every LayerNorm gain drawn
+    from U(gain_lo, gain_hi) per feature, the returns tokenizer's std x ``returns_std_scale`` (the scale of the decoded
+    return-to-go).  Returns (state_dict, stats) copies; the inputs are left alone."""
+    out = {}
+    for name, w in sd.items():
+        if name == "pos_embed":
+            out[name] = w
+        elif w.dim() == 2 and (name.endswith(".weight") or name.endswith("in_proj_weight")):
+            out[name] = w * float(linear_scale)
+        elif w.dim() == 1 and name.endswith(".weight") and (".norm" in name or name.endswith(".0.weight")):
+            u = torch.rand(w.shape, generator=_gen("trained_like." + name, seed), dtype=torch.float32)
+            out[name] = (gain_lo + (gain_hi - gain_lo) * u).to(torch.float32)
+        else:
+            out[name] = w
+    st = {k: {f: np.array(v, copy=True) for f, v in d.items()} for k, d in stats.items()}
+    st["returns"]["std"] = (st["returns"]["std"] * np.float32(returns_std_scale)).astype(np.float32)
+    return out, st
+
+
 def make_tokenizer_stats(dims: Dims, seed: int = 0) -> Dict[str, Dict[str, np.ndarray]]:
     """Per-key mean/std/min/max as float32 arrays (SURVEY 8d recipe)."""
     stats = {}

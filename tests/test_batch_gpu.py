@@ -248,9 +248,12 @@ def test_c3_planner_bf16_rescore_keeps_reference_argmax():
     assert int(g["argmax"]) in p.last["topk"].cpu().numpy()
     assert np.abs(ev.cpu().numpy() - g["eval_action"]).max() < 2e-2
     # the SAMPLED action (learner.py:324-325) in bf16: the certified race reproduces the reference's index
-    if int(torch.argmax(torch.from_numpy(g["p"].reshape(-1)) / q)) == int(g["sample_idx"].reshape(-1)[0]):
-        assert int(p.last["sample_idx"].item()) == int(g["sample_idx"].reshape(-1)[0])
-        assert np.abs(p.last["sample_action"].cpu().numpy().reshape(-1) - g["sample_action"].reshape(-1)).max() < 2e-5
+    # (first the replay itself: the stored index IS argmax(p / q) of the stored p and the seed's variates -- a fixture regenerated
+    # under a torch whose multinomial draws differently fails here instead of silently switching the check off)
+    assert int(torch.argmax(torch.from_numpy(g["p"].reshape(-1)) / q)) == int(g["sample_idx"].reshape(-1)[0])
+    assert int(p.last["sample_idx"].item()) == int(g["sample_idx"].reshape(-1)[0])
+    assert np.abs(p.last["sample_action"].cpu().numpy().reshape(-1) - g["sample_action"].reshape(-1)).max() < 2e-5
+    assert p.last["certified"]
     p.handle.close()
 
 

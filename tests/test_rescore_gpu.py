@@ -213,3 +213,46 @@ def test_non_constant_returns_rows_are_planned_as_the_reference_does(dtype):
     p.rtg_guiding(const, h)
     assert float((p.last["expect_return"].cpu() - ref["expect_return"]).abs().max()) > 1e-3 * scale  # the row mattered
     p.handle.close()
+
+
+def test_fused_heads_ticket_stress():
+    """head_f32_fused_kernel (gemm_f32_direct.hip) hands each row tile's partial sums to the LAST of its 16 workgroups through
+    an atomic ticket that resets itself, with agent-scope atomic stores / loads and no fence.  Stress: ~1500 few-row
+    fp32 scoring passes of random sizes (8 .. 4096 head rows, two heads) alternating between the two chain workspaces on two
+    streams that run concurrently; every result must equal, bit for bit, the one the same call produced on an idle device."""
+    dims = synth.Dims(11, 3, 32)
+    H, CAP = 16, 256  # 256 candidates x 16 scored steps = 4096 rows per head
+    hd = capi.Handle(dims.state_dim, dims.action_dim, dims.traj_length, max_candidates=CAP, max_batch=1, max_rescore=CAP)
+    hd.load_weights(synth.make_state_dict(dims, 0))
+    st = synth.make_tokenizer_stats(dims, 0)
+    for k, name in enumerate(synth.KEYS):
+        hd.set_tokenizer(k, st[name]["mean"], st[name]["std"], normalize=(name != "actions"))
+    hist = synth.make_history(dims, 0)
+    s = torch.from_numpy(hist["observations"][100:132]).cuda()
+    a = torch.from_numpy(hist["actions"][100:132]).cuda()
+    r = torch.from_numpy(hist["rewards"][100:132]).cuda()
+    for slot in (0, 1):  # the returns tokens of both slots (PASS 1 leaves them there)
+        hd.policy_pass(capi.MODE_RTG, s, a, r, H, 3.0 + slot, slot=slot)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    cand = torch.rand((CAP, H, dims.action_dim), device="cuda", generator=g) * 2 - 1
+    sizes = [1, 2, 3, 8, 17, 31, 64, 100, 129, 200, 255, 256]
+    ref = {}
+    for slot in (0, 1):
+        for n in sizes:
+            ref[(slot, n)] = hd.score_actions(capi.MODE_RTG, s, a, r, cand[:n], None, H, 0.6, 0.99, slot=slot).clone()
+            torch.cuda.synchronize()
+    assert all(torch.isfinite(v).all() for v in ref.values())
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    rng = np.random.default_rng(3)
+    got = []
+    for it in range(1500):
+        slot = it & 1
+        n = int(rng.choice(sizes))
+        with torch.cuda.stream(streams[slot]):
+            got.append((slot, n, hd.score_actions(capi.MODE_RTG, s, a, r, cand[:n], None, H, 0.6, 0.99, slot=slot)))
+        if it % 250 == 249:
+            torch.cuda.synchronize()
+            bad = [(sl, n) for sl, n, v in got if not torch.equal(v, ref[(sl, n)])]
+            assert not bad, bad[:8]
+            got = []
+    hd.close()
