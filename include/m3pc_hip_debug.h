@@ -32,7 +32,8 @@ int m3pc_debug_block_fused(const void* O, int M, const float* res, const float* 
 int m3pc_debug_block_fused_qkv(const void* O, int M, const float* res, const void* Wo, const void* W1, const void* W2, const void* Wqkv,
                                void* stream_buf, const float* bo, const float* b1, const float* b2, const float* ln2_g,
                                const float* ln2_b, const float* lnA_g, const float* lnA_b, const float* bqkv, float* Xout, void* QKV,
-                               void* stream, long long* stamps);
+                               void* stream, long long* stamps, int x_bf16);  /* x_bf16: res / Xout are (M, 512) bf16 rows (round 6);
+                                                                                 m3pc_debug_block_fused: bit 16 of `variant` */
 /* the decoder form with the two scalar output heads inside the tail (see csrc/m3pc.hip for the argument layout) */
 int m3pc_debug_block_fused_heads(const void* O, int M, const float* rowtab, int rt_mod, const void* Wo, const void* W1, const void* W2,
                                  const void* Wh, void* stream_buf, const float* bo, const float* b1, const float* b2, const float* ln2_g,

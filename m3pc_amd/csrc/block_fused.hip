@@ -217,9 +217,13 @@ __device__ __forceinline__ void acc_touch(f32x16 (&c)[16]) {
 // 4 = VALU slice in a region of its own behind its MFMA, 5 = gelu of every second value only, 6 = no s_barrier in the
 // per-stage sync, 7 = weight fragments read once (no LDS reads in the loops).  2, 5, 6, 7 compute wrong results.  p.stamps: phase stamps (shader clocks) of one workgroup
 // TAIL: what follows the FFN in the stream -- 1: the next layer's in_proj rows (p.QKVout), 2: the two scalar output heads (p.head_out)
-template <int DBG, int TAIL>
+// XB (round 6): the residual rows p.res and the output rows p.Xout are bf16 (BlockP::x_bf16).  A 128-byte line then holds the 64
+// features of TWO feature tiles, so the residual arrives and X'' leaves a tile PAIR at a time: half the LDS-DMA pieces, half the
+// stores, half the bytes of both HBM bursts of a tile; everything between (X' in the accumulators, both LayerNorms) stays fp32.
+template <int DBG, int TAIL, int XB = 0>
 __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     constexpr bool QKV = TAIL == 1, HEADS = TAIL == 2, SPLIT = TAIL == 3;
+    static_assert(!XB || TAIL == 0 || TAIL == 1, "bf16 residual rows: the plain and the next-Q|K|V forms only");
     // SPLIT (few tiles: a launch would leave most CUs idle for a whole tile): blockIdx.y = which quarter of the FFN's hidden
     // chunks this workgroup takes; every quarter repeats the out-proj and LayerNorm-2 (11 % of a tile), adds its share of
     // FFN2 to zero (quarter 0: to X' + b2) and stores the fp32 partial to its slab; block_split_reduce sums the slabs in order
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
             } else {
                 rowoff = (size_t)rs * p.ldr;
             }
-            rsrc[pp] = (unsigned)((rowoff + 4 * (cc ^ rr8)) * 4);
+            rsrc[pp] = XB ? (unsigned)(rowoff * 2 + 16 * (cc ^ rr8)) : (unsigned)((rowoff + 4 * (cc ^ rr8)) * 4);
         }
     }
     char* const rstage = smem + ACT_OFF + wu * ACT_LDS * 1024;
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     // full vmcnt(0), which would drain the weight stream every phase)
     const __amdgpu_buffer_rsrc_t r_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.rowtab ? p.rowtab : p.res), 0, 0xfffffff0u, 0x00020000);
     (void)r_rs;
-    auto rdma = [&](int t) {  // residual values of feature tile t -> buffer t & 1
+    auto rdma = [&](int t) {  // residual values of feature tile t (XB: of the tile pair 2 t, 2 t + 1: 128 bytes of bf16) -> buffer t & 1
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp)
@@ -431,7 +435,17 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     auto acc_init = [&](int jn) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 x = *(const f32x4 __attribute__((address_space(3)))*)(rback + (jn & 1) * 4096 + (((2 * q + lh) ^ (l31 & 7)) << 4));
+            f32x4 x;
+            if constexpr (XB) {  // features 32 jn + 8 q + 4 lh .. of the pair's line: chunk 4 (jn & 1) + q, its half lh
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 v = *(const u32x2 __attribute__((address_space(3)))*)(rback + ((jn >> 1) & 1) * 4096 + (((4 * (jn & 1) + q) ^ (l31 & 7)) << 4) + 8 * lh);
+                x[0] = __builtin_bit_cast(float, v[0] << 16);
+                x[1] = __builtin_bit_cast(float, v[0] & 0xffff0000u);
+                x[2] = __builtin_bit_cast(float, v[1] << 16);
+                x[3] = __builtin_bit_cast(float, v[1] & 0xffff0000u);
+            } else {
+                x = *(const f32x4 __attribute__((address_space(3)))*)(rback + (jn & 1) * 4096 + (((2 * q + lh) ^ (l31 & 7)) << 4));
+            }
             const f32x4 b = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_BO + 32 * jn + 8 * q);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[jn][4 * q + i] = x[i] + b[i];
@@ -444,16 +458,27 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     // At the sync of phase jn the operations issued behind stage (jn + 1)'s last piece are one weight piece, these 4 and the
     // phase's first 6 pieces: vmcnt(11).  In front of acc_init(jn) the operations behind tile jn's pieces are 8 weight pieces,
     // the 4 of tile jn + 1 and 8 more weight pieces: vmcnt(20) (16 behind the last tile's).  Wave-private data: no barrier.
-#define OUTPROJ(jn, SL, NR, WAIT)                                                                                            \
-    asm volatile("s_waitcnt vmcnt(" #WAIT ")" ::: "memory");                                                                 \
+    // XB: the prologue brought the pairs 0, 1 (tiles 0..3); pair P + 2 is sent for when phase 2 P + 1 starts -- right behind
+    // acc_init(2 P + 1), the last reader of its buffer -- and has three phases to land.  Behind the pieces of pair P (P >= 2) and in
+    // front of acc_init(2 P): three phases of 8 weight pieces + the 4 of pair P + 1: vmcnt(28) (24 behind the last pair's).
+#define OUTPROJ(jn, SL, NR, WAIT, RD)                                                                                        \
+    if ((WAIT) < 63) asm volatile("s_waitcnt vmcnt(" #WAIT ")" ::: "memory");                                                \
     acc_init(jn);                                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                                       \
-    if ((jn) + 2 < NT) rdma((jn) + 2);                                                                                       \
+    if ((RD) >= 0) rdma(RD);                                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                                       \
     phase_n(jn, SL{}, std::integral_constant<int, NR>{}, no_extra, [&](int i, u32x4 a, int) { mfma_a(acc[jn], a, ofr[i]); }, no_valu);
-    OUTPROJ(0, S0, 4, 0) OUTPROJ(1, S1, 4, 20) OUTPROJ(2, S2, 4, 20) OUTPROJ(3, S0, 4, 20) OUTPROJ(4, S1, 4, 20) OUTPROJ(5, S2, 4, 20)
-    OUTPROJ(6, S0, 4, 20) OUTPROJ(7, S1, 4, 20) OUTPROJ(8, S2, 4, 20) OUTPROJ(9, S0, 4, 20) OUTPROJ(10, S1, 4, 20) OUTPROJ(11, S2, 4, 20)
-    OUTPROJ(12, S0, 4, 20) OUTPROJ(13, S1, 4, 20) OUTPROJ(14, S2, 0, 20) OUTPROJ(15, S0, 0, 16)
+    if constexpr (XB) {
+        OUTPROJ(0, S0, 0, 63, -1) OUTPROJ(1, S1, 4, 63, 2) OUTPROJ(2, S2, 0, 63, -1) OUTPROJ(3, S0, 4, 63, 3)
+        OUTPROJ(4, S1, 0, 28, -1) OUTPROJ(5, S2, 4, 63, 4) OUTPROJ(6, S0, 0, 28, -1) OUTPROJ(7, S1, 4, 63, 5)
+        OUTPROJ(8, S2, 0, 28, -1) OUTPROJ(9, S0, 4, 63, 6) OUTPROJ(10, S1, 0, 28, -1) OUTPROJ(11, S2, 4, 63, 7)
+        OUTPROJ(12, S0, 0, 28, -1) OUTPROJ(13, S1, 0, 63, -1) OUTPROJ(14, S2, 0, 24, -1) OUTPROJ(15, S0, 0, 63, -1)
+    } else {
+        OUTPROJ(0, S0, 4, 0, 2) OUTPROJ(1, S1, 4, 20, 3) OUTPROJ(2, S2, 4, 20, 4) OUTPROJ(3, S0, 4, 20, 5) OUTPROJ(4, S1, 4, 20, 6)
+        OUTPROJ(5, S2, 4, 20, 7) OUTPROJ(6, S0, 4, 20, 8) OUTPROJ(7, S1, 4, 20, 9) OUTPROJ(8, S2, 4, 20, 10) OUTPROJ(9, S0, 4, 20, 11)
+        OUTPROJ(10, S1, 4, 20, 12) OUTPROJ(11, S2, 4, 20, 13) OUTPROJ(12, S0, 4, 20, 14) OUTPROJ(13, S1, 4, 20, 15)
+        OUTPROJ(14, S2, 0, 20, -1) OUTPROJ(15, S0, 0, 16, -1)
+    }
 #undef OUTPROJ
     mfma_done_a(acc);  // (the accumulators are next read by v_accvgpr_read)
     stamps[2] = __builtin_readcyclecounter();
@@ -665,14 +690,15 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
         // instruction touched 32 lines for 1 KiB -- 8192 line touches per wave, which is what the X'' store took (23 k clocks
         // per tile, the texture path's one line per clock; staged: 512).  Same swizzle as the residual tiles' way in.
         const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)p.Xout, 0, (unsigned)((unsigned long long)(SPLIT ? SPLIT_N : 1) * p.M * p.ldx * 4), 0x00020000);
+            (void*)p.Xout, 0, (unsigned)((unsigned long long)(SPLIT ? SPLIT_N : 1) * p.M * p.ldx * (XB ? 2 : 4)), 0x00020000);
         (void)x_rs;
         const int r8 = lane >> 3, cc = lane & 7;
         unsigned xoff[4];
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
             const int rr = row0 + 32 * wu + 8 * pp + r8;
-            xoff[pp] = rr < p.M ? (unsigned)(((SPLIT ? (size_t)blockIdx.y * p.M : 0) + (size_t)rr) * p.ldx * 4 + ((cc ^ r8) << 4)) : 0x80000000u;
+            if constexpr (XB) xoff[pp] = rr < p.M ? (unsigned)rr * (unsigned)(p.ldx * 2) + (unsigned)((cc ^ r8) << 4) : 0x80000000u;
+            else xoff[pp] = rr < p.M ? (unsigned)(((SPLIT ? (size_t)blockIdx.y * p.M : 0) + (size_t)rr) * p.ldx * 4 + ((cc ^ r8) << 4)) : 0x80000000u;
         }
         typedef char __attribute__((address_space(3))) * lds_c_t;
         lds_c_t xwr = (lds_c_t)(rstage + l31 * 128);
@@ -680,6 +706,33 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
         asm volatile("" : "+v"(xwr), "+v"(xrd));
         u32x4 xs[2][4];
 #if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (XB) {
+            // bf16 rows: the staging buffer holds a tile PAIR (32 rows x 128 B = 64 features); tile jn's quarter q is chunk
+            // 4 (jn & 1) + q of its row's line, half lh of it; a finished pair leaves as four 1-KiB stores of 8 rows x one line
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) {
+                const int P = jn >> 1;
+                // (the conversion reads VGPRs -- unlike the fp32 rows' ds_write_b128, which takes the accumulator registers as they
+                // are -- and left alone hipcc copies all 256 accumulators out in front of the loop and spills around it: the copy
+                // of a tile may not move above this statement)
+                asm volatile("" : "+a"(acc[jn]));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    bf16x4 w;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) w[i] = (bf16_t)acc[jn][4 * q + i];
+                    *(u32x2 __attribute__((address_space(3)))*)(xwr + (P & 1) * 4096 + (((4 * (jn & 1) + q) ^ (l31 & 7)) << 4) + 8 * lh) = __builtin_bit_cast(u32x2, w);
+                }
+                if (jn & 1) {  // (read back and stored at once: one register set -- with two, hipcc spilled an accumulator tile around the stores)
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) xs[0][pp] = *(const u32x4 __attribute__((address_space(3)))*)(xrd + (P & 1) * 4096 + pp * 1024);
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) __builtin_amdgcn_raw_buffer_store_b128(xs[0][pp], x_rs, xoff[pp], P * 128, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int jn = 0; jn < NT; ++jn) {
 #pragma unroll
@@ -699,6 +752,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
         }
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) __builtin_amdgcn_raw_buffer_store_b128(xs[(NT - 1) & 1][pp], x_rs, xoff[pp], (NT - 1) * 128, 0);
+        }
 #endif
     }
     stamps[5] = __builtin_readcyclecounter();
@@ -1442,6 +1496,11 @@ bool block_fused_accepts(const BlockP& p) {
     if (p.split) {  // four workgroups per tile, fp32 partials to four slabs of M rows behind Xout (block_split_reduce sums them)
         if (p.Hout || p.QKVout || p.head_out[0] || !p.Xout || p.Xout == p.res || p.res_L > 0) return false;
     }
+    if (p.x_bf16) {  // bf16 residual rows in, bf16 X'' rows out: whole 128-byte lines of 64 features
+        if (p.rowtab || p.split || p.head_out[0] || p.res_L > 0 || p.variant || !p.res) return false;
+        if ((p.ldr % 8) || (unsigned long long)p.M * p.ldr * 2 >= 0xfffffff0ull) return false;
+        if (p.Xout && ((p.ldx % 8) || (unsigned long long)p.M * p.ldx * 2 >= 0x80000000ull)) return false;
+    }
     return true;
 }
 
@@ -1459,7 +1518,9 @@ bool launch_block_fused(const BlockP& p, hipStream_t st) {
     else if (p.variant == 7) hipLaunchKernelGGL((block_fused_kernel<7, 0>), grid, block, 0, st, p);
     else
 #endif
-    if (p.split) hipLaunchKernelGGL((block_fused_kernel<0, 3>), dim3((p.M + 127) / 128, SPLIT_N), block, 0, st, p);
+    if (p.x_bf16 && p.QKVout) hipLaunchKernelGGL((block_fused_kernel<0, 1, 1>), grid, block, 0, st, p);
+    else if (p.x_bf16) hipLaunchKernelGGL((block_fused_kernel<0, 0, 1>), grid, block, 0, st, p);
+    else if (p.split) hipLaunchKernelGGL((block_fused_kernel<0, 3>), dim3((p.M + 127) / 128, SPLIT_N), block, 0, st, p);
     else if (p.QKVout) hipLaunchKernelGGL((block_fused_kernel<0, 1>), grid, block, 0, st, p);
     else if (p.head_out[0]) hipLaunchKernelGGL((block_fused_kernel<0, 2>), dim3(2 * ((p.M / 2 + 127) / 128)), block, 0, st, p);
     else hipLaunchKernelGGL((block_fused_kernel<0, 0>), grid, block, 0, st, p);

@@ -166,8 +166,21 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(EmbedP p, int CB, int n
         }
         const long long row = (long long)b * p.L + j;
         if (!(indep && p.x_first_only && b > 0)) {
+            if (p.Xb) {
 #pragma unroll
-            for (int i = 0; i < NV; ++i) *(float4*)(p.X + row * d + (i * 64 + lane) * 4) = x[i];
+                for (int i = 0; i < NV; ++i) {
+                    typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+                    bf16x4_t o;
+                    o[0] = (bf16_t)x[i].x;
+                    o[1] = (bf16_t)x[i].y;
+                    o[2] = (bf16_t)x[i].z;
+                    o[3] = (bf16_t)x[i].w;
+                    *(bf16x4_t*)(p.Xb + row * d + (i * 64 + lane) * 4) = o;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) *(float4*)(p.X + row * d + (i * 64 + lane) * 4) = x[i];
+            }
         }
         if (!p.ln_g) continue;
         if (p.Hf) {

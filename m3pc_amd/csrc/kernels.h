@@ -121,6 +121,10 @@ struct BlockP {
     const float* ln2_b;
     float* Xout;            // optional; may alias res
     int ldx;
+    int x_bf16;             // round 6: res and Xout are bf16 rows (ldr / ldx in elements; res / Xout are bf16_t* behind the casts): the
+                            // residual stream crosses HBM between the encoder layers in bf16 -- half of a tile's residual bytes in,
+                            // half of its X'' bytes out (oracle/lowprec_study.py "bf16_res": delta x 0.95-1.25).  Plain and
+                            // next-Q|K|V forms only (no rowtab, no split, no heads, no shared leading rows)
     const float* lnA_g;     // LayerNorm of the block output (next block's norm1 / the stack's final norm)
     const float* lnA_b;
     const float* lnB_g[2];  // optional second LayerNorm on top (an output head's norm), per row group
@@ -269,6 +273,7 @@ struct EmbedP {
     const int2* tokmap;      // (L,) {key, t} of every kept token, encoder order
     int batch, L, d, T;
     float* X;                // (batch, L, d)
+    bf16_t* Xb;              // instead of X: the same rows rounded to bf16 (the residual stream of a pass whose layer tails take it so)
     const float* ln_g;       // optional: also emit LayerNorm(X row) (the first block's norm1) ...
     const float* ln_b;
     float* Hf;               // ... as fp32 and/or

@@ -130,6 +130,18 @@ int m3pc_create(const m3pc_dims* dims, int device, m3pc_handle** out) {
         static std::mutex shared_aux_mutex;  // (handles of different threads may be created at the same time)
         std::lock_guard<std::mutex> lock(shared_aux_mutex);
         hipStream_t& sa = shared_aux[device];
+#ifdef M3PC_LAB  // (tools/cu_mask_probe.py: the candidate passes' second stream confined to a CU mask, comma-separated hex words)
+        if (!sa)
+            if (const char* e = M3PC_ENV("M3PC_AUX_CU_MASK")) {
+                std::vector<uint32_t> words;
+                for (const char* q = e; *q;) {
+                    words.push_back((uint32_t)strtoul(q, nullptr, 16));
+                    while (*q && *q != ',') ++q;
+                    if (*q == ',') ++q;
+                }
+                HIPCHK(hipExtStreamCreateWithCUMask(&sa, (uint32_t)words.size(), words.data()));
+            }
+#endif
         if (!sa) HIPCHK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
         h->aux = sa;
     }
@@ -1323,7 +1335,8 @@ int m3pc_debug_block_fused(const void* O, int M, const float* res, const float* 
     b.out_grp = out_grp;
     b.Hout = (bf16_t*)Hout;
     b.ldh = 512;
-    b.variant = variant;
+    b.variant = variant & 15;
+    b.x_bf16 = (variant & 16) ? 1 : 0;  // (res and Xout are then (M, 512) bf16 rows)
     b.stamps = stamps;
     if (!launch_block_fused(b, st)) return fail(M3PC_EINVAL, "block_fused: arguments not covered");
     return check_launch("debug_block_fused");
@@ -1333,7 +1346,7 @@ int m3pc_debug_block_fused(const void* O, int M, const float* res, const float* 
 int m3pc_debug_block_fused_qkv(const void* O, int M, const float* res, const void* Wo, const void* W1, const void* W2, const void* Wqkv,
                                void* stream_buf, const float* bo, const float* b1, const float* b2, const float* ln2_g,
                                const float* ln2_b, const float* lnA_g, const float* lnA_b, const float* bqkv, float* Xout, void* QKV,
-                               void* stream, long long* stamps) {
+                               void* stream, long long* stamps, int x_bf16) {
     hipStream_t st = (hipStream_t)stream;
     launch_pack_block_stream((const bf16_t*)Wo, (const bf16_t*)W1, (const bf16_t*)W2, (bf16_t*)stream_buf, st);
     launch_pack_block_qkv((const bf16_t*)Wqkv, (bf16_t*)stream_buf, st);
@@ -1359,6 +1372,7 @@ int m3pc_debug_block_fused_qkv(const void* O, int M, const float* res, const voi
     b.qkv_bytes = (unsigned)((size_t)M * 1536 * 2);
     b.bqkv = bqkv;
     b.stamps = stamps;
+    b.x_bf16 = x_bf16 ? 1 : 0;  // (res and Xout are then (M, 512) bf16 rows)
     if (!launch_block_fused(b, st)) return fail(M3PC_EINVAL, "block_fused (qkv): arguments not covered");
     return check_launch("debug_block_fused_qkv");
 }

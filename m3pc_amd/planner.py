@@ -30,6 +30,7 @@ import types
 from typing import Dict, Optional
 
 import contextlib
+import warnings
 
 import numpy as np
 
@@ -135,7 +136,7 @@ class HipPlanner(GoalMixin, LockstepMixin):
                  rescore: str = "bound", rescore_min: int = 8, rescore_max: int = 128, rescore_delta: Optional[float] = None,
                  max_windows: int = 1, pipeline_depth: int = 3, chain_priority: int = -1, tail_stream: bool = True,
                  defer_join: bool = True, goal_batch: int = 0, race_min: int = 2, calibration_windows: Optional[int] = None, certify_sample: bool = True,
-                 chain_mode: str = "alternate", policy_head: str = "full"):
+                 chain_mode: str = "alternate", policy_head: str = "full", auto_fp32: bool = True):
         """cfg: any object with traj_length, action_samples, horizon, discount, temperature, lmbda,
         plan_guidance (finetune.py RunConfig fields read at learner.py:276,319,342).
         tokenizer_manager: a TokenizerManager (this package's) or {key: {"mean","std","min","max"}}.
@@ -156,6 +157,12 @@ class HipPlanner(GoalMixin, LockstepMixin):
           rescore="topk": the fixed ``rescore_topk`` best candidates (round-1 behaviour, no certificate, no host read).
           Either way the select runs on the MERGED vector: fp32 scores for the re-scored candidates, bf16 scores minus the
           estimated shift for the rest, so an un-re-scored candidate cannot win the arg-max through a constant bf16 offset.
+        auto_fp32 (bf16 + rescore="bound"): the certificate keeps a bf16 step's arg-max and draw the fp32 ones whatever the weights
+          are, but its PRICE depends on them -- where the bf16 deviation delta is not small against the spread of the scores the
+          certificate asks for most of the candidates in fp32 (tests/test_certificate_gpu.py, "trained-like" weights: every Linear
+          x 2 already re-scores a third of them) and the step is slower than a plain fp32 step.  With auto_fp32 the planner watches
+          for that -- half of the candidates or more re-scored in fp32, on average over the last (up to 16, at least 4) steps -- and
+          plans in fp32 from then on (one warning; ``planner.fp32_fallback``), until the next weight load gives bf16 another try.
         pipeline_depth: how many plan steps ``action_sample_batch`` / ``rollout`` keep in flight (<= capi.SLOTS - 1).
         goal_batch: the largest number of zero-shot windows one ``action_piid_sample_batch`` / ``goal_actions`` call plans
         through the pruned many-window path (m3pc_goal_step_batch; BASELINE config 5: 8192 per GPU); 0 = that path is off."""
@@ -190,6 +197,11 @@ class HipPlanner(GoalMixin, LockstepMixin):
         self.rescore = rescore if self.precision == capi.PREC_BF16 else "none"
         self.rescore_min, self.rescore_max = int(rescore_min), int(rescore_max)
         self.race_min = max(1, int(race_min))  # race entries of a first pass (the winner of the bf16 race + one runner-up)
+        self._auto_fp32 = bool(auto_fp32) and self.precision == capi.PREC_BF16 and self.rescore == "bound"
+        self._configured = (self.precision, self.rescore)  # what the caller asked for (the fp32 fallback returns to it)
+        self._sat_recent: list = []  # saturated flags of the last 16 resolved steps
+        self._want_fp32 = False      # set by _finish, acted on by the next _issue (steps in flight are drained first)
+        self.fp32_fallback = False
         self._delta_fixed = None if rescore_delta is None else float(rescore_delta)
         # Adaptive state of the certified re-score.  It must not depend on how many steps are in flight (a pipelined run has
         # to reproduce the serial one bit for bit), so it is LAGGED: step t uses what the steps up to t - capi.SLOTS saw --
@@ -270,6 +282,10 @@ class HipPlanner(GoalMixin, LockstepMixin):
         self._cal_left = getattr(self, "_cal_windows", 3)
         self._hist = {}
         self.delta_grown = 0
+        if getattr(self, "fp32_fallback", False):  # new weights: bf16 gets another try
+            self.precision, self.rescore = self._configured
+            self.fp32_fallback = False
+        self._sat_recent, self._want_fp32 = [], False
 
     # -- adaptive re-score state ------------------------------------------------------------------------
     @property
@@ -437,6 +453,8 @@ class HipPlanner(GoalMixin, LockstepMixin):
         stream -- i.e. for the previous step's candidate pass, which costs the overlap of the policy pass."""
         cfg = self.cfg
         N, T, A = int(cfg.action_samples), self.T, self.A
+        if self._auto_fp32 and not self.fp32_fallback:
+            self._maybe_fall_back_to_fp32()
         if not pipelined:
             self._drain()  # a serial step runs its fp32 chains on the current stream: nothing pipelined may still be using them
         sl = (slot if slot is not None else self._acquire_slot()).ready(self)
@@ -509,6 +527,21 @@ class HipPlanner(GoalMixin, LockstepMixin):
             self._enqueue_tail(tk)
             self._mark_main()
         return tk
+
+    def _maybe_fall_back_to_fp32(self):
+        """auto_fp32: the certified bf16 step costs more than an fp32 step once its certificates keep asking for the whole window
+        set (delta not small against the score spread: a property of the weights).  Decided on the steps up to index - SLOTS, like
+        every adaptive quantity (_adapt): the same decision at the same step at any pipeline depth."""
+        seen = [v[3] for _, v in sorted((i, v) for i, v in self._hist.items() if i <= self._step_index - capi.SLOTS)[-16:] if len(v) > 3]
+        N = int(self.cfg.action_samples)
+        if len(seen) < 4 or sum(seen) < 0.5 * N * len(seen):  # (re-scoring k of N candidates costs ~k / N of an fp32 step on top of the bf16 one)
+            return
+        for tk in [sl.owner for sl in self._slots if sl.owner is not None]:
+            self._finish(tk)  # (issued as bf16 steps: resolved as such)
+        warnings.warn(f"m3pc_amd: the bf16 certificate re-scored {sum(seen) / len(seen):.0f} of {N} candidates in fp32 on average over "
+                      f"the last {len(seen)} plan steps (delta = {self._delta:.3g}): planning in fp32 until the next weight load "
+                      f"(HipPlanner(auto_fp32=False) keeps bf16)")
+        self.precision, self.rescore, self.fp32_fallback = capi.PREC_FP32, "none", True
 
     def _rescore_args(self, tk):
         return (tk.mode, tk.states, tk.actions, tk.rewards, tk.eps), (tk.h, tk.rtg, tk.lmbda, float(self.cfg.discount))
@@ -615,7 +648,7 @@ class HipPlanner(GoalMixin, LockstepMixin):
             extra["race"] = tk.lst[tk.R - extra["n_race"] : tk.R]  # the re-scored racers (a view: best bf16 race key LAST)
             # what this step saw feeds the steps from SLOTS later on (_adapt): the bound, and the sizes of the first pass
             self._hist[tk.index] = (float(extra["deviation"]), min(int(extra["n_in_window"]), tk.kmax),
-                                    min(int(extra["need_race"]), tk.R))
+                                    min(int(extra["need_race"]), tk.R), int(extra["n_rescored"]) + int(extra["n_race"]))
             for i in [i for i in self._hist if i < tk.index - 64]:
                 # (old enough that every step still to come would count it anyway: fold its deviation into the base bound)
                 if self._delta_fixed is None:
@@ -873,9 +906,15 @@ def _versions(module):
     return per, total
 
 
-def attach(learner, precision: str = "fp32", rescore_topk: int = 16, group=None, generator: Optional[torch.Generator] = None,
+def attach(learner, precision: str = "bf16", rescore_topk: int = 16, group=None, generator: Optional[torch.Generator] = None,
            **planner_kw):
     """Rebind the plan path of a reference-style ``Learner`` onto the HIP library.
+
+    precision: "bf16" (default since round 6: the configuration the headline is measured on) -- the bf16 candidate pass with the
+    certified fp32 re-score: BOTH returned actions follow the fp32 path's decisions (the arg-max behind ``eval_action`` and
+    the multinomial index behind ``sample_action`` are certified, ``certify_sample=True``; ``eval_action``'s weights p agree
+    to ~1e-4), and ``auto_fp32`` falls back to plain fp32 steps for weights on which the certificate is expensive.
+    "fp32": every tolerance of the reference's own fp32 arithmetic, ~8 x the time per step.
 
     Reads: learner.cfg, learner.mtm (state_dict + config), learner.tokenizer_manager.tokenizers[k]
     (._data_mean, ._data_std, .normalize, .stats), learner.iql.qf (state_dict, obs_mean, obs_std).

@@ -16,7 +16,15 @@ removes), delta = 1.5 x the largest deviation (the planner's calibration), and n
 candidates the arg-max certificate would have to re-score in fp32.  (Attention products stay fp32 here: in the HIP path they are
 bf16 MFMAs with fp32 softmax; their share of the deviation is part of what the HIP path measures and this emulation does not.)
 
-    python -m oracle.lowprec_study [N] [seeds]      -> a table on stdout, JSON to gpurun_out/ or /tmp
+Round 6 adds the question behind the step's 102x HBM traffic: the fp32 residual stream crosses HBM between the
+fused layer tails (2 KB per token row out + in per layer: a third of a tile's input bytes, half of its output bytes).  What if
+that buffer were bf16?
+    bf16_res  as bf16, and the residual stream is rounded to bf16 wherever it would cross HBM in the HIP candidate pass: the
+              input rows of every encoder layer (the embedding kernel's X; the layer-1 tail's X''), used both by that layer's
+              norm1 and by its residual add.  (Inside a layer X' never leaves the registers; the last encoder layer's X'' feeds
+              encoder.norm inside the tail; the decoder's scored rows come from a candidate-independent fp32 table.)
+
+    python -m oracle.lowprec_study [N] [seeds] [modes, comma-separated]      -> a table on stdout, JSON to gpurun_out/ or /tmp
 """
 from __future__ import annotations
 
@@ -72,27 +80,32 @@ def make_linear(sd, mode: str):
         if mode == "fp32" or K % 32 != 0:  # (the tiny-K encoder embeddings stay fp32: K = 11 / 3 / 1 -- not MFMA work in the HIP path either)
             return F.linear(x, W, b)
         is_ffn = ".linear1." in name or ".linear2." in name
-        fn = round_mxfp8 if (mode == "fp8_all" or (mode == "fp8_ffn" and is_ffn)) else round_bf16
+        fn = round_mxfp8 if (mode == "fp8_all" or (mode == "fp8_ffn" and is_ffn)) else round_bf16  # (bf16_res: bf16 operands)
         return F.linear(fn(x), q_weight(W, fn), b)
 
     return linear
 
 
 def scores(sd, stats, cfg, win, h, acts, mode):
-    keep = O.F
+    keep, keep_block = O.F, O._block
     O.F = types.SimpleNamespace(linear=make_linear(sd, mode), layer_norm=F.layer_norm, gelu=F.gelu)
+    if mode == "bf16_res":
+        def block(x, sd_, prefix, n_head):
+            return keep_block(round_bf16(x) if prefix.startswith("encoder.layers.") else x, sd_, prefix, n_head)
+        O._block = block
     try:
         out = []
         for c0 in range(0, acts.shape[0], 256):
             out.append(O.plan_candidates(sd, stats, cfg, win, h, acts[c0 : c0 + 256], "rtg", 0.6))
         return torch.cat(out)
     finally:
-        O.F = keep
+        O.F, O._block = keep, keep_block
 
 
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ["bf16", "fp8_ffn", "fp8_all", "bf16_res"]
     T, H = 32, 16
     dims = synth.Dims(11, 3, T)
     rows = []
@@ -109,7 +122,7 @@ def main():
         f = scores(sd, stats, cfg, win, h, acts, "fp32")
         t_f = time.time() - t0
         fbest = float(f.max())
-        for mode in ("bf16", "fp8_ffn", "fp8_all"):
+        for mode in modes:
             b = scores(sd, stats, cfg, win, h, acts, mode)
             d = b - f
             c = float(d.median())
@@ -122,7 +135,7 @@ def main():
             print(rows[-1], flush=True)
         print(f"# seed {ws}: fp32 pass {t_f:.1f} s on {torch.get_num_threads()} threads", flush=True)
     out_dir = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "/tmp"
-    with open(os.path.join(out_dir, f"r05_lowprec_study_N{N}.json"), "w") as fh:
+    with open(os.path.join(out_dir, f"r06_lowprec_study_N{N}.json"), "w") as fh:
         json.dump(rows, fh, indent=1)
     print("| weight seed | mode | shift | dev rms | dev max | delta = 1.5 max | need (of %d) | score sigma |" % N)
     print("|---|---|---|---|---|---|---|---|")

@@ -134,13 +134,13 @@ def test_block_fused_with_next_qkv(M):
     fn = lib.m3pc_debug_block_fused_qkv
     fn.restype = C.c_int
     vp = C.c_void_p
-    fn.argtypes = [vp, C.c_int] + [vp] * 18
+    fn.argtypes = [vp, C.c_int] + [vp] * 18 + [C.c_int]
 
-    def call(O_, R_, Xout, QKV):
+    def call(O_, R_, Xout, QKV, xb=0):
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         rc = fn(O_.data_ptr(), O_.shape[0], R_.data_ptr(), W["o"].data_ptr(), W["1"].data_ptr(), W["2"].data_ptr(), Wqkv.data_ptr(),
                 sb.data_ptr(), p["bo"].data_ptr(), p["b1"].data_ptr(), p["b2"].data_ptr(), p["g2"].data_ptr(), p["be2"].data_ptr(),
-                p["gA"].data_ptr(), p["bA"].data_ptr(), bqkv.data_ptr(), Xout.data_ptr(), QKV.data_ptr(), st, None)
+                p["gA"].data_ptr(), p["bA"].data_ptr(), bqkv.data_ptr(), Xout.data_ptr(), QKV.data_ptr(), st, None, xb)
         assert rc == 0, lib.m3pc_last_error()
         torch.cuda.synchronize()
 
@@ -170,6 +170,45 @@ def test_block_fused_with_next_qkv(M):
         Q3 = torch.empty(n, 3 * D, device=dev, dtype=torch.bfloat16)
         call(O[lo:lo + n].contiguous(), R[lo:lo + n].contiguous(), X3, Q3)
         assert torch.equal(X3, Xout[lo:lo + n]) and torch.equal(Q3, QKV[lo:lo + n])
+    # round 6: the same launch on a bf16 residual stream (BlockP::x_bf16: residual rows in and X'' rows out are bf16).  With the
+    # residual the fp32 launch saw rounded to bf16 beforehand, X' -- hence every Q|K|V bit -- is the fp32-row launch's, and X''
+    # is that launch's X'' rounded to bf16; in place (Xout = res) as the candidate pass runs it
+    Rb = R.to(torch.bfloat16)
+    Xf = torch.empty_like(Xout)
+    Qf = torch.full((M + 1, 3 * D), float("nan"), device=dev, dtype=torch.bfloat16)
+    call(O, Rb.float(), Xf, Qf)
+    Xb = torch.cat([Rb.clone(), torch.full((1, D), float("nan"), device=dev, dtype=torch.bfloat16)])  # (guard row)
+    Qb = torch.full((M + 1, 3 * D), float("nan"), device=dev, dtype=torch.bfloat16)
+    call(O, Xb, Xb, Qb, xb=1)
+    assert torch.isnan(Xb[M].float()).all() and torch.isnan(Qb[M].float()).all(), "rows past M written"
+    assert torch.equal(Qb[:M], Qf[:M])
+    assert torch.equal(Xb[:M], Xf.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M", [128, 4096 + 37, 25088])
+def test_block_fused_on_a_bf16_residual_stream(M):
+    """BlockP::x_bf16 on the plain form (the last encoder layer's tail: X'' is not stored, encoder.norm rows are; and with X''
+    stored): bit-identical to the fp32-row launch fed the bf16-rounded residual."""
+    lib = lab_library()
+    dev = torch.device("cuda")
+    W, p, _, g = make_params(77 + M)
+    O = torch.randn(M, D, device=dev, generator=g).to(torch.bfloat16)
+    Rb = torch.randn(M, D, device=dev, generator=g).to(torch.bfloat16)
+    nbytes = lib.m3pc_debug_block_stream_bytes
+    nbytes.restype = C.c_longlong
+    sb = torch.empty(int(nbytes()), dtype=torch.uint8, device=dev)
+    Xf = torch.empty(M, D, device=dev)
+    Hf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+    _call(lib, O, Rb.float(), None, 1, W, sb, 1, p, [None] * 4, 0, 0, Xf, Hf)
+    x2, y = reference(O, Rb.float(), W, p)
+    assert float((Xf - x2).abs().max()) / float(x2.abs().max()) <= 2e-3
+    Hb = torch.full((M + 1, D), float("nan"), device=dev, dtype=torch.bfloat16)
+    _call(lib, O, Rb, None, 1, W, sb, 0, p, [None] * 4, 0, 0, None, Hb, variant=16)       # X'' not stored
+    assert torch.isnan(Hb[M].float()).all() and torch.equal(Hb[:M], Hf)
+    Xb = torch.cat([Rb.clone(), torch.full((1, D), float("nan"), device=dev, dtype=torch.bfloat16)])
+    Hb2 = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+    _call(lib, O, Xb, None, 1, W, sb, 0, p, [None] * 4, 0, 0, Xb, Hb2, variant=16)        # in place
+    assert torch.isnan(Xb[M].float()).all() and torch.equal(Hb2, Hf) and torch.equal(Xb[:M], Xf.to(torch.bfloat16))
 
 
 @pytest.mark.parametrize("n,hh,detok", [(512, 16, True), (333, 5, False), (64, 32, True)])

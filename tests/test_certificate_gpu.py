@@ -59,12 +59,12 @@ def test_certificate_sweep_argmax_sample_index_and_deviation(env, guidance, tau,
 # "Trained-like" weights: delta is a calibrated statistic, and every sweep above draws its weights from
 # ONE init recipe.  synth.trained_like moves that recipe towards a trained model -- every Linear x 2 or x 4, LayerNorm gains
 # ~ U(0.5, 2), the returns tokenizer's std x 0.1 or x 10 (the x 1000 returns term of learner.py:305 then sits on another
-# sigma / delta ratio) -- four variants per shape; the bar is the same: 0 wrong arg-maxes, 0 wrong multinomial indices.
-TRAINED = [(2.0, 0.1), (2.0, 10.0), (4.0, 0.1), (4.0, 10.0)]
+# sigma / delta ratio) -- six variants per shape; the bar is the same: 0 wrong arg-maxes, 0 wrong multinomial indices.
+TRAINED = [(1.0, 10.0), (1.5, 1.0), (2.0, 0.1), (2.0, 10.0), (4.0, 0.1), (4.0, 10.0)]
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("N,T,H,per_variant", [(1024, 32, 16, 12), (625, 8, 4, 12)], ids=["N1024-T32", "N625-T8"])
+@pytest.mark.parametrize("N,T,H,per_variant", [(1024, 32, 16, 8), (625, 8, 4, 8)], ids=["N1024-T32", "N625-T8"])
 def test_certificate_sweep_trained_like_weights(N, T, H, per_variant):
     dims = synth.Dims(11, 3, T)
     sets = []
@@ -84,8 +84,8 @@ def _sweep(env, guidance, tau, N, T, H, weight_sets, per_seed, family, fp32_tol=
     mismatches = sample_mismatches = 0
     for ws, (label, sd, st) in enumerate(weight_sets):
         qsd, om, os_ = synth.make_critic(dims, ws) if mode == capi.MODE_CRITIC else (None, None, None)
-        mk = lambda prec: HipPlanner(_cfg(T, N, H, tau, guidance), sd, st, qsd, om, os_, precision=prec,
-                                     generator=torch.Generator(device="cuda").manual_seed(1))
+        mk = lambda prec: HipPlanner(_cfg(T, N, H, tau, guidance), sd, st, qsd, om, os_, precision=prec, auto_fp32=False,
+                                     generator=torch.Generator(device="cuda").manual_seed(1))  # (auto_fp32 off: the certificate itself is what is measured)
         pb, pf = mk("bf16"), mk("fp32")  # (same generator seed: both draw the same Exp(1) variates step for step)
         for t in range(per_seed):
             hist = _window(dims, t)
@@ -260,5 +260,39 @@ def test_load_critic_recalibrates_the_bound():
     steps(pb._cal_windows + 1, 100)
     assert pb._cal_left == 0
     assert pb._delta0 > 3.0 * d_old, (pb._delta0, d_old)  # the bound follows the new Q scale (measured: ~8 x)
+    pb.handle.close()
+    pf.handle.close()
+
+
+def test_auto_fp32_fallback_on_weights_that_make_the_certificate_expensive():
+    """HipPlanner(auto_fp32=True), the default: with every Linear x 4 the bf16 deviation exceeds the score spread, every step's
+    certificate re-scores most of the candidates in fp32, and a certified bf16 step costs more than an fp32 step -- the planner says so once
+    and plans in fp32 until the next weight load.  The decision is lagged by capi.SLOTS steps (same step at any pipeline depth)."""
+    N, T, H = 1024, 32, 16  # (the headline shape: profiles/r06_certificate_sweep_trained_like_*: 1046 of 1024 + 32 list entries re-scored)
+    dims = synth.Dims(11, 3, T)
+    sd0, st0 = synth.make_state_dict(dims, 2), synth.make_tokenizer_stats(dims, 2)
+    sd4, st4 = synth.trained_like(sd0, st0, seed=2, linear_scale=4.0, returns_std_scale=0.1)
+    pb = HipPlanner(_cfg(T, N, H), sd4, st4, None, precision="bf16", generator=torch.Generator(device="cuda").manual_seed(1))
+    pf = HipPlanner(_cfg(T, N, H), sd4, st4, None, precision="fp32", generator=torch.Generator(device="cuda").manual_seed(1))
+    switched_at = None
+    with pytest.warns(UserWarning, match="planning in fp32"):
+        for t in range(4 + capi.SLOTS + 2):
+            hist = _window(dims, t)
+            eps = synth.make_eps(N, dims, 300 + t).cuda()
+            pb._eps = pf._eps = lambda shape: eps
+            ab = pb.action_sample(hist, plan=True, eval=True, rtg=3.0)
+            af = pf.action_sample(hist, plan=True, eval=True, rtg=3.0)
+            assert int(pb.last["argmax"].item()) == int(pf.last["argmax"].item())
+            assert int(pb.last["sample_idx"].item()) == int(pf.last["sample_idx"].item())
+            if pb.fp32_fallback:
+                switched_at = t if switched_at is None else switched_at
+                assert torch.equal(ab, af) and torch.equal(pb.last["expect_return"], pf.last["expect_return"])
+            else:
+                assert pb.last["certified"] and pb.last["n_rescored"] + pb.last["n_race"] >= N // 2
+    assert switched_at == 3 + capi.SLOTS  # four expensive steps seen, SLOTS steps late
+    pb.load_state_dict(sd0)   # new weights: bf16 again (the tokenizer statistics stay: the point is the switch)
+    assert not pb.fp32_fallback and pb.precision == capi.PREC_BF16 and pb.rescore == "bound"
+    pb.action_sample(_window(dims, 0), plan=True, eval=True, rtg=3.0)
+    assert pb.last.get("expect_return_bf16") is not None
     pb.handle.close()
     pf.handle.close()

@@ -292,7 +292,9 @@ def test_attach_rebinds_a_learner_like_object_and_tracks_weight_updates():
     qf.obs_mean, qf.obs_std = om, os_
     learner = types.SimpleNamespace(cfg=_cfg(8, 16, 4, 0.01, "rtg_guiding"), mtm=mtm,
                                     tokenizer_manager=types.SimpleNamespace(tokenizers=toks), iql=types.SimpleNamespace(qf=qf))
-    planner = attach(learner)
+    import inspect
+    assert inspect.signature(attach).parameters["precision"].default == "bf16"  # (round 6: the drop-in's default is the headline's)
+    planner = attach(learner, precision="fp32")  # (this test holds the result to the reference's fp32 golden at 2e-5)
     eps = synth.make_eps(16, dims, 1).cuda()
     planner._eps = lambda shape: eps
     hist = synth.make_history(dims, 0)

@@ -29,12 +29,16 @@ __device__ __forceinline__ bf16x8 lds_frag(unsigned addr) {
     return v;
 }
 
-template <int SHAPE, int FILL>
-__global__ __launch_bounds__(256) void probe(float* out, long long* stamps, int passes, const unsigned short* seed_bits) {
+// NW: waves per workgroup (4: one per SIMD, as the fused tail runs; 8: two per SIMD -- round 6, VERDICT r5 item 1: what would a second
+// wave per SIMD buy an LDS-fed MFMA loop of this filler density on this chip, in cycles AND in wall time?  Per-wave state is the same
+// 128 accumulator registers either way, so NW = 8 does twice the work per workgroup).  BAR: one s_barrier per 32 fragments per wave
+// (the ring-stage sync of the fused tail).
+template <int SHAPE, int FILL, int NW = 4, int BAR = 0>
+__global__ __launch_bounds__(64 * NW) void probe(float* out, long long* stamps, int passes, const unsigned short* seed_bits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     // random weight image (bf16 bit patterns of values in [-1, 1)), the same for every workgroup
-    for (int i = tid; i < NFRAG * 512; i += 256) ((unsigned short*)lds)[i] = seed_bits[i];
+    for (int i = tid; i < NFRAG * 512; i += 64 * NW) ((unsigned short*)lds)[i] = seed_bits[i];
     __syncthreads();
     bf16x8 b[8];  // the wave's activations: 8 k-steps of its 32 token rows (B operand; for 16x16x32 two 16-token groups per register set)
     for (int j = 0; j < 8; ++j)
@@ -54,6 +58,7 @@ __global__ __launch_bounds__(256) void probe(float* out, long long* stamps, int 
         for (int g = 0; g < NFRAG / 4; ++g) {
             // four fragments ahead: the reads of the next group are issued before this group's MFMAs
             const unsigned nb = base + (((g + 1) & (NFRAG / 4 - 1)) * 4) * 1024;
+            if (BAR && (g & 7) == 0) asm volatile("s_barrier" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
 #pragma unroll
             for (int q = 0; q < 4; ++q) nxt[q] = lds_frag(nb + q * 1024);
@@ -83,49 +88,52 @@ __global__ __launch_bounds__(256) void probe(float* out, long long* stamps, int 
     }
     for (int j = 0; j < 16; ++j) s += acc4[j][0] + acc4[j][1] + acc4[j][2] + acc4[j][3];
     for (int q = 0; q < 4; ++q) s += (float)cur[q][0];
-    out[blockIdx.x * 256 + tid] = s;
+    out[blockIdx.x * 64 * NW + tid] = s;
     if (lane == 0) {
-        stamps[(blockIdx.x * 4 + (tid >> 6)) * 2] = t1 - t0;
-        stamps[(blockIdx.x * 4 + (tid >> 6)) * 2 + 1] = r1 - r0;
+        stamps[(blockIdx.x * NW + (tid >> 6)) * 2] = t1 - t0;
+        stamps[(blockIdx.x * NW + (tid >> 6)) * 2 + 1] = r1 - r0;
     }
 }
 
-template <int SHAPE, int FILL>
+template <int SHAPE, int FILL, int NW = 4, int BAR = 0>
 static void run(float* out, long long* stamps, const unsigned short* seed, int passes) {
     const int blocks = 256;
-    hipFuncSetAttribute((const void*)probe<SHAPE, FILL>, hipFuncAttributeMaxDynamicSharedMemorySize, NFRAG * 1024);
+    passes = passes * 4 / NW;  // (the same work per workgroup)
+    hipFuncSetAttribute((const void*)probe<SHAPE, FILL, NW, BAR>, hipFuncAttributeMaxDynamicSharedMemorySize, NFRAG * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int w = 0; w < 40; ++w) probe<SHAPE, FILL><<<blocks, 256, NFRAG * 1024>>>(out, stamps, passes, seed);  // warm: the clock settles under load
+    for (int w = 0; w < 40; ++w) probe<SHAPE, FILL, NW, BAR><<<blocks, 64 * NW, NFRAG * 1024>>>(out, stamps, passes, seed);  // warm: the clock settles under load
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    probe<SHAPE, FILL><<<blocks, 256, NFRAG * 1024>>>(out, stamps, passes, seed);
+    probe<SHAPE, FILL, NW, BAR><<<blocks, 64 * NW, NFRAG * 1024>>>(out, stamps, passes, seed);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    std::vector<long long> st(blocks * 4 * 2);
+    std::vector<long long> st(blocks * NW * 2);
     hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost);
     std::vector<double> cyc, clk;
-    for (int i = 0; i < blocks * 4; ++i) {
+    for (int i = 0; i < blocks * NW; ++i) {
         cyc.push_back((double)st[2 * i]);
         clk.push_back((double)st[2 * i] / (double)st[2 * i + 1] * 0.1);  // s_memrealtime ticks at 100 MHz -> GHz
     }
     std::sort(cyc.begin(), cyc.end());
     std::sort(clk.begin(), clk.end());
     const double frags = (double)passes * NFRAG;
-    const double flops = (double)blocks * 4 * frags * 2.0 * 32 * 32 * 16;
-    printf("shape %s fill %d: wall %.3f ms  %.1f TFLOP/s  cycles/fragment %.2f (median wave)  in-kernel clock %.3f GHz\n",
-           SHAPE == 32 ? "32x32x16" : "16x16x32", FILL, ms, flops / ms / 1e9, cyc[cyc.size() / 2] / frags, clk[clk.size() / 2]);
+    const double flops = (double)blocks * NW * frags * 2.0 * 32 * 32 * 16;
+    // cycles per fragment PER SIMD: with two waves per SIMD a wave's own fragment takes twice the SIMD's
+    printf("shape %s fill %d waves/SIMD %d barrier %d: wall %.3f ms  %.1f TFLOP/s  cycles/fragment/SIMD %.2f (median wave)  in-kernel clock %.3f GHz\n",
+           SHAPE == 32 ? "32x32x16" : "16x16x32", FILL, NW / 4, BAR, ms, flops / ms / 1e9, cyc[cyc.size() / 2] / frags / (NW / 4),
+           clk[clk.size() / 2]);
 }
 
 int main() {
     float* out;
     long long* stamps;
     unsigned short* seed;
-    hipMalloc(&out, 256 * 256 * 4);
-    hipMalloc(&stamps, 256 * 4 * 2 * 8);
+    hipMalloc(&out, 256 * 512 * 4);
+    hipMalloc(&stamps, 256 * 8 * 2 * 8);
     hipMalloc(&seed, NFRAG * 1024);
     std::vector<unsigned short> h(NFRAG * 512);
     srand(1);
@@ -144,6 +152,16 @@ int main() {
         run<16, 3>(out, stamps, seed, passes);
         run<32, 6>(out, stamps, seed, passes);
         run<16, 6>(out, stamps, seed, passes);
+        // round 6: a second wave per SIMD (and the per-stage barrier of a shared weight ring)
+        run<32, 0, 8>(out, stamps, seed, passes);
+        run<32, 3, 8>(out, stamps, seed, passes);
+        run<32, 6, 8>(out, stamps, seed, passes);
+        run<32, 3, 4, 1>(out, stamps, seed, passes);
+        run<32, 3, 8, 1>(out, stamps, seed, passes);
+        run<32, 6, 4, 1>(out, stamps, seed, passes);
+        run<32, 6, 8, 1>(out, stamps, seed, passes);
+        run<16, 3, 8>(out, stamps, seed, passes);
+        run<16, 6, 8>(out, stamps, seed, passes);
     }
     return 0;
 }
