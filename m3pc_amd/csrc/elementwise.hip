@@ -516,8 +516,87 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutP p) {
         if (lane == 0) y[f] = s;
     }
 }
+// The same on the matrix cores, for the many-row bf16 passes (round 6; critic_lambda_guiding's 17-wide states head ran 65536 rows
+// per plan step of config 3 through head_out_kernel: one wave per row, a 64-lane butterfly per output feature -- 4.5 % of the step
+// for 2 GFLOP).  Y^T[feature][row] = W2[feature][k] X^T[k][row]: W2 = the MFMA A operand (D <= 32 features padded to 32, split
+// into a bf16 head and a bf16 remainder so that the weights keep ~16 mantissa bits: two MFMAs per k-step, the FLOPs are nothing),
+// the rows' hidden activations (bf16: the GEMM + gelu in front writes them so, half the bytes of the fp32 rows) = the B operand,
+// read straight from global memory in operand order (16 bytes of a lane's own row per k-step).  An accumulator holds lane = row,
+// registers = features: bias and de-tokeniser apply per register, a lane stores its own row's values.  The W2 fragments sit in LDS
+// (2 x 32 KiB, built once per workgroup); workgroups are persistent over 128-row tiles.
+namespace {
+typedef float hf32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned hu32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
+constexpr int HO_D = 512, HO_KS = HO_D / 16;
+}
+__global__ __launch_bounds__(256) void head_out_mfma_kernel(HeadOutP p, int n_tiles) {
+    __shared__ __attribute__((aligned(16))) hu32x4 wfrag[2][HO_KS][64];  // [hi | lo][k-step][lane]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    for (int i = tid; i < HO_KS * 64; i += 256) {
+        const int s = i >> 6, ln = i & 63, f = ln & 31, h = ln >> 5;
+        hbf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float w = f < p.D ? p.W[(long long)f * HO_D + 16 * s + 8 * h + j] : 0.f;
+            hi[j] = (bf16_t)w;
+            lo[j] = (bf16_t)(w - (float)hi[j]);
+        }
+        wfrag[0][s][ln] = __builtin_bit_cast(hu32x4, hi);
+        wfrag[1][s][ln] = __builtin_bit_cast(hu32x4, lo);
+    }
+    __syncthreads();
+    // this lane's features: register e <-> feature (e & 3) + 8 (e >> 2) + 4 lh
+    float bias[16], sc[16], sh[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int f = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const bool on = f < p.D;
+        bias[e] = on ? p.b[f] : 0.f;
+        sc[e] = on && p.mean ? p.stdv[f] : 1.f;
+        sh[e] = on && p.mean ? p.mean[f] : 0.f;
+    }
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int r = t * 128 + 32 * wv + l31;
+        const int rl = r < p.rows ? r : p.rows - 1;
+        const bf16_t* x = p.Xb + (long long)rl * p.ldx + 8 * lh;
+        hf32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < HO_KS; c += 8) {
+            hu32x4 b[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) b[s] = *(const hu32x4*)(x + 16 * (c + s));
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const hbf16x8 bv = __builtin_bit_cast(hbf16x8, b[s]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hbf16x8, wfrag[1][c + s][lane]), bv, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hbf16x8, wfrag[0][c + s][lane]), bv, acc, 0, 0, 0);
+            }
+        }
+        if (r < p.rows) {
+            float* y = p.Y + (long long)map_row(p.ymap, r) * p.ldy;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int f = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (f < p.D) {
+                    float v = acc[e] + bias[e];
+                    if (p.mean) v = __fadd_rn(__fmul_rn(v, sc[e]), sh[e]);
+                    y[f] = v;
+                }
+            }
+        }
+    }
+}
+bool head_out_mfma_covers(int rows, int d, int D) { return d == HO_D && D >= 1 && D <= 32 && rows >= 2048; }
 void launch_head_out(const HeadOutP& p, hipStream_t st) {
     if (p.rows <= 0) return;
+    if (p.Xb) {  // (the caller asked head_out_mfma_covers first)
+        const int n_tiles = (p.rows + 127) / 128;
+        hipLaunchKernelGGL(head_out_mfma_kernel, dim3(n_tiles < 512 ? n_tiles : 512), dim3(256), 0, st, p, n_tiles);
+        return;
+    }
     hipLaunchKernelGGL(head_out_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, st, p);
 }
 

@@ -302,6 +302,7 @@ void launch_gather_rows(const GatherP& p, hipStream_t st);
 // with the de-tokenizer folded in (tokenizers/continuous.py:81-94).
 struct HeadOutP {
     const float* X;
+    const bf16_t* Xb;  // instead of X: the rows in bf16 (many-row bf16 passes: head_out_mfma_kernel, round 6)
     int ldx;
     int rows, d, D;
     const float* W;    // (D, d)
@@ -313,6 +314,7 @@ struct HeadOutP {
     int ldy;
 };
 void launch_head_out(const HeadOutP& p, hipStream_t st);
+bool head_out_mfma_covers(int rows, int d, int D);  // Xb rows: d == 512, D <= 32, enough rows to fill the chip
 
 // DiagGaussianActor (mtm_model.py:313-321): mu = x.Wmu + bmu ; std = exp(-5 + 3.5*(tanh(x.Wls + bls)+1))
 struct ActorP {

@@ -452,11 +452,17 @@ int run_head_tail(m3pc_handle* h, int k, const void* ln_rows, int rows, float* o
     GemmP p = gemm_basic(ln_rows, d, Wop(h, "output_head_dict." + kn + ".1.weight", dt), d, rows, d, d,
                          W(h, "output_head_dict." + kn + ".1.bias").f);
     p.gelu = 1;
-    gemm_out(p, DT_F32, h->G, d);
+    // many-row bf16 passes: the gelu'd hidden rows cross HBM in bf16 and the last Linear runs on the matrix cores (round 6)
+    static const bool no_mfma_head = M3PC_ENV("M3PC_NO_HEAD_OUT_MFMA") != nullptr;  // A/B switch
+    // (chosen by the size of the WHOLE step, never by a shard's rows: sharded scores stay bit-identical to the unsharded ones)
+    const long long step_rows = (long long)((double)rows * h->pass_scale + 0.5);
+    const bool hb = dt == DT_BF16 && !no_mfma_head && head_out_mfma_covers((int)(step_rows < 0x7fffffff ? step_rows : 0x7fffffff), d, h->feat[k]);
+    gemm_out(p, hb ? DT_BF16 : DT_F32, h->G, d);
     gemm(h, p, dt, st);
     HeadOutP ho;
     memset(&ho, 0, sizeof(ho));
-    ho.X = h->G;
+    if (hb) ho.Xb = (const bf16_t*)h->G;
+    else ho.X = h->G;
     ho.ldx = d;
     ho.rows = rows;
     ho.d = d;
