@@ -275,6 +275,8 @@ def main():
     ap.add_argument("--policy-head", default="full", choices=["pruned", "full"],
                     help="policy pass: every row of the policy head (default) or the h sampled action tokens only, through the pruned decoder")
     ap.add_argument("--race-min", type=int, default=0, help="race entries of a first re-score pass (0: the planner's default)")
+    ap.add_argument("--rescore-round", type=int, default=0, help="a first re-score pass's size is rounded up to a multiple of this (0: the planner's default)")
+    ap.add_argument("--calibration-factor", type=float, default=0.0, help="delta = this x the calibration passes' largest deviation (0: the planner's default, 1.6)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU (tests/test_bench_launch_cpu.py): the ranks meet over gloo and rank 0 prints a stub line")
     args = ap.parse_args()
@@ -341,6 +343,8 @@ def main():
                          rescore=args.rescore, **({"rescore_min": args.rescore_min} if args.rescore_min else {}), group=group,
                          certify_sample=not args.no_certify_sample, **({"race_min": args.race_min} if args.race_min else {}),
                          chain_mode=args.chain_mode, policy_head=args.policy_head, chain_priority=args.chain_priority,
+                         **({"calibration_factor": args.calibration_factor} if args.calibration_factor else {}),
+                         **({"rescore_round": args.rescore_round} if args.rescore_round else {}),
                          pipeline_depth=max(1, min(args.depth, capi.SLOTS - 1)))
     hist = synth.make_history(dims, 0 if (shard_cand or world == 1) else rank)  # env sharding: every rank its own environment
     hist["path_length"] = 500
@@ -384,7 +388,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    run(args.settle)  # per-weight-load setup: lets the re-score's error bound settle (a raise repeats that step's merge + select)
+    run(max(args.settle, planner._cal_windows + capi.SLOTS))  # per-weight-load setup (calibration passes included): lets the re-score's error bound settle (a raise repeats that step's merge + select)
     run(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -674,7 +678,7 @@ def plan_leg(local_rank, env, guidance, N, H, T, steps=20, warm=4, settle=12, de
         while flight:
             flight.popleft().pair()
 
-    run(settle)
+    run(max(settle, p._cal_windows + capi.SLOTS))  # (every calibration pass of the weight load behind us before anything is timed)
     run(warm)
     if world > 1:
         torch.distributed.barrier(group)
@@ -902,6 +906,8 @@ def extras(args, dims, cfg, hist, planner, S, A):
     for prec in ("bf16", "fp32"):
         p8 = HipPlanner(c8, synth.make_state_dict(d8, 0), synth.make_tokenizer_stats(d8, 0), None, precision=prec,
                         generator=torch.Generator(device="cuda").manual_seed(1))
+        for _ in range(p8._cal_windows + capi.SLOTS if prec == "bf16" else 0):  # (the weight load's calibration passes, untimed)
+            p8.action_sample(h8, plan=True, eval=True, rtg=3.0)
         ship[prec] = _time_calls(lambda: p8.action_sample(h8, plan=True, eval=True, rtg=3.0).cpu(), 40)
         if prec == "bf16":  # several environments in flight at the shipped config (rollout.evaluate_plan's pattern)
             hs8 = [dict(synth.make_history(d8, i), path_length=500) for i in range(8)]
@@ -928,7 +934,7 @@ def extras(args, dims, cfg, hist, planner, S, A):
                 hi = synth.make_history(dims, i)
                 hi["path_length"] = 500
                 hs.append(hi)
-            for _ in range(8):  # (the certificate's bound settles within the first calls: every raise repeats a merge + select)
+            for _ in range(max(8, -(-(pb._cal_windows + capi.SLOTS) // E) + 2)):  # (calibration passes + the bound's settling, untimed)
                 pb.action_sample_batch(hs, eval=True, rtg=3.0)
             torch.cuda.synchronize()
             t0 = time.perf_counter()

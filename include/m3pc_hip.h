@@ -42,11 +42,15 @@
 extern "C" {
 #endif
 
-/* ABI history.  v5 (round 5): m3pc_topk_race_window, m3pc_rescore_merge_race, m3pc_merge_race_select (the certified multinomial
+/* ABI history.  v6 (round 6): no new entry point and no structure change; m3pc_rescore_merge now writes all 8 floats of its
+ * host_stats block (slots 5..7 as zeros: a reader of the 8-float layout never sees an earlier race merge's values), so a caller
+ * that passed the 5-float block of m3pc_topk_window must pass 8.  Inside the library: a bf16 candidate pass carries its residual
+ * stream between the encoder layers in bf16 and runs the output heads' last Linear on bf16 hidden rows (scores move within the
+ * bf16 deviation the certified re-score is calibrated on; fp32 passes are unchanged).  v5 (round 5): m3pc_topk_race_window, m3pc_rescore_merge_race, m3pc_merge_race_select (the certified multinomial
  * draw of the bf16 plan step); M3PC_PLAN_PRUNED_POLICY; m3pc_profile_enable(h, 3); the handle holds two chain workspaces per kind,
  * picked by the parity of m3pc_plan_args::slot.  v4: m3pc_goal_step_batch, m3pc_dims::max_goal_batch.  v3: M3PC_PLAN_DEFER_JOIN,
  * m3pc_candidate_join.  No structure changed layout in v5. */
-#define M3PC_ABI_VERSION 5
+#define M3PC_ABI_VERSION 6
 
 #define M3PC_OK 0
 #define M3PC_EINVAL (-1)   /* bad argument / shape mismatch            */

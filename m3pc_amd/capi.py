@@ -21,7 +21,7 @@ KEYS = ("states", "actions", "rewards", "returns")
 MODE_RTG, MODE_CRITIC, MODE_NOISE = 0, 1, 2
 PREC_FP32, PREC_BF16 = 0, 1
 PROF_LAYER_TAIL = 16  # m3pc_profile_read: the fused layer-tail launches only
-ABI_VERSION = 5
+ABI_VERSION = 6
 GOAL_PIID, GOAL_ID = 0, 1  # m3pc_goal_step_batch goal_mode
 SLOTS = 4  # M3PC_SLOTS: plan steps in flight per handle
 

@@ -136,7 +136,8 @@ class HipPlanner(GoalMixin, LockstepMixin):
                  rescore: str = "bound", rescore_min: int = 8, rescore_max: int = 128, rescore_delta: Optional[float] = None,
                  max_windows: int = 1, pipeline_depth: int = 3, chain_priority: int = -1, tail_stream: bool = True,
                  defer_join: bool = True, goal_batch: int = 0, race_min: int = 2, calibration_windows: Optional[int] = None, certify_sample: bool = True,
-                 chain_mode: str = "alternate", policy_head: str = "full", auto_fp32: bool = True):
+                 chain_mode: str = "alternate", policy_head: str = "full", auto_fp32: bool = True,
+                 calibration_factor: float = 1.6, rescore_round: int = 4):
         """cfg: any object with traj_length, action_samples, horizon, discount, temperature, lmbda,
         plan_guidance (finetune.py RunConfig fields read at learner.py:276,319,342).
         tokenizer_manager: a TokenizerManager (this package's) or {key: {"mean","std","min","max"}}.
@@ -208,12 +209,20 @@ class HipPlanner(GoalMixin, LockstepMixin):
         # exactly the steps that are certain to be resolved when step t is issued (its slot's previous owner is step
         # t - SLOTS) -- whatever has been resolved since.  _delta0: the calibrated bound; _hist[t] = (deviation, need) of step t.
         self._delta0: Optional[float] = self._delta_fixed
-        # full-pass calibrations behind a weight load: enough windows for ~4096 candidates in all (r5 long sweep, 3 windows x 1.5:
-        # the largest deviation of any candidate of 1200 later steps reached 0.98 of the bound at N = 1024 and 1.03 at N = 625),
-        # at least 3, at most 16
-        self._cal_windows = max(1, int(calibration_windows)) if calibration_windows is not None else max(3, min(16, -(-4096 // max(N, 1))))
+        # full-pass calibrations behind a weight load: 16 windows, 8 from N = 2048 on (one fp32 candidate pass each, ~10 ms at
+        # N = 1024: ~0.16 s per weight load).  Round 5 took enough windows for ~4096 candidates (4 at N = 1024): fine on the init
+        # recipe (0 of 3216 long-sweep trials above the bound, maximum 0.994), but on the "trained-like" weight families of round 6
+        # some candidate exceeded the bound in 14 of 1248 trials, by up to 1.28 x -- a window's deviation SCALE depends on its
+        # history, and four windows do not see that.  Raising the factor to 2.1 left 3 of 1248 (<= 1.04) and cost every step
+        # (bench -2 %, the shipped N = 625 config +31 % per pipelined step: delta 6.8 -> 8.7, 18 -> 27 candidates re-scored); 16
+        # windows at the old factor leave 1 of 1248 (1.003) and cost only the weight load (profiles/r06_certificate_sweep*,
+        # r06_ab_calibration_factor.txt, r06_ab_shipped_calibration.txt)
+        self._cal_windows = max(1, int(calibration_windows)) if calibration_windows is not None else max(8, min(16, -(-16384 // max(N, 1))))
         self._cal_left = self._cal_windows  # full-pass calibrations still to run behind the last weight load
-        self.calibration_factor = 1.6
+        # delta = calibration_factor x the largest deviation the calibration passes saw (see _cal_windows above for what round 6
+        # measured: more WINDOWS, not a larger factor, is what the "trained-like" weight families needed)
+        self.calibration_factor = float(calibration_factor)
+        self.rescore_round = max(1, int(rescore_round))  # a first pass's size is rounded up to a multiple of this (_adapt)
         self._hist: Dict[int, tuple] = {}
         self._step_index = 0
         self.generator = generator
@@ -315,7 +324,8 @@ class HipPlanner(GoalMixin, LockstepMixin):
         recent = sorted(seen)[-16:]
         q80 = lambda vals: sorted(vals)[min(len(vals) - 1, int(0.8 * len(vals)))]
         rfirst = min(max(self.race_min, q80([v[2] for _, v in recent]) if recent else 0), self._R)
-        total = max(self.rescore_min, -(-(q80([v[1] for _, v in recent]) + rfirst) // 4) * 4) if recent else self.rescore_min
+        rr = self.rescore_round
+        total = max(self.rescore_min, -(-(q80([v[1] for _, v in recent]) + rfirst) // rr) * rr) if recent else self.rescore_min
         return grow, max(total - rfirst, 1), rfirst
 
     def load_critic(self, q_state_dict, obs_mean, obs_std):

@@ -84,7 +84,8 @@ def _sweep(env, guidance, tau, N, T, H, weight_sets, per_seed, family, fp32_tol=
     mismatches = sample_mismatches = 0
     for ws, (label, sd, st) in enumerate(weight_sets):
         qsd, om, os_ = synth.make_critic(dims, ws) if mode == capi.MODE_CRITIC else (None, None, None)
-        mk = lambda prec: HipPlanner(_cfg(T, N, H, tau, guidance), sd, st, qsd, om, os_, precision=prec, auto_fp32=False,
+        kw = json.loads(os.environ.get("M3PC_SWEEP_KW", "{}"))  # (for the record runs: e.g. '{"calibration_factor": 1.6, "calibration_windows": 16}')
+        mk = lambda prec: HipPlanner(_cfg(T, N, H, tau, guidance), sd, st, qsd, om, os_, precision=prec, auto_fp32=False, **kw,
                                      generator=torch.Generator(device="cuda").manual_seed(1))  # (auto_fp32 off: the certificate itself is what is measured)
         pb, pf = mk("bf16"), mk("fp32")  # (same generator seed: both draw the same Exp(1) variates step for step)
         for t in range(per_seed):
@@ -142,7 +143,7 @@ def _sweep(env, guidance, tau, N, T, H, weight_sets, per_seed, family, fp32_tol=
                         "gap); n_rescored = score-list + race-list candidates re-scored in fp32")
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
-        tag = "_long" if os.environ.get("M3PC_SWEEP_SCALE") else ""
+        tag = ("_long" if os.environ.get("M3PC_SWEEP_SCALE") else "") + os.environ.get("M3PC_SWEEP_TAG", "")
         with open(os.path.join(out_dir, f"r06_certificate_sweep{family}{tag}_{env}_{guidance.split('_')[0]}_N{N}_T{T}.json"), "w") as fh:
             json.dump(dict(summary=summary, rows=rows), fh, indent=0)
     print(json.dumps(summary))

@@ -71,6 +71,27 @@ def test_forward_bf16_close_to_oracle():
     h.close()
 
 
+def test_forward_bf16_many_rows_takes_the_matrix_core_heads():
+    """Round 6: with >= 2048 rows per key the heads' last Linear runs as head_out_mfma_kernel on bf16 hidden rows (17-wide
+    states head included).  Same forward, 2 rows (the row-per-wave kernel on fp32 hidden rows) against 96 sequences (the MFMA
+    kernel): the shared sequences agree to bf16 noise, and both stay within the bf16 tolerance of the fp32 oracle."""
+    T, B = 32, 96  # 96 x 32 = 3072 rows per key
+    dims = synth.Dims(17, 6, T)
+    h, sd, stats, _ = make_handle(dims, max_candidates=8, max_batch=B)
+    masks = O.fd_mask(T, 16)
+    g = torch.Generator().manual_seed(5)
+    toks = {k: torch.randn(B, T, 1, f, generator=g) for k, f in dims.feat.items()}
+    ins = [toks[k][:, :, 0].cuda() for k in synth.KEYS]
+    big = h.forward(ins, [masks[k] for k in synth.KEYS], precision=capi.PREC_BF16)
+    small = h.forward([x[:2].contiguous() for x in ins], [masks[k] for k in synth.KEYS], precision=capi.PREC_BF16)
+    ref = O.mtm_forward(sd, {k: v[:8] for k, v in toks.items()}, masks, 4)
+    for k in ("states", "rewards", "returns"):
+        _assert_close(big[k][:8], ref[k][:, :, 0], 5e-2, f"bf16 many rows {k}")
+        _assert_close(big[k][:2], small[k], 5e-2, f"bf16 many rows vs few rows {k}")
+        assert torch.isfinite(big[k]).all()
+    h.close()
+
+
 # ------------------------------------------------------------------------------------ tokenizer
 def test_tokenizer_roundtrip_and_f64():
     dims = synth.Dims(11, 3, 8, n_embd=64, n_head=2)

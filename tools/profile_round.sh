@@ -4,7 +4,7 @@
 #   the serial-order kernel trace (every launch alone: the `alone` durations) and the config-5 leg.  usage: tools/profile_round.sh r05
 set -euo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}"
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 B="python3 bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline --no-alone-pass"
