@@ -450,15 +450,15 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
         const unsigned vk[2] = {voff(p.ldkv1, 0), voff(p.ldkv1, 1)}, vk2[2] = {voff(p.ldkv2, 0), voff(p.ldkv2, 1)};
         // source rows [0, L) of `src` (row stride ld elements) -> image rows R0 .. R0 + L - 1: the image pieces that hold them, lanes
         // of other rows switched off (a piece at the seam of two segments is issued once for each)
-        auto seg_dma = [&](const bf16_t* src, int ld, const unsigned (&v)[2], char* img, auto r0_c, auto l_c) {
-            constexpr int R0 = decltype(r0_c)::value, L = decltype(l_c)::value;
+        auto seg_dma = [&](const bf16_t* src, int ld, const unsigned (&v)[2], char* img, auto r0_c, auto l_c, auto aux_c) {
+            constexpr int R0 = decltype(r0_c)::value, L = decltype(l_c)::value, AUX = decltype(aux_c)::value;  // (AUX: the item's own rows are read once: streamed)
             if (L == 0) return;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src - (long long)R0 * ld), 0, (unsigned)((R0 + L) * ld * 2), 0x00020000);
 #pragma unroll
             for (int pc = R0 / 4; pc <= (R0 + L - 1) / 4; ++pc) {
                 const bool lo = 4 * pc >= R0 ? true : 4 * pc + r4 >= R0;
                 const bool hi = 4 * pc + 3 < R0 + L ? true : 4 * pc + r4 < R0 + L;
-                if (lo && hi) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(img + pc * 1024), 16, v[pc & 1], pc * 4 * ld * 2, 0, 0);
+                if (lo && hi) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(img + pc * 1024), 16, v[pc & 1], pc * 4 * ld * 2, 0, AUX);
             }
         };
         using I0 = std::integral_constant<int, 0>;
@@ -466,11 +466,12 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
             if (p.no_pipe == 3) return;  // (lab timing: no loads)
             const int b = it >> 2, head = it & 3;  // (4 heads: try_pipe)
             char* const B = lds + buf * APIPE_BUF;
-            seg_dma((const bf16_t*)p.K1 + b * p.kv1_bstride + head * HD, p.ldkv1, vk, B + APIPE_IMG, I0{}, std::integral_constant<int, N1>{});
-            seg_dma((const bf16_t*)p.K2 + head * HD, p.ldkv2, vk2, B + APIPE_IMG, std::integral_constant<int, N1>{}, std::integral_constant<int, SH>{});
-            seg_dma((const bf16_t*)p.Q + b * p.q_bstride + head * HD, p.ldq, vq, B + 2 * APIPE_IMG, std::integral_constant<int, QROW0>{}, std::integral_constant<int, N1>{});
-            seg_dma((const bf16_t*)p.V1 + b * p.kv1_bstride + head * HD, p.ldkv1, vk, B, I0{}, std::integral_constant<int, N1>{});
-            seg_dma((const bf16_t*)p.V2 + head * HD, p.ldkv2, vk2, B, std::integral_constant<int, N1>{}, std::integral_constant<int, SH>{});
+            using AS = std::integral_constant<int, M3PC_STREAM_AUX>;  // the item's own rows: read once; the shared segment: by every item of the head
+            seg_dma((const bf16_t*)p.K1 + b * p.kv1_bstride + head * HD, p.ldkv1, vk, B + APIPE_IMG, I0{}, std::integral_constant<int, N1>{}, AS{});
+            seg_dma((const bf16_t*)p.K2 + head * HD, p.ldkv2, vk2, B + APIPE_IMG, std::integral_constant<int, N1>{}, std::integral_constant<int, SH>{}, I0{});
+            seg_dma((const bf16_t*)p.Q + b * p.q_bstride + head * HD, p.ldq, vq, B + 2 * APIPE_IMG, std::integral_constant<int, QROW0>{}, std::integral_constant<int, N1>{}, AS{});
+            seg_dma((const bf16_t*)p.V1 + b * p.kv1_bstride + head * HD, p.ldkv1, vk, B, I0{}, std::integral_constant<int, N1>{}, AS{});
+            seg_dma((const bf16_t*)p.V2 + head * HD, p.ldkv2, vk2, B, std::integral_constant<int, N1>{}, std::integral_constant<int, SH>{}, I0{});
         };
         if (n_mine > 0) issue(blockIdx.x, 0);
         if (n_mine > 1) issue(blockIdx.x + stride, 1);
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(192, 2) void attn_bf16_pipe_kernel(AttnP p, int n_i
                 const int pc = low_rows ? j : (j < NPC_HI ? 8 + j : 8 + NPC_HI - 1);
                 const int row = 4 * pc + r4;
                 const unsigned off = row < Lk ? (unsigned)((SH ? row : p.orow1 + row) * p.ldo * 2) : 0x80000000u;
-                __builtin_amdgcn_raw_buffer_store_b128(ov[j], o_rs, off + ((c16 ^ (row & 7)) << 4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(ov[j], o_rs, off + ((c16 ^ (row & 7)) << 4), 0, M3PC_STREAM_AUX);
             }
         }
         if (p.stamps && k == 2) st_[6] = __builtin_readcyclecounter();
@@ -702,8 +703,8 @@ __global__ __launch_bounds__(192, 1) void attn_bf16_pipe_dec_kernel(AttnP p, int
                 for (int pc = 0; pc < NPC; ++pc) {
                     const bool ok = 4 * pc + 3 < N1 ? true : 4 * pc + r4 < N1;
                     if (ok) {
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lptr_t)(B + APIPE_IMG + pc * 1024), 16, v[pc & 1], pc * 4 * p.ldkv1 * 2, 0, 0);
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lptr_t)(B + pc * 1024), 16, v[pc & 1], pc * 4 * p.ldkv1 * 2, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lptr_t)(B + APIPE_IMG + pc * 1024), 16, v[pc & 1], pc * 4 * p.ldkv1 * 2, 0, M3PC_STREAM_AUX);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lptr_t)(B + pc * 1024), 16, v[pc & 1], pc * 4 * p.ldkv1 * 2, 0, M3PC_STREAM_AUX);
                     }
                 }
             }
@@ -860,7 +861,7 @@ __global__ __launch_bounds__(192, 1) void attn_bf16_pipe_dec_kernel(AttnP p, int
                 for (int pc = 0; pc < 8; ++pc) {
                     const int row = 4 * pc + r4;
                     const unsigned off = row < p.Lq ? (unsigned)((p.orow1 + row) * p.ldo * 2) : 0x80000000u;
-                    __builtin_amdgcn_raw_buffer_store_b128(ov[pc], o_rs, off + ((c16 ^ (row & 7)) << 4), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov[pc], o_rs, off + ((c16 ^ (row & 7)) << 4), 0, M3PC_STREAM_AUX);
                 }
             }
         }
@@ -938,11 +939,11 @@ __global__ __launch_bounds__(192, 1) void attn_bf16_pipe_mix_kernel(AttnP p, int
                 for (int pc = 0; pc < NPC1; ++pc) {
                     const bool ok = 4 * pc + 3 < N1 ? true : 4 * pc + r4 < N1;
                     if (ok) {
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lptr_t)(B + APIPE_IMG + pc * 1024), 16, v1[pc & 1], pc * 4 * p.ldkv1 * 2, 0, 0);
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lptr_t)(B + pc * 1024), 16, v1[pc & 1], pc * 4 * p.ldkv1 * 2, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lptr_t)(B + APIPE_IMG + pc * 1024), 16, v1[pc & 1], pc * 4 * p.ldkv1 * 2, 0, M3PC_STREAM_AUX);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lptr_t)(B + pc * 1024), 16, v1[pc & 1], pc * 4 * p.ldkv1 * 2, 0, M3PC_STREAM_AUX);
                     }
                 }
-                if (r4 < p.Lq) __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lptr_t)(B + 2 * APIPE_IMG), 16, vq, 0, 0, 0);  // (Lq <= 4: one piece)
+                if (r4 < p.Lq) __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lptr_t)(B + 2 * APIPE_IMG), 16, vq, 0, 0, M3PC_STREAM_AUX);  // (Lq <= 4: one piece)
             }
         };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1099,7 +1100,7 @@ __global__ __launch_bounds__(192, 1) void attn_bf16_pipe_mix_kernel(AttnP p, int
                 for (int pc = 0; pc < 8; ++pc) {
                     const int row = 4 * pc + r4;
                     const unsigned off = row < p.Lq + p.Lq2 ? (unsigned)(row * p.ldo * 2) : 0x80000000u;
-                    __builtin_amdgcn_raw_buffer_store_b128(ov[pc], o_rs, off + ((c16 ^ (row & 7)) << 4), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov[pc], o_rs, off + ((c16 ^ (row & 7)) << 4), 0, M3PC_STREAM_AUX);
                 }
             }
         }

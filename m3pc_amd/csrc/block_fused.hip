@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     {
         const bf16_t* const orow = p.O + (size_t)rld * p.ldo + 8 * lh;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) ofr[s] = *(const u32x4*)(orow + 16 * s);
+        for (int s = 0; s < KS; ++s) ofr[s] = *(const u32x4*)(orow + 16 * s);  // (default policy: as nt loads these fragments -- rows the attention kernel has just written -- took 10 % off the tile, round 6)
     }
     // Residual staging: this wave's 8 KiB of the LayerNorm-2 fragment region are idle until the out-proj is over -- two
     // buffers of one feature tile (32 rows x 128 B) each, filled by LDS-DMA in whole-line pieces (8 rows x 128 B: lane
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rs, (lptr_t)(rstage + (t & 1) * 4096 + pp * 1024), 16, rsrc[pp], 128 * t, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rs, (lptr_t)(rstage + (t & 1) * 4096 + pp * 1024), 16, rsrc[pp], 128 * t, 0, M3PC_STREAM_AUX);
 #endif
     };
     rdma(0);
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
 #pragma unroll
                     for (int pp = 0; pp < 4; ++pp) xs[0][pp] = *(const u32x4 __attribute__((address_space(3)))*)(xrd + (P & 1) * 4096 + pp * 1024);
 #pragma unroll
-                    for (int pp = 0; pp < 4; ++pp) __builtin_amdgcn_raw_buffer_store_b128(xs[0][pp], x_rs, xoff[pp], P * 128, 0);
+                    for (int pp = 0; pp < 4; ++pp) __builtin_amdgcn_raw_buffer_store_b128(xs[0][pp], x_rs, xoff[pp], P * 128, M3PC_STREAM_AUX);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -746,12 +746,12 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
             for (int pp = 0; pp < 4; ++pp) xs[jn & 1][pp] = *(const u32x4 __attribute__((address_space(3)))*)(xrd + (jn & 1) * 4096 + pp * 1024);
             if (jn > 0) {
 #pragma unroll
-                for (int pp = 0; pp < 4; ++pp) __builtin_amdgcn_raw_buffer_store_b128(xs[(jn - 1) & 1][pp], x_rs, xoff[pp], (jn - 1) * 128, 0);
+                for (int pp = 0; pp < 4; ++pp) __builtin_amdgcn_raw_buffer_store_b128(xs[(jn - 1) & 1][pp], x_rs, xoff[pp], (jn - 1) * 128, M3PC_STREAM_AUX);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp) __builtin_amdgcn_raw_buffer_store_b128(xs[(NT - 1) & 1][pp], x_rs, xoff[pp], (NT - 1) * 128, 0);
+        for (int pp = 0; pp < 4; ++pp) __builtin_amdgcn_raw_buffer_store_b128(xs[(NT - 1) & 1][pp], x_rs, xoff[pp], (NT - 1) * 128, M3PC_STREAM_AUX);
         }
 #endif
     }
@@ -869,7 +869,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
                         // so the stores start one slot later; j = 0: nothing is staged yet, the stores go out of the buffer's range)
                         if (STORE && ((g == 6 && k > 0) || (g == 7 && k == 0))) {
                             const int pp = g == 6 ? k - 1 : 3;
-                            __builtin_amdgcn_raw_buffer_store_b128(sreg[pp], q_rs, j >= 2 ? srow[pp] : 0x80000000u, ((j - 2) >> 1) * 128, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(sreg[pp], q_rs, j >= 2 ? srow[pp] : 0x80000000u, ((j - 2) >> 1) * 128, M3PC_STREAM_AUX);
                         }
 #endif
                     });
@@ -894,7 +894,7 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const u32x4 v = *(const u32x4 __attribute__((address_space(3)))*)(srd + (((3 * NT - 2) >> 1) & 1) * 4096 + k * 1024);
-            __builtin_amdgcn_raw_buffer_store_b128(v, q_rs, srow[k], ((3 * NT - 2) >> 1) * 128, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v, q_rs, srow[k], ((3 * NT - 2) >> 1) * 128, M3PC_STREAM_AUX);
         }
 #endif
     } else if constexpr (HEADS) {
@@ -1356,7 +1356,7 @@ __global__ __launch_bounds__(256, 1) void kv_fused_kernel(KvFusedP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
                     if (STORE && ((g == 6 && k > 0) || (g == 7 && k == 0))) {  // (behind the sync and stage ph + 2's last piece)
                         const int pp = g == 6 ? k - 1 : 3;
-                        __builtin_amdgcn_raw_buffer_store_b128(sreg[pp], kv_rs, j >= 2 ? srow[pp] : 0x80000000u, ((j - 2) >> 1) * 128, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(sreg[pp], kv_rs, j >= 2 ? srow[pp] : 0x80000000u, ((j - 2) >> 1) * 128, M3PC_STREAM_AUX);
                     }
 #endif
                 });
@@ -1380,7 +1380,7 @@ __global__ __launch_bounds__(256, 1) void kv_fused_kernel(KvFusedP p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const u32x4 v = *(const u32x4 __attribute__((address_space(3)))*)(srd + (((2 * NT - 2) >> 1) & 1) * 4096 + k * 1024);
-        __builtin_amdgcn_raw_buffer_store_b128(v, kv_rs, srow[k], ((2 * NT - 2) >> 1) * 128, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, kv_rs, srow[k], ((2 * NT - 2) >> 1) * 128, M3PC_STREAM_AUX);
     }
 #endif
     stamps[5] = __builtin_readcyclecounter();

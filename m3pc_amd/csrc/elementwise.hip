@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(EmbedP p, int CB, int n
                     o[1] = (bf16_t)x[i].y;
                     o[2] = (bf16_t)x[i].z;
                     o[3] = (bf16_t)x[i].w;
-                    *(bf16x4_t*)(p.Xb + row * d + (i * 64 + lane) * 4) = o;
+                    stream_store(o, (bf16x4_t*)(p.Xb + row * d + (i * 64 + lane) * 4));
                 }
             } else {
 #pragma unroll
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(EmbedP p, int CB, int n
                 o[1] = (bf16_t)y[i].y;
                 o[2] = (bf16_t)y[i].z;
                 o[3] = (bf16_t)y[i].w;
-                *(bf16x4_t*)(dst + (i * 64 + lane) * 4) = o;
+                stream_store(o, (bf16x4_t*)(dst + (i * 64 + lane) * 4));
             }
         }
     }

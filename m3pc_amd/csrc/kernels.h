@@ -21,6 +21,23 @@ static inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
 
 // Row remap used by GEMM / LayerNorm operands whose logical rows are a strided subset of a
 // larger tensor: physical_row = (r / rpg) * gstride + (r % rpg) + off.   rpg == 0: identity.
+// Cache policy of activation rows that are written once and read once (the residual stream, Q|K|V, K|V, attention outputs: ~2 GB
+// of a plan step's HBM traffic): 0 = default (what ships), 2 = nt (non-temporal).  Round 6 measured nt, same box, three runs each
+// (tools/ab_libs.sh on -DM3PC_STREAM_AUX builds, profiles/r06_ab_nt_streams.txt): on the fused kernels' residual pieces and row
+// stores +0.6 %; on those plus the attention kernels' own-row pieces / stores and the embedding's stores +0.4 % (one pair of three
+// the other way); with the fused tail's O / Z fragment LOADS and LayerNorm-row stores too -4.5 % (a tile alone 149 -> 165 us: rows
+// another kernel has just written are in the caches, and an nt load does not take them from there).  Inside the noise: not adopted.
+#ifndef M3PC_STREAM_AUX
+#define M3PC_STREAM_AUX 0
+#endif
+template <typename V>
+__device__ __forceinline__ V stream_load(const V* p) { return M3PC_STREAM_AUX ? __builtin_nontemporal_load(p) : *p; }
+template <typename V>
+__device__ __forceinline__ void stream_store(V v, V* p) {
+    if (M3PC_STREAM_AUX) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 struct RowMap {
     int rpg;
     int gstride;
