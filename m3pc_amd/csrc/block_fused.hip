@@ -358,12 +358,14 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     // full vmcnt(0), which would drain the weight stream every phase)
     const __amdgpu_buffer_rsrc_t r_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.rowtab ? p.rowtab : p.res), 0, 0xfffffff0u, 0x00020000);
     (void)r_rs;
-    auto rdma = [&](int t) {  // residual values of feature tile t (XB: of the tile pair 2 t, 2 t + 1: 128 bytes of bf16) -> buffer t & 1
+    auto rdma_piece = [&](int t, int pp) {  // piece pp (8 rows) of the residual values of feature tile t (XB: of the tile pair 2 t, 2 t + 1: 128 bytes of bf16) -> buffer t & 1
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-        for (int pp = 0; pp < 4; ++pp)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rs, (lptr_t)(rstage + (t & 1) * 4096 + pp * 1024), 16, rsrc[pp], 128 * t, 0, M3PC_STREAM_AUX);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rs, (lptr_t)(rstage + (t & 1) * 4096 + pp * 1024), 16, rsrc[pp], 128 * t, 0, M3PC_STREAM_AUX);
 #endif
+    };
+    auto rdma = [&](int t) {
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) rdma_piece(t, pp);
     };
     rdma(0);
     rdma(1);
@@ -432,52 +434,81 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
 
     // ---- out-proj: phase jn = the 32 k-steps of feature tile jn.  Its accumulator starts at the residual + bias of its 32
     // features, read back from the staging buffer its pieces were sent to two phases ago.
-    auto acc_init = [&](int jn) {
+    // Tile jn's start values in two parts -- the read-back of its residual values and bias, then a quarter at a time the sum into
+    // the accumulator -- so that they ride in the last MFMA slots of phase jn - 1 (round 6; in front of the phase they cost ~0.4 k of
+    // its 1.75 k clocks with no MFMA in flight).  The residual of tile jn is in LDS by then: the stage sync of phase jn - 1 lets only
+    // the 11 (7) youngest vector-memory operations stay in flight, and tile jn's pieces are older than those.
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    f32x4 ai_x[4], ai_b[4];
+    u32x2 ai_v[4];
+    (void)ai_x;
+    (void)ai_v;
+    auto acc_init_reads = [&](int jn) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4 x;
-            if constexpr (XB) {  // features 32 jn + 8 q + 4 lh .. of the pair's line: chunk 4 (jn & 1) + q, its half lh
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                const u32x2 v = *(const u32x2 __attribute__((address_space(3)))*)(rback + ((jn >> 1) & 1) * 4096 + (((4 * (jn & 1) + q) ^ (l31 & 7)) << 4) + 8 * lh);
-                x[0] = __builtin_bit_cast(float, v[0] << 16);
-                x[1] = __builtin_bit_cast(float, v[0] & 0xffff0000u);
-                x[2] = __builtin_bit_cast(float, v[1] << 16);
-                x[3] = __builtin_bit_cast(float, v[1] & 0xffff0000u);
-            } else {
-                x = *(const f32x4 __attribute__((address_space(3)))*)(rback + (jn & 1) * 4096 + (((2 * q + lh) ^ (l31 & 7)) << 4));
-            }
-            const f32x4 b = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_BO + 32 * jn + 8 * q);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[jn][4 * q + i] = x[i] + b[i];
+            if constexpr (XB)  // features 32 jn + 8 q + 4 lh .. of the pair's line: chunk 4 (jn & 1) + q, its half lh
+                ai_v[q] = *(const u32x2 __attribute__((address_space(3)))*)(rback + ((jn >> 1) & 1) * 4096 + (((4 * (jn & 1) + q) ^ (l31 & 7)) << 4) + 8 * lh);
+            else
+                ai_x[q] = *(const f32x4 __attribute__((address_space(3)))*)(rback + (jn & 1) * 4096 + (((2 * q + lh) ^ (l31 & 7)) << 4));
+            ai_b[q] = *(const f32x4 __attribute__((address_space(3)))*)(tabl + T_BO + 32 * jn + 8 * q);
         }
     };
-    // vmcnt bookkeeping (operations complete in issue order): the 4 pieces of residual tile jn + 2 are issued when phase jn
-    // STARTS (right behind acc_init(jn), which has just emptied their buffer): they have two phases to land -- with one phase
+    auto acc_init_quarter = [&](int jn, int q) {
+        f32x4 x;
+        if constexpr (XB) {
+            x[0] = __builtin_bit_cast(float, ai_v[q][0] << 16);
+            x[1] = __builtin_bit_cast(float, ai_v[q][0] & 0xffff0000u);
+            x[2] = __builtin_bit_cast(float, ai_v[q][1] << 16);
+            x[3] = __builtin_bit_cast(float, ai_v[q][1] & 0xffff0000u);
+        } else {
+            x = ai_x[q];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[jn][4 * q + i] = x[i] + ai_b[q][i];
+    };
+    // LayerNorm-2's row sums ride under the out-proj too (round 6): tile jn - 1 is final when phase jn runs -- one element per
+    // second MFMA slot, in the order the separate pass summed them (tile by tile, register by register: the same bits); only the
+    // last tile's 16 elements are left for behind the out-proj
+    float s1o = 0.f, s2o = 0.f;
+    auto ln2_stat = [&](float x) {
+        s1o += x;
+        s2o = fmaf(x, x, s2o);
+    };
+    // vmcnt bookkeeping (operations complete in issue order): the 4 pieces of residual tile jn + 2 are issued in the first four
+    // MFMA groups of phase jn (their buffer was emptied by the read-back of tile jn, in phase jn - 1): they have two phases to land -- with one phase
     // (issued when phase jn + 1 starts) a tile alone on the chip measures the same, but beside the other streams' kernels every
     // phase waits for its residual tile and a pipelined step takes 2.2 ms instead of 1.25.
     // At the sync of phase jn the operations issued behind stage (jn + 1)'s last piece are one weight piece, these 4 and the
-    // phase's first 6 pieces: vmcnt(11).  In front of acc_init(jn) the operations behind tile jn's pieces are 8 weight pieces,
-    // the 4 of tile jn + 1 and 8 more weight pieces: vmcnt(20) (16 behind the last tile's).  Wave-private data: no barrier.
-    // XB: the prologue brought the pairs 0, 1 (tiles 0..3); pair P + 2 is sent for when phase 2 P + 1 starts -- right behind
-    // acc_init(2 P + 1), the last reader of its buffer -- and has three phases to land.  Behind the pieces of pair P (P >= 2) and in
-    // front of acc_init(2 P): three phases of 8 weight pieces + the 4 of pair P + 1: vmcnt(28) (24 behind the last pair's).
-#define OUTPROJ(jn, SL, NR, WAIT, RD)                                                                                        \
-    if ((WAIT) < 63) asm volatile("s_waitcnt vmcnt(" #WAIT ")" ::: "memory");                                                \
-    acc_init(jn);                                                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                                       \
-    if ((RD) >= 0) rdma(RD);                                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                                                       \
-    phase_n(jn, SL{}, std::integral_constant<int, NR>{}, no_extra, [&](int i, u32x4 a, int) { mfma_a(acc[jn], a, ofr[i]); }, no_valu);
+    // phase's first 6 pieces: vmcnt(11).  Wave-private data: no barrier.
+    // XB: the prologue brought the pairs 0, 1 (tiles 0..3); pair P + 2 is sent for when phase 2 P + 1 starts -- its buffer's last
+    // reader was the read-back of tile 2 P + 1, in phase 2 P -- and has three phases to land.
+#define OUTPROJ(jn, SL, NR, RD)                                                                                              \
+    phase_n(jn, SL{}, std::integral_constant<int, NR>{}, no_extra, [&](int i, u32x4 a, int) { mfma_a(acc[jn], a, ofr[i]); },         \
+            [&](int g, int k) {                                                                                              \
+                if ((RD) >= 0 && g < 4 && k == 3) rdma_piece((RD) >= 0 ? (RD) : 0, g);  /* (in front of the stage sync: counted there) */ \
+                if ((jn) > 0 && (k & 1) == 0) ln2_stat(acc[(jn) > 0 ? (jn) - 1 : 0][2 * g + (k >> 1)]);                      \
+                if ((jn) + 1 < NT) {                                                                                         \
+                    constexpr int T1 = (jn) + 1 < NT ? (jn) + 1 : 0;                                                         \
+                    if (g == 6 && k == 0) acc_init_reads(T1);                                                                \
+                    if (g == 6 && k >= 2) acc_init_quarter(T1, k - 2);                                                       \
+                    if (g == 7 && k < 2) acc_init_quarter(T1, 2 + k);                                                        \
+                }                                                                                                            \
+            });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (tile 0: the prologue's pieces -- waited for above already)
+    acc_init_reads(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc_init_quarter(0, q);
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (XB) {
-        OUTPROJ(0, S0, 0, 63, -1) OUTPROJ(1, S1, 4, 63, 2) OUTPROJ(2, S2, 0, 63, -1) OUTPROJ(3, S0, 4, 63, 3)
-        OUTPROJ(4, S1, 0, 28, -1) OUTPROJ(5, S2, 4, 63, 4) OUTPROJ(6, S0, 0, 28, -1) OUTPROJ(7, S1, 4, 63, 5)
-        OUTPROJ(8, S2, 0, 28, -1) OUTPROJ(9, S0, 4, 63, 6) OUTPROJ(10, S1, 0, 28, -1) OUTPROJ(11, S2, 4, 63, 7)
-        OUTPROJ(12, S0, 0, 28, -1) OUTPROJ(13, S1, 0, 63, -1) OUTPROJ(14, S2, 0, 24, -1) OUTPROJ(15, S0, 0, 63, -1)
+        OUTPROJ(0, S0, 0, -1) OUTPROJ(1, S1, 4, 2) OUTPROJ(2, S2, 0, -1) OUTPROJ(3, S0, 4, 3)
+        OUTPROJ(4, S1, 0, -1) OUTPROJ(5, S2, 4, 4) OUTPROJ(6, S0, 0, -1) OUTPROJ(7, S1, 4, 5)
+        OUTPROJ(8, S2, 0, -1) OUTPROJ(9, S0, 4, 6) OUTPROJ(10, S1, 0, -1) OUTPROJ(11, S2, 4, 7)
+        OUTPROJ(12, S0, 0, -1) OUTPROJ(13, S1, 0, -1) OUTPROJ(14, S2, 0, -1) OUTPROJ(15, S0, 0, -1)
     } else {
-        OUTPROJ(0, S0, 4, 0, 2) OUTPROJ(1, S1, 4, 20, 3) OUTPROJ(2, S2, 4, 20, 4) OUTPROJ(3, S0, 4, 20, 5) OUTPROJ(4, S1, 4, 20, 6)
-        OUTPROJ(5, S2, 4, 20, 7) OUTPROJ(6, S0, 4, 20, 8) OUTPROJ(7, S1, 4, 20, 9) OUTPROJ(8, S2, 4, 20, 10) OUTPROJ(9, S0, 4, 20, 11)
-        OUTPROJ(10, S1, 4, 20, 12) OUTPROJ(11, S2, 4, 20, 13) OUTPROJ(12, S0, 4, 20, 14) OUTPROJ(13, S1, 4, 20, 15)
-        OUTPROJ(14, S2, 0, 20, -1) OUTPROJ(15, S0, 0, 16, -1)
+        OUTPROJ(0, S0, 4, 2) OUTPROJ(1, S1, 4, 3) OUTPROJ(2, S2, 4, 4) OUTPROJ(3, S0, 4, 5) OUTPROJ(4, S1, 4, 6)
+        OUTPROJ(5, S2, 4, 7) OUTPROJ(6, S0, 4, 8) OUTPROJ(7, S1, 4, 9) OUTPROJ(8, S2, 4, 10) OUTPROJ(9, S0, 4, 11)
+        OUTPROJ(10, S1, 4, 12) OUTPROJ(11, S2, 4, 13) OUTPROJ(12, S0, 4, 14) OUTPROJ(13, S1, 4, 15)
+        OUTPROJ(14, S2, 0, -1) OUTPROJ(15, S0, 0, -1)
     }
 #undef OUTPROJ
     mfma_done_a(acc);  // (the accumulators are next read by v_accvgpr_read)
@@ -486,16 +517,14 @@ __global__ __launch_bounds__(256, 1) void block_fused_kernel(BlockP p) {
     // ---- LayerNorm-2 of X' (in the accumulators) -> act (bf16 B-operand fragments of FFN1)
     u32x4 act[KS - ACT_LDS];  // k-steps 0..23; k-steps 24..31 go to this wave's LDS region
     {
-        float s1 = 0.f, s2 = 0.f;
+        float s1 = s1o, s2 = s2o;  // (tiles 0..14: summed under the out-proj)
 #pragma unroll
-        for (int jn = 0; jn < NT; ++jn)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float x = acc[jn][e];
-                s1 += x;
-                s2 = fmaf(x, x, s2);
-                if (e == 15) __builtin_amdgcn_sched_barrier(0);  // (keeps the accumulator reads of one tile together)
-            }
+        for (int e = 0; e < 16; ++e) {
+            const float x = acc[NT - 1][e];
+            s1 += x;
+            s2 = fmaf(x, x, s2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         s1 = half_swap_sum(s1);
         s2 = half_swap_sum(s2);
         const float mean = s1 * (1.0f / BD);
