@@ -297,3 +297,44 @@ def test_auto_fp32_fallback_on_weights_that_make_the_certificate_expensive():
     assert pb.last.get("expect_return_bf16") is not None
     pb.handle.close()
     pf.handle.close()
+
+
+def test_auto_fp32_fallback_is_the_same_step_at_any_pipeline_depth():
+    """The fallback is decided on the steps up to index - SLOTS (like every adaptive quantity of the certified re-score), so a
+    pipelined run switches at the same step as the serial one and returns the same actions, bit for bit."""
+    N, T, H = 1024, 32, 16
+    dims = synth.Dims(11, 3, T)
+    sd0, st0 = synth.make_state_dict(dims, 2), synth.make_tokenizer_stats(dims, 2)
+    sd4, st4 = synth.trained_like(sd0, st0, seed=2, linear_scale=4.0, returns_std_scale=0.1)
+    n_steps = 4 + capi.SLOTS + 4
+
+    def planner():
+        return HipPlanner(_cfg(T, N, H), sd4, st4, None, precision="bf16", generator=torch.Generator(device="cuda").manual_seed(5),
+                          pipeline_depth=3)
+
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ps = planner()
+        serial, sw_serial = [], None
+        for t in range(n_steps):
+            serial.append(ps.action_sample(_window(dims, t), plan=True, eval=(t % 2 == 0), rtg=3.0).clone())
+            if ps.fp32_fallback and sw_serial is None:
+                sw_serial = t
+        ps.handle.close()
+        pp = planner()
+        got, flight, sw_pipe = [None] * n_steps, [], None
+        for t in range(n_steps):
+            flight.append((t, pp.plan_async(_window(dims, t), eval=(t % 2 == 0), rtg=3.0)))
+            if pp.fp32_fallback and sw_pipe is None:
+                sw_pipe = t  # (decided when step t was issued)
+            while len(flight) > 3:
+                i, tk = flight.pop(0)
+                got[i] = tk.result().clone()
+        for i, tk in flight:
+            got[i] = tk.result().clone()
+        torch.cuda.synchronize()
+        pp.handle.close()
+    assert sw_serial == 3 + capi.SLOTS and sw_pipe == sw_serial, (sw_serial, sw_pipe)
+    bad = [i for i, (a, b) in enumerate(zip(serial, got)) if not torch.equal(a, b)]
+    assert not bad, bad
