@@ -1267,25 +1267,49 @@ __global__ __launch_bounds__(256, 1) void kv_fused_kernel(KvFusedP p) {
     using NR0 = std::integral_constant<int, 0>;
     using NR4 = std::integral_constant<int, 4>;
 
-    // ---- embedding: phase jn = the 32 k-steps of feature tile jn (vmcnt bookkeeping as the out-proj of block_fused_kernel)
-    auto acc_init = [&](int jn) {
+    // ---- embedding: phase jn = the 32 k-steps of feature tile jn (vmcnt bookkeeping as the out-proj of block_fused_kernel, and --
+    // round 6 -- the same bookkeeping in the MFMA slots: tile jn + 1's start values are read back behind phase jn's stage sync and
+    // written into the accumulator a quarter per slot, the four table pieces of tile jn + 2 go out one per MFMA group in front of
+    // the sync, norm1's row sums of tile jn - 1 take every second slot, in the order the separate pass summed them)
+    f32x4 ai_x[4];
+    auto acc_init_reads = [&](int jn) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 x = *(const f32x4 __attribute__((address_space(3)))*)(rback + (jn & 1) * 4096 + (((2 * q + lh) ^ (l31 & 7)) << 4));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[jn][4 * q + i] = x[i];
-        }
+        for (int q = 0; q < 4; ++q)
+            ai_x[q] = *(const f32x4 __attribute__((address_space(3)))*)(rback + (jn & 1) * 4096 + (((2 * q + lh) ^ (l31 & 7)) << 4));
     };
-#define KV_EMB(jn, SL, NR, WAIT)                                                                                             \
-    asm volatile("s_waitcnt vmcnt(" #WAIT ")" ::: "memory");                                                                 \
-    acc_init(jn);                                                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                                       \
-    if ((jn) + 2 < NT) rdma((jn) + 2);                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                                       \
-    phase_n(jn, SL{}, std::integral_constant<int, NR>{}, [&](int i, u32x4 a, int) { mfma_a(acc[jn], a, ofr[i]); }, no_valu);
-    KV_EMB(0, S0, 4, 0) KV_EMB(1, S1, 4, 20) KV_EMB(2, S2, 4, 20) KV_EMB(3, S0, 4, 20) KV_EMB(4, S1, 4, 20) KV_EMB(5, S2, 4, 20)
-    KV_EMB(6, S0, 4, 20) KV_EMB(7, S1, 4, 20) KV_EMB(8, S2, 4, 20) KV_EMB(9, S0, 4, 20) KV_EMB(10, S1, 4, 20) KV_EMB(11, S2, 4, 20)
-    KV_EMB(12, S0, 4, 20) KV_EMB(13, S1, 4, 20) KV_EMB(14, S2, 0, 20) KV_EMB(15, S0, 0, 16)
+    auto acc_init_quarter = [&](int jn, int q) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[jn][4 * q + i] = ai_x[q][i];
+    };
+    auto rdma_piece = [&](int t, int pp) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rs, (lptr_t)(rstage + (t & 1) * 4096 + pp * 1024), 16, rsrc[pp], 128 * t, 0, 0);
+#endif
+    };
+    float s1o = 0.f, s2o = 0.f;
+    auto ln_stat = [&](float x) {
+        s1o += x;
+        s2o = fmaf(x, x, s2o);
+    };
+#define KV_EMB(jn, SL, NR)                                                                                                   \
+    phase_n(jn, SL{}, std::integral_constant<int, NR>{}, [&](int i, u32x4 a, int) { mfma_a(acc[jn], a, ofr[i]); },            \
+            [&](int g, int k) {                                                                                              \
+                if ((jn) + 2 < NT && g < 4 && k == 3) rdma_piece((jn) + 2 < NT ? (jn) + 2 : 0, g);                            \
+                if ((jn) > 0 && (k & 1) == 0) ln_stat(acc[(jn) > 0 ? (jn) - 1 : 0][2 * g + (k >> 1)]);                       \
+                if ((jn) + 1 < NT) {                                                                                         \
+                    constexpr int T1 = (jn) + 1 < NT ? (jn) + 1 : 0;                                                         \
+                    if (g == 6 && k == 0) acc_init_reads(T1);                                                                \
+                    if (g == 6 && k >= 2) acc_init_quarter(T1, k - 2);                                                       \
+                    if (g == 7 && k < 2) acc_init_quarter(T1, 2 + k);                                                        \
+                }                                                                                                            \
+            });
+    acc_init_reads(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc_init_quarter(0, q);
+    __builtin_amdgcn_sched_barrier(0);
+    KV_EMB(0, S0, 4) KV_EMB(1, S1, 4) KV_EMB(2, S2, 4) KV_EMB(3, S0, 4) KV_EMB(4, S1, 4) KV_EMB(5, S2, 4)
+    KV_EMB(6, S0, 4) KV_EMB(7, S1, 4) KV_EMB(8, S2, 4) KV_EMB(9, S0, 4) KV_EMB(10, S1, 4) KV_EMB(11, S2, 4)
+    KV_EMB(12, S0, 4) KV_EMB(13, S1, 4) KV_EMB(14, S2, 0) KV_EMB(15, S0, 0)
 #undef KV_EMB
     mfma_done_a(acc);
     stamps[2] = __builtin_readcyclecounter();
@@ -1293,16 +1317,14 @@ __global__ __launch_bounds__(256, 1) void kv_fused_kernel(KvFusedP p) {
     // ---- norm1 of the embedded rows -> act (bf16 B-operand fragments, kept where the accumulators were)
     u32x4 act[KS];
     {
-        float s1 = 0.f, s2 = 0.f;
+        float s1 = s1o, s2 = s2o;  // (tiles 0..14: summed under the embedding)
 #pragma unroll
-        for (int jn = 0; jn < NT; ++jn)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float x = acc[jn][e];
-                s1 += x;
-                s2 = fmaf(x, x, s2);
-                if (e == 15) __builtin_amdgcn_sched_barrier(0);
-            }
+        for (int e = 0; e < 16; ++e) {
+            const float x = acc[NT - 1][e];
+            s1 += x;
+            s2 = fmaf(x, x, s2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         s1 = half_swap_sum(s1);
         s2 = half_swap_sum(s2);
         const float mean = s1 * (1.0f / BD);
