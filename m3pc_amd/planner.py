@@ -149,8 +149,8 @@ class HipPlanner(GoalMixin, LockstepMixin):
             ``certify_sample``) -- and the library counts who can still beat the best re-scored fp32 score (``need``) or win the
             draw (``need_race``); a certificate that asks for more gets a second pass (at most ``rescore_max`` / 32 through the
             lists; beyond that the whole set goes through a slow path with a warning, ``last["saturated"]``).  delta is
-            calibrated per weight load on FULL fp32 candidate passes over the first few steps (``calibration_windows``, default:
-            enough for ~4096 candidates; 1.6 x the largest deviation from the median over all of them), checked on every step's
+            calibrated per weight load on FULL fp32 candidate passes over the first steps (``calibration_windows``, default 16,
+            8 from N = 2048 on; ``calibration_factor`` = 1.6 x the largest deviation from the median over all of them), checked on every step's
             re-scored set and raised when 1.5 x what that step saw is more (``delta_grown``), or fixed by ``rescore_delta``.
             ``planner.last`` reports n_rescored / n_race (score / race entries re-scored), n_in_window / need_race (what the
             first certificates asked for), min_margin_outside, shift, deviation and delta.  One 32-byte device-to-host read per
