@@ -256,3 +256,46 @@ def test_fused_heads_ticket_stress():
             assert not bad, bad[:8]
             got = []
     hd.close()
+
+
+_HEADCMP = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[2])
+from m3pc_amd import capi, synth
+dims = synth.Dims(11, 3, 32)
+H, CAP = 16, 256
+hd = capi.Handle(dims.state_dim, dims.action_dim, dims.traj_length, max_candidates=CAP, max_batch=1, max_rescore=CAP)
+hd.load_weights(synth.make_state_dict(dims, 0))
+st = synth.make_tokenizer_stats(dims, 0)
+for k, name in enumerate(synth.KEYS):
+    hd.set_tokenizer(k, st[name]["mean"], st[name]["std"], normalize=(name != "actions"))
+hist = synth.make_history(dims, 0)
+s, a, r = (torch.from_numpy(hist[k][100:132]).cuda() for k in ("observations", "actions", "rewards"))
+hd.policy_pass(capi.MODE_RTG, s, a, r, H, 3.0, slot=0)
+cand = torch.rand((CAP, H, dims.action_dim), device="cuda", generator=torch.Generator(device="cuda").manual_seed(9)) * 2 - 1
+np.savez(sys.argv[1], **{str(n): hd.score_actions(capi.MODE_RTG, s, a, r, cand[:n], None, H, 0.6, 0.99, slot=0).cpu().numpy()
+                         for n in (1, 8, 17, 64, 129, 256)})
+"""
+
+
+def test_fused_heads_agree_with_the_unfused_chain(tmp_path):
+    """The one-launch fp32 scalar heads (head_f32_fused_kernel) against the chain they replaced (GEMM + head_out launches; the lab
+    build's M3PC_NO_HEAD_F32_FUSED switch), few-row scoring passes of 1..256 candidates in fresh processes: the two sum the same
+    products in different orders, so they agree to fp32 rounding (measured <= 9e-7 of the score scale), not bit for bit."""
+    import subprocess
+    import sys
+
+    from hip_util import lab_library
+
+    lab_library()  # (built if stale)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lab = os.path.join(root, "m3pc_amd", "libm3pc_hip_lab.so")
+    outs = {}
+    for tag, extra in (("fused", {}), ("unfused", {"M3PC_NO_HEAD_F32_FUSED": "1"})):
+        path = str(tmp_path / f"{tag}.npz")
+        env = dict(os.environ, M3PC_LIB=lab, **extra)
+        subprocess.run([sys.executable, "-c", _HEADCMP, path, root], env=env, check=True, timeout=300)
+        outs[tag] = np.load(path)
+    for k in outs["fused"].files:
+        a, b = outs["fused"][k], outs["unfused"][k]
+        assert np.isfinite(a).all() and np.abs(a - b).max() <= 5e-6 * np.abs(a).max(), (k, float(np.abs(a - b).max()), float(np.abs(a).max()))
