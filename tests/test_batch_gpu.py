@@ -341,3 +341,53 @@ def test_planner_from_checkpoint_files_matches_the_oracle(tmp_path):
     assert int(p.last["argmax"].item()) == ref["argmax"]
     assert float((ev.cpu() - ref["eval_action"]).abs().max()) < 1e-4
     p.handle.close()
+
+
+_XB16 = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[2])
+from m3pc_amd import capi, synth
+dims = synth.Dims(11, 3, 32)
+N, H = 1024, 16
+hd = capi.Handle(dims.state_dim, dims.action_dim, dims.traj_length, max_candidates=N, max_batch=1, max_rescore=64)
+hd.load_weights(synth.make_state_dict(dims, 0))
+st = synth.make_tokenizer_stats(dims, 0)
+for k, name in enumerate(synth.KEYS):
+    hd.set_tokenizer(k, st[name]["mean"], st[name]["std"], normalize=(name != "actions"))
+hist = synth.make_history(dims, 0)
+s, a, r = (torch.from_numpy(hist[k][469:501]).cuda() for k in ("observations", "actions", "rewards"))
+eps = synth.make_eps(N, dims, 1).cuda()
+out = {}
+for prec, tag in ((capi.PREC_BF16, "bf16"), (capi.PREC_FP32, "fp32")):
+    out[tag] = hd.plan_step(capi.MODE_RTG, s, a, r, eps, H, 3.0, 0.6, 0.99, N, precision=prec)["expect_return"].cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_bf16_residual_stream_is_what_the_candidate_pass_runs(tmp_path):
+    """Round 6: a bf16 candidate pass of the headline shape carries its residual stream between the encoder layers in bf16.  Fresh
+    processes on the lab build with and without M3PC_NO_BF16_RESIDUAL: the scores differ (the path is taken, not silently the fp32
+    rows), the fp32 pass is untouched bit for bit, and the deviation from it (about its median: the common shift the certificate
+    removes) stays what it was -- the study's finding (oracle/lowprec_study.py, delta x 0.95-1.25) on the HIP path."""
+    import subprocess
+    import sys
+
+    from hip_util import lab_library
+
+    lab_library()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lab = os.path.join(root, "m3pc_amd", "libm3pc_hip_lab.so")
+    outs = {}
+    for tag, extra in (("xb16", {}), ("x32", {"M3PC_NO_BF16_RESIDUAL": "1"})):
+        path = str(tmp_path / f"{tag}.npz")
+        subprocess.run([sys.executable, "-c", _XB16, path, root], env=dict(os.environ, M3PC_LIB=lab, **extra), check=True, timeout=300)
+        outs[tag] = np.load(path)
+    assert np.array_equal(outs["xb16"]["fp32"], outs["x32"]["fp32"])
+    assert not np.array_equal(outs["xb16"]["bf16"], outs["x32"]["bf16"]), "the bf16 residual path was not taken"
+    f = outs["xb16"]["fp32"]
+    dev = {}
+    for tag in ("xb16", "x32"):
+        d = outs[tag]["bf16"] - f
+        dev[tag] = float(np.abs(d - np.median(d)).max())
+    assert dev["xb16"] <= 1.5 * dev["x32"] + 1e-3, dev
+    print("largest deviation of (bf16 - fp32) from its median: bf16 residual %.3f, fp32 residual %.3f" % (dev["xb16"], dev["x32"]))
