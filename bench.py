@@ -951,7 +951,7 @@ def extras(args, dims, cfg, hist, planner, S, A):
         pl_ = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), None, precision="bf16",
                          generator=torch.Generator(device="cuda").manual_seed(1), max_batch=E, max_windows=E)
         hs = [dict(synth.make_history(dims, i), path_length=500) for i in range(E)]
-        for _ in range(4):
+        for _ in range(max(4, -(-pl_._cal_windows // E) + 2)):  # (the lock-step calls calibrate over the same number of windows, untimed)
             pl_.action_sample_batch(hs, eval=True, rtg=3.0, lockstep=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -72,11 +72,18 @@ class LockstepMixin:
                 smode = capi.MODE_RTG if mode == capi.MODE_RTG else capi.MODE_CRITIC
                 R = self._R if bound else 0
                 if bound:
-                    if self._delta is None:  # calibrate on window 0 of the group: all of its candidates in fp32
-                        f32 = self.handle.score_actions(smode, s[0], a[0], r[0], acts[0], None, h, lmbda, float(cfg.discount))
-                        d = er[0] - f32
-                        self._delta = max(self.calibration_factor * float((d - d.median()).abs().max()), 1e-6 * float(f32.abs().max()),
-                                          1e-30)
+                    if self._delta_fixed is None and (self._delta0 is None or self._cal_left > 0):
+                        # calibrate on this group's windows -- all of a window's candidates in fp32 -- until the weight load's
+                        # calibration windows are used up (round 6: the same count as the single-window steps take, certificate
+                        # sweeps of DESIGN section 5; round 5 took window 0 of the first group only)
+                        d0 = self._delta0 or 0.0
+                        n_cal = max(1, min(Eg, self._cal_left))
+                        for w in range(n_cal):
+                            f32 = self.handle.score_actions(smode, s[w], a[w], r[w], acts[w], None, h, lmbda, float(cfg.discount))
+                            d = er[w] - f32
+                            d0 = max(d0, self.calibration_factor * float((d - d.median()).abs().max()), 1e-6 * float(f32.abs().max()), 1e-30)
+                        self._delta0 = d0
+                        self._cal_left = max(0, self._cal_left - n_cal)
                     # The certified re-score of certificate.py, for all windows of the group at once: the kmin best candidates
                     # by score and the rfirst best by race key of every window in ONE fp32 pass, merge + select enqueued for
                     # every window, THEN one host read of the certificates; windows that ask for more get passes of their own.
@@ -129,7 +136,8 @@ class LockstepMixin:
                         ops_w.merge_select(ctx.nd[w], ctx.rd[w], delta)
                     certs[w] = _resolve_certificate(self, N, kmax, R, ctx.nd[w], ctx.rd[w], delta, ops_w)
                     if certs[w]["delta"] > delta:  # this window saw a larger deviation than the bound: raised for everybody from here on
-                        delta = self._delta = certs[w]["delta"]
+                        delta = certs[w]["delta"]
+                        self._delta0 = max(self._delta0, delta)  # (the base bound, not the setter: calibration windows still to come stay)
                     counts[w] = certs[w]["n_rescored"]
             for j, i in enumerate(ids):
                 p, ev, am, si, sa = sels[j]
