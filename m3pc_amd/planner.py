@@ -674,7 +674,7 @@ class HipPlanner(GoalMixin, LockstepMixin):
         res = tk.res
         self.last = dict(expect_return=tk.er, expect_return_bf16=tk.er_b if self.rescore != "none" else None, p=p, argmax=argmax,
                          sample_idx=sample_idx, loc=res["loc"], std=res["std"], sample_actions=res["sample_actions"], eps=tk.eps,
-                         topk=top, eval_action=eval_action, sample_action=sample_action, horizon=tk.h, **extra)
+                         topk=top, eval_action=eval_action, sample_action=sample_action, horizon=tk.h, expo=tk.expo, **extra)
         tk.info = self.last
         tk.out = (sample_action, eval_action)
         if sl.owner is tk:
