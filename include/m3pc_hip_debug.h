@@ -58,6 +58,9 @@ int m3pc_debug_attention_bf16(const void* QKV, const void* QKVs, void* O, int ba
  * the candidates' own [K | V] rows; O (n, nq, 512).  kernel as m3pc_debug_attention_bf16 */
 int m3pc_debug_attention_dec_bf16(const void* Qtab, const void* QKVm, const void* KV, void* O, float* pre, int n, int nq, int Lm, int kernel,
                                   void* stream);
+/* the same with Le own [K | V] rows per candidate (KV (n, Le, 1024)) and nq <= 64: the T = 64 decoder is Le = 97, nq = 64 */
+int m3pc_debug_attention_dec_le_bf16(const void* Qtab, const void* QKVm, const void* KV, void* O, float* pre, int n, int nq, int Lm, int Le,
+                                     int kernel, void* stream);
 /* the decoder's bf16 attention of a critic_lambda_guiding candidate pass: Qown (n, Lq <= 4, 512) the candidates' own query rows, Qsh (Lq2, 1536)
  * the batch-shared query rows [Q | . | .], KV (n, 49, 1024) the candidates' own [K | V] rows, QKVm (79, 1536) the batch-shared rows [. | K | V];
  * O (n, Lq + Lq2, 512), own rows first.  kernel as m3pc_debug_attention_bf16 */

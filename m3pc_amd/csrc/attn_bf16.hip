@@ -1108,6 +1108,280 @@ __global__ __launch_bounds__(192, 1) void attn_bf16_pipe_mix_kernel(AttnP p, int
     }
 #endif
 }
+// The T = 64 candidate pass (BASELINE config 4: 97 rows per candidate -- 33 own + 64 history rows in the first layer) in the
+// pipelined form.  attn_bf16_direct_kernel<4, 2, 4> gives every (candidate, head, 64 query slots) a short-lived workgroup: 140-340 us
+// per launch for 200-400 MB.  Same scheme as attn_bf16_pipe_kernel -- persistent workgroup, a loader wave that keeps the next item's rows
+// in flight by LDS-DMA, compute waves that never wait for their stores, O out through the Q image in whole 256-byte rows -- cut for
+// 100-row images: one workgroup per CU (2 x {V | K | Q} = 150 KB), one compute wave per 32-query tile of the item (up to 4), four
+// 32-key tiles in the accumulators, seven 16-key steps of P V.  Query / output rows: the SHQ batch-shared ones first (their fragments
+// stay in registers: a workgroup's items share the head), then the item's own NQ1; keys: the item's own NK1, then SHK shared.
+// PRE: the decoder (all queries shared, the item's own K|V rows, merged with the pre-reduced block of the masked tokens' keys as
+// attn_bf16_pipe_dec_kernel merges it).  Arithmetic and its order are the direct kernel's: bit-identical.
+namespace {
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {  // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): loop indices as immediates
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+constexpr int WPIPE_NR = 100, WPIPE_IMG = WPIPE_NR * 256, WPIPE_BUF = 3 * WPIPE_IMG, WPIPE_LDS = 160 * 1024;
+}
+template <int NQ1, int SHQ, int NK1, int SHK, bool PRE>
+__global__ __launch_bounds__(((NQ1 + SHQ + 31) / 32 + 1) * 64, 1) void attn_bf16_pipe_wide_kernel(AttnP p, int n_items) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int HD = 128, NS = 8, HDT = 4;
+    constexpr int Lq = NQ1 + SHQ, Lk = NK1 + SHK;
+    constexpr int NQT = (Lq + 31) / 32, NKT = (Lk + 31) / 32, NSTEP = (Lk + 15) / 16;
+    constexpr int NTHR = (NQT + 1) * 64;
+    constexpr int NPQ = NQ1 ? (Lq + 3) / 4 - SHQ / 4 : 0;                      // 4-row pieces: the own query rows,
+    constexpr int NPK = (NK1 + 3) / 4 + (SHK ? (Lk + 3) / 4 - NK1 / 4 : 0);    // the two key segments (the piece at the seam twice)
+    constexpr int NDMA = NPQ + 2 * NPK;
+    static_assert(Lq <= WPIPE_NR && Lk <= WPIPE_NR && SHQ % 32 == 0 && NKT <= 4 && NQT <= 4 && (!PRE || (NQ1 == 0 && SHK == 0)), "shapes");
+    // (query rows 100..127 of the second buffer's Q image read up to byte 2 * WPIPE_BUF - WPIPE_IMG + 128 * 256 of the allocation)
+    static_assert(2 * WPIPE_BUF - WPIPE_IMG + 128 * 256 <= WPIPE_LDS, "LDS");
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // WPIPE_LDS bytes
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0 .. NQT - 1: compute (query rows 32 wid ..); NQT: loader
+    const int l31 = lane & 31, lh = lane >> 5;
+    {   // the V rows of keys >= Lk are never written and must be zero: P is exactly zero there
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        constexpr int NZ = (WPIPE_NR - Lk) * 16;
+        for (int i = tid; i < 2 * NZ; i += NTHR) *(u32x4*)(lds + (i / NZ) * WPIPE_BUF + Lk * 256 + (i % NZ) * 16) = z;
+    }
+    const int r4 = lane >> 4, c16 = lane & 15;
+    const int n_mine = ((int)blockIdx.x < n_items) ? (n_items - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int stride = gridDim.x;
+    const int head = blockIdx.x & 3;  // (4 heads, grid a multiple of 4: try_pipe)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    if (wid == NQT) {
+        // ---------------------------------------------------------------- loader
+        auto voff = [&](int ld, int odd) { return (unsigned)(r4 * ld * 2 + ((c16 ^ (4 * odd + r4)) << 4)); };
+        const unsigned vq[2] = {voff(p.ldq, 0), voff(p.ldq, 1)};
+        const unsigned vk[2] = {voff(p.ldkv1, 0), voff(p.ldkv1, 1)}, vk2[2] = {voff(p.ldkv2, 0), voff(p.ldkv2, 1)};
+        auto seg_dma = [&](const bf16_t* src, int ld, const unsigned (&v)[2], char* img, auto r0_c, auto l_c) {
+            constexpr int R0 = decltype(r0_c)::value, L = decltype(l_c)::value;
+            if (L == 0) return;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src - (long long)R0 * ld), 0, (unsigned)((R0 + L) * ld * 2), 0x00020000);
+#pragma unroll
+            for (int pc = R0 / 4; pc <= (R0 + L - 1) / 4; ++pc) {
+                const bool lo = 4 * pc >= R0 ? true : 4 * pc + r4 >= R0;
+                const bool hi = 4 * pc + 3 < R0 + L ? true : 4 * pc + r4 < R0 + L;
+                if (lo && hi) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(img + pc * 1024), 16, v[pc & 1], pc * 4 * ld * 2, 0, 0);
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        auto issue = [&](int it, int buf) {
+            if (p.no_pipe == 3) return;  // (lab timing: no loads)
+            const long long b = it >> 2;
+            char* const B = lds + buf * WPIPE_BUF;
+            seg_dma((const bf16_t*)p.K1 + b * p.kv1_bstride + head * HD, p.ldkv1, vk, B + WPIPE_IMG, I0{}, std::integral_constant<int, NK1>{});
+            seg_dma((const bf16_t*)p.K2 + head * HD, p.ldkv2, vk2, B + WPIPE_IMG, std::integral_constant<int, NK1>{}, std::integral_constant<int, SHK>{});
+            seg_dma((const bf16_t*)p.Q + b * p.q_bstride + head * HD, p.ldq, vq, B + 2 * WPIPE_IMG, std::integral_constant<int, SHQ>{}, std::integral_constant<int, NQ1>{});
+            seg_dma((const bf16_t*)p.V1 + b * p.kv1_bstride + head * HD, p.ldkv1, vk, B, I0{}, std::integral_constant<int, NK1>{});
+            seg_dma((const bf16_t*)p.V2 + head * HD, p.ldkv2, vk2, B, std::integral_constant<int, NK1>{}, std::integral_constant<int, SHK>{});
+        };
+        if (n_mine > 0) issue(blockIdx.x, 0);
+        if (n_mine > 1) issue(blockIdx.x + stride, 1);
+        for (int k = 0; k < n_mine; ++k) {
+            // (the counter holds 63: with more pieces per item the issue of item 1 already waited for item 0's oldest, and "63 outstanding"
+            // of 2 NDMA still means item 0 is in)
+            if (k == 0 && n_mine > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA < 63 ? NDMA : 63) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");  // A: the compute waves start on item k
+            if (k >= 1 && k + 1 < n_mine) issue(blockIdx.x + (k + 1) * stride, (k + 1) & 1);
+            asm volatile("s_barrier" ::: "memory");  // B: they are done with the buffer
+        }
+        return;
+    }
+    // -------------------------------------------------------------------- compute waves
+    const int qrow_i = wid * 32 + l31;  // this lane's query = image row = output row (shared rows first)
+    const int sw = l31 & 7;
+    const int gi = lane & 15;
+    const bool shared_q = wid * 32 < SHQ;  // (wave-uniform)
+    u32x4 qf[NS];
+    if (shared_q) {  // the shared queries of this workgroup's head, once
+        const bf16_t* qsrc = PRE ? (const bf16_t*)p.Q : (const bf16_t*)p.Q2;
+        const int ld = PRE ? p.ldq : p.ldq2;
+        const int qlim = PRE ? p.Lq : SHQ;
+        const bf16_t* qrow = qsrc + head * HD + (long long)(qrow_i < qlim ? qrow_i : 0) * ld + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) qf[s] = *(const u32x4*)(qrow + 16 * s);
+    }
+    float mp = -INFINITY, lp = 0.f;
+    f32x4v po[PRE ? HDT : 1][4];  // (PRE) pre_O of this lane's query at the dims it owns: d * 32 + 8 q + 4 lh ..
+    if constexpr (PRE) {
+        if (qrow_i < p.Lq) {
+            mp = p.pre_m[head * p.Lq + qrow_i];
+            lp = p.pre_l[head * p.Lq + qrow_i];
+        }
+        const float* prow = p.pre_O + ((long long)head * p.Lq + (qrow_i < p.Lq ? qrow_i : 0)) * HD + 4 * lh;
+#pragma unroll
+        for (int d = 0; d < HDT; ++d)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) po[d][q] = *(const f32x4v*)(prow + d * 32 + 8 * q);
+    }
+    const int n_out = PRE ? p.Lq : Lq;  // output rows that exist
+    for (int k = 0; k < n_mine; ++k) {
+        const int it = blockIdx.x + k * stride;
+        const char* const B = lds + (k & 1) * WPIPE_BUF;
+        asm volatile("s_barrier" ::: "memory");  // A
+        if (p.no_pipe == 2) {  // (lab timing: no arithmetic)
+            asm volatile("s_barrier" ::: "memory");
+            continue;
+        }
+        const unsigned vbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)B;  // (the V image: first in the buffer)
+        const char* const Ki = B + WPIPE_IMG;
+        const char* const Qi = B + 2 * WPIPE_IMG;
+        if (!shared_q) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) qf[s] = *(const u32x4*)(Qi + qrow_i * 256 + (((2 * s + lh) ^ sw) << 4));
+        }
+        // ---- S^T = K Q^T (the key tiles' accumulator chains side by side)
+        f32x16 sacc[NKT];
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[t][e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int t = 0; t < NKT; ++t) {
+                const u32x4 kf = *(const u32x4*)(Ki + (32 * t + l31) * 256 + (((2 * s + lh) ^ sw) << 4));
+                sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[s]), sacc[t], 0, 0, 0);
+            }
+        // (a key slot past Lk in both lane halves is dead at compile time: an exact 0 in the sum and in P, the direct kernel's exp2(-inf))
+        float m = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if (jt * 32 + (e & 3) + 8 * (e >> 2) >= Lk) continue;
+                const int j = jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const float v = (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 < Lk || j < Lk) ? sacc[jt][e] * p.scale : -INFINITY;
+                sacc[jt][e] = v;
+                m = fmaxf(m, v);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if (jt * 32 + (e & 3) + 8 * (e >> 2) >= Lk) {
+                    sacc[jt][e] = 0.f;
+                    continue;
+                }
+                const float v = __builtin_amdgcn_exp2f((sacc[jt][e] - m) * 1.44269504088896340736f);
+                sacc[jt][e] = v;
+                l += v;
+            }
+        l += __shfl_xor(l, 32);
+        float inv = 1.0f / l, fpre = 0.f;
+        if constexpr (PRE) {  // the pre-reduced block: two blocks of a streaming softmax (attn_bf16_direct_kernel)
+            const float mt = fmaxf(m, mp);
+            const float a = __builtin_amdgcn_exp2f((m - mt) * 1.44269504088896340736f);
+            const float bs = __builtin_amdgcn_exp2f((mp - mt) * 1.44269504088896340736f);
+            const float lt = l * a + lp * bs;
+            inv = a / lt;
+            fpre = bs / lt;
+        }
+        // ---- O^T = V^T P^T (lane = query, registers = dims).  P leaves the score accumulators as bf16 operands first (a wave has 256
+        // registers here -- five waves on four SIMDs -- and 64 of scores + 64 of output + the transposed V reads do not fit beside the rest)
+        u32x4 pa[NSTEP];
+#pragma unroll
+        for (int n = 0; n < NSTEP; ++n) {
+            bf16x8 w;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = (bf16_t)(sacc[n >> 1][8 * (n & 1) + e] * inv);
+            pa[n] = __builtin_bit_cast(u32x4, w);
+            asm volatile("" : "+v"(pa[n]));
+        }
+        f32x16 oacc[HDT];
+#pragma unroll
+        for (int d = 0; d < HDT; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+        // transposing reads of 16-key step n (see attn_bf16_pipe_kernel; rows past the V image: K rows x exact zeros).  A step's 8 addresses
+        // are 4 per-lane bases (one per 32-dim tile: the swizzle is by row & 7, which a 16-row step does not change) + immediates -- as
+        // registers the 56 of them would be hoisted out of the item loop and spilled
+        s16x4 tv[2][2 * HDT];
+        unsigned tb[HDT];
+        {
+            const int kr = 4 * lh + (gi >> 2);
+#pragma unroll
+            for (int d = 0; d < HDT; ++d) {
+                const int bo = d * 64 + ((lane >> 4) & 1) * 32 + (gi & 3) * 8;
+                tb[d] = vbase + kr * 256 + ((((bo >> 4) ^ (kr & 7)) << 4) | (bo & 15));
+            }
+        }
+        auto tr_reads = [](auto n_c, const unsigned (&tb)[HDT], s16x4 (&v)[2 * HDT]) {  // (no captures: hipcc rejects one in an asm operand of a generic lambda)
+            constexpr int n = decltype(n_c)::value;
+#pragma unroll
+            for (int d = 0; d < HDT; ++d) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v[2 * d]) : "v"(tb[d]), "n"(n * 4096));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v[2 * d + 1]) : "v"(tb[d]), "n"(n * 4096 + 2048));
+            }
+        };
+        tr_reads(std::integral_constant<int, 0>{}, tb, tv[0]);
+        static_for<NSTEP>([&](auto n_c) {
+            constexpr int n = decltype(n_c)::value;
+            s16x4(&cur)[2 * HDT] = tv[n & 1];
+            if constexpr (n < NSTEP - 1) {
+                tr_reads(std::integral_constant<int, n + 1>{}, tb, tv[(n + 1) & 1]);
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
+            }
+#pragma unroll
+            for (int d = 0; d < HDT; ++d) {
+                const s16x8 vb = __builtin_shufflevector(cur[2 * d], cur[2 * d + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vb), __builtin_bit_cast(bf16x8, pa[n]), oacc[d], 0, 0, 0);
+            }
+        });
+        // ---- bf16 through this wave's rows of the Q image (its Q fragments are in registers), whole rows out
+        {
+            char* const Oi = (char*)Qi;
+            if (qrow_i < WPIPE_NR) {
+#pragma unroll
+                for (int d = 0; d < HDT; ++d)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        bf16x4 w;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) w[i] = (bf16_t)(PRE ? fmaf(fpre, po[PRE ? d : 0][q][i], oacc[d][4 * q + i]) : oacc[d][4 * q + i]);
+                        *(bf16x4*)(Oi + qrow_i * 256 + (((4 * d + q) ^ sw) << 4) + 8 * lh) = w;
+                    }
+            }
+        }
+        // read back the rows this wave wrote (same wave: LDS operations execute in order), 4 rows per piece
+        // (a wave whose tile ends before its 8 pieces -- the last one: rows 96..99 -- repeats the image's last piece and sends the repeats
+        // out of the buffer's range: no branches, the same instruction stream for every wave)
+        u32x4 ov[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int pc = 8 * wid + j < WPIPE_NR / 4 ? 8 * wid + j : WPIPE_NR / 4 - 1;
+            ov[j] = *(const u32x4*)(Qi + (4 * pc + r4) * 256 + c16 * 16);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B: the pieces of the item after next may land
+        {
+            const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((bf16_t*)p.O + (long long)(it >> 2) * p.o_bstride + head * HD), 0, 0x7fffffffu, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pc = 8 * wid + j;
+                const int row = 4 * pc + r4;
+                // (output row: with a shared segment the image row itself -- run_block: shared rows first; else orow1 + row)
+                const unsigned off = pc < WPIPE_NR / 4 && row < n_out ? (unsigned)((SHQ && !PRE ? row : p.orow1 + row) * p.ldo * 2) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(ov[j], o_rs, off + ((c16 ^ (row & 7)) << 4), 0, 0);
+            }
+        }
+    }
+#endif
+}
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE opt-in: cached per (kernel, device) -- a process with handles on two
 // GPUs must set it on both (a process-wide flag left the second device without it, and its large-LDS launches failed
 // instead of falling back to the direct kernel).
@@ -1159,15 +1433,31 @@ static bool launch_pipe(const AttnP& p, hipStream_t st) {
     hipLaunchKernelGGL((attn_bf16_pipe_kernel<N1, SH>), dim3(grid), dim3(192), lds_bytes, st, p, n_items);
     return true;
 }
-// the shapes the pipelined kernel is built for (the two encoder layers of the T = 32 candidate pass); everything else takes the kernels below
+static bool wide_off() {  // A/B switch (lab build): the T = 64 shapes on the direct kernel
+    static const bool off = M3PC_ENV("M3PC_NO_ATTN_PIPE_WIDE") != nullptr;
+    return off;
+}
+template <int NQ1, int SHQ, int NK1, int SHK, bool PRE>
+static bool launch_pipe_wide(const AttnP& p, hipStream_t st) {
+    const int n_items = p.batch * p.n_head;
+    const int grid = n_items < 256 ? n_items : 256;  // one workgroup per CU (150 KB of row images); a multiple of the 4 heads
+    if (!lds_opt_in(attn_bf16_pipe_wide_kernel<NQ1, SHQ, NK1, SHK, PRE>, WPIPE_LDS)) return false;
+    constexpr int NTHR = ((NQ1 + SHQ + 31) / 32 + 1) * 64;
+    hipLaunchKernelGGL((attn_bf16_pipe_wide_kernel<NQ1, SHQ, NK1, SHK, PRE>), dim3(grid), dim3(NTHR), WPIPE_LDS, st, p, n_items);
+    return true;
+}
+// the shapes the pipelined kernels are built for (the encoder layers and the decoder of the T = 32 and T = 64 candidate passes); everything
+// else takes the kernels below
 static bool try_pipe(const AttnP& p, hipStream_t st) {
     if (p.hd != 128 || p.n_head != 4 || p.no_pipe == 1 || p.batch * p.n_head < 1024) return false;
     if (p.pre_m) {  // the decoder of an rtg_guiding candidate pass: 32 batch-shared queries, the candidate's own 49 K|V rows, pre-reduced block
-        if (p.q_bstride != 0 || p.Q2 || p.K2 || p.Lq < 1 || p.Lq > 32 || p.L1 != 49 || p.L2 != 0 || !p.pre_l || !p.pre_O) return false;
+        if (p.q_bstride != 0 || p.Q2 || p.K2 || p.Lq < 1 || p.L2 != 0 || !p.pre_l || !p.pre_O) return false;
         if (((uintptr_t)p.Q | (uintptr_t)p.K1 | (uintptr_t)p.V1 | (uintptr_t)p.O | (uintptr_t)p.pre_O) & 15) return false;
         if ((p.ldq | p.ldkv1 | p.ldo) % 8 || (p.kv1_bstride | p.o_bstride) % 8) return false;
-        if ((long long)64 * p.ldkv1 * 2 >= 0x7fffffffLL || (long long)64 * p.ldo * 2 >= 0x7fffffffLL) return false;
-        return launch_pipe_dec<49>(p, st);
+        if ((long long)128 * p.ldkv1 * 2 >= 0x7fffffffLL || (long long)128 * p.ldo * 2 >= 0x7fffffffLL) return false;
+        if (p.Lq <= 32 && p.L1 == 49) return launch_pipe_dec<49>(p, st);
+        if (p.Lq > 32 && p.Lq <= 64 && p.L1 == 97 && !wide_off()) return launch_pipe_wide<0, 64, 97, 0, true>(p, st);  // T = 64
+        return false;
     }
     if (((uintptr_t)p.Q | (uintptr_t)p.K1 | (uintptr_t)p.V1 | (uintptr_t)p.O) & 15) return false;
     if ((p.ldq | p.ldkv1 | p.ldo) % 8 || (p.q_bstride | p.kv1_bstride | p.o_bstride) % 8) return false;
@@ -1179,6 +1469,13 @@ static bool try_pipe(const AttnP& p, hipStream_t st) {
     if ((long long)64 * p.ldq * 2 >= 0x7fffffffLL || (long long)64 * p.ldkv1 * 2 >= 0x7fffffffLL || (long long)64 * p.ldo * 2 >= 0x7fffffffLL) return false;
     if (!p.Q2 && !p.K2 && p.Lq == 49 && p.L1 == 49 && p.L2 == 0 && p.orow1 >= 0) {
         return launch_pipe<49, 0>(p, st);
+    }
+    // T = 64 (BASELINE config 4): 97 rows per candidate; first layer 33 own + 64 shared
+    if ((long long)128 * p.ldq * 2 >= 0x7fffffffLL || (long long)128 * p.ldkv1 * 2 >= 0x7fffffffLL || (long long)128 * p.ldo * 2 >= 0x7fffffffLL) return false;
+    if (!p.Q2 && !p.K2 && p.Lq == 97 && p.L1 == 97 && p.L2 == 0 && p.orow1 >= 0 && !wide_off()) return launch_pipe_wide<97, 0, 97, 0, false>(p, st);
+    if (p.Q2 && p.K2 && p.V2 && p.Lq == 33 && p.L1 == 33 && p.Lq2 == 64 && p.L2 == 64 && p.orow1 == 64 && p.orow2 == 0 && !wide_off() &&
+        !(((uintptr_t)p.Q2 | (uintptr_t)p.K2 | (uintptr_t)p.V2) & 15) && (p.ldq2 | p.ldkv2) % 8 == 0 && (long long)128 * p.ldkv2 * 2 < 0x7fffffffLL) {
+        return launch_pipe_wide<33, 64, 33, 64, false>(p, st);
     }
     // first layer: the history tokens' rows are shared by the batch (run_block: 17 own + 32 shared rows, shared rows first in the output)
     if (p.Q2 && p.K2 && p.V2 && p.Lq == 17 && p.L1 == 17 && p.Lq2 == 32 && p.L2 == 32 && p.orow1 == 32 && p.orow2 == 0 &&

@@ -1469,7 +1469,12 @@ int m3pc_debug_attention_bf16(const void* QKV, const void* QKVs, void* O, int ba
 
 int m3pc_debug_attention_dec_bf16(const void* Qtab, const void* QKVm, const void* KV, void* O, float* pre, int n, int nq, int Lm, int kernel,
                                   void* stream) {
-    const int d = 512, nh = 4, hd = 128, Le = 49;
+    return m3pc_debug_attention_dec_le_bf16(Qtab, QKVm, KV, O, pre, n, nq, Lm, 49, kernel, stream);
+}
+
+int m3pc_debug_attention_dec_le_bf16(const void* Qtab, const void* QKVm, const void* KV, void* O, float* pre, int n, int nq, int Lm, int Le, int kernel,
+                                     void* stream) {
+    const int d = 512, nh = 4, hd = 128;
     hipStream_t st = (hipStream_t)stream;
     float* pre_m = pre;
     float* pre_l = pre + nh * nq;

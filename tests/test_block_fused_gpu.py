@@ -332,12 +332,14 @@ def test_kv_fused_rows_independent_of_batch():
 
 
 # ------------------------------------------------------------------------------------------------ bf16 attention (attn_bf16.hip)
-@pytest.mark.parametrize("batch,n_own,n_sh", [(512, 49, 0), (512, 17, 32), (300, 49, 0), (257, 17, 32), (256, 20, 29)])
+@pytest.mark.parametrize("batch,n_own,n_sh", [(512, 49, 0), (512, 17, 32), (300, 49, 0), (257, 17, 32), (256, 20, 29),
+                                              (512, 97, 0), (300, 97, 0), (512, 33, 64), (257, 33, 64), (256, 40, 57)])
 def test_pipelined_attention_is_the_direct_kernel_bit_for_bit(batch, n_own, n_sh):
     """attn_bf16_pipe_kernel (persistent workgroups, rows by LDS-DMA, two items in flight) against attn_bf16_direct_kernel on the two
     encoder-layer shapes of the candidate pass (second layer: 49 own rows; first: 17 own + 32 history rows shared by the batch): same
     products, same order -- equal bits -- and both against a float64 softmax.  (20 + 29: a split only the direct kernel takes.)
-    Item counts that are / are not multiples of the grid, so that workgroups end on different iterations."""
+    Item counts that are / are not multiples of the grid, so that workgroups end on different iterations.  97 rows (33 own + 64
+    shared in the first layer): the T = 64 pass of BASELINE config 4, attn_bf16_pipe_wide_kernel against attn_bf16_direct_kernel<4, 2, 4>."""
     lib = lab_library()
     fn = lib.m3pc_debug_attention_bf16
     fn.restype = C.c_int
@@ -381,6 +383,39 @@ def test_pipelined_decoder_attention_is_the_direct_kernel_bit_for_bit(n, nq, Lm)
     for kernel in (0, 1):
         O = torch.full((n, nq, 512), float("nan"), device="cuda", dtype=torch.bfloat16)
         rc = fn(qtab.data_ptr(), qkvm.data_ptr(), kv.data_ptr(), O.data_ptr(), pre.data_ptr(), n, nq, Lm, kernel,
+                C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, lib.m3pc_last_error()
+        torch.cuda.synchronize()
+        outs.append(O)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    for b in (0, n // 2, n - 1):
+        q = qtab[:, :512].double()
+        k = torch.cat([kv[b, :, :512], qkvm[:, 512:1024]], 0).double()
+        v = torch.cat([kv[b, :, 512:], qkvm[:, 1024:]], 0).double()
+        ref = torch.cat([torch.softmax(q[:, 128 * h:128 * h + 128] @ k[:, 128 * h:128 * h + 128].T / 128 ** 0.5, -1)
+                         @ v[:, 128 * h:128 * h + 128] for h in range(4)], 1)
+        assert float((outs[0][b].double() - ref).abs().max()) < 3e-2
+
+
+@pytest.mark.parametrize("n,nq,Lm", [(512, 64, 95), (300, 64, 95), (257, 50, 70)])
+def test_pipelined_wide_decoder_attention_is_the_direct_kernel_bit_for_bit(n, nq, Lm):
+    """The T = 64 decoder (BASELINE config 4: 64 batch-shared queries, the candidate's own 97 K|V rows, the pre-reduced block of the masked
+    tokens' keys): attn_bf16_pipe_wide_kernel<0, 64, 97, 0, true> against attn_bf16_direct_kernel<4, 2, 4>: equal bits, and both
+    against a float64 softmax over all keys."""
+    lib = lab_library()
+    fn = lib.m3pc_debug_attention_dec_le_bf16
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]
+    Le = 97
+    g = torch.Generator(device="cuda").manual_seed(n + Lm)
+    qtab = torch.randn(nq, 1536, device="cuda", generator=g).to(torch.bfloat16)
+    qkvm = torch.randn(Lm, 1536, device="cuda", generator=g).to(torch.bfloat16)
+    kv = torch.randn(n, Le, 1024, device="cuda", generator=g).to(torch.bfloat16)
+    pre = torch.zeros(4 * nq * 130, device="cuda")
+    outs = []
+    for kernel in (0, 1):
+        O = torch.full((n, nq, 512), float("nan"), device="cuda", dtype=torch.bfloat16)
+        rc = fn(qtab.data_ptr(), qkvm.data_ptr(), kv.data_ptr(), O.data_ptr(), pre.data_ptr(), n, nq, Lm, Le, kernel,
                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0, lib.m3pc_last_error()
         torch.cuda.synchronize()

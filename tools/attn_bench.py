@@ -12,13 +12,14 @@ from m3pc_amd import capi  # noqa: E402
 
 
 def main():
-    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 512
     lib = capi.load_library()
     fn = lib.m3pc_debug_attention_bf16
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p] * 2
     nset = 10
-    for n_own, n_sh in ((49, 0), (17, 32)):
+    shapes = ((97, 0), (33, 64)) if "T64" in sys.argv else ((49, 0), (17, 32))  # (T64: the 97-row shapes of BASELINE config 4)
+    for n_own, n_sh in shapes:
         L = n_own + n_sh
         sets = [(torch.randn(batch, n_own, 1536, device="cuda").to(torch.bfloat16), torch.randn(max(n_sh, 1), 1536, device="cuda").to(torch.bfloat16),
                  torch.empty(batch, L, 512, device="cuda", dtype=torch.bfloat16)) for _ in range(nset)]
@@ -36,7 +37,7 @@ def main():
                 if rep:
                     ts += [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(nset)]
             ts.sort()
-            if kernel == 0:
+            if kernel == 0 and n_own + n_sh <= 52:
                 stamps = torch.zeros(16, dtype=torch.int64, device="cuda")
                 q, qs, o = sets[0]
                 for _ in range(2):
@@ -53,16 +54,17 @@ def main():
 
 def dec(batch):
     lib = capi.load_library()
-    fn = lib.m3pc_debug_attention_dec_bf16
-    fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]
-    nset, nq, Lm = 10, 32, 47
+    fn0 = lib.m3pc_debug_attention_dec_le_bf16
+    fn0.restype = C.c_int
+    fn0.argtypes = [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]
+    nset, nq, Lm, Le = (10, 64, 95, 97) if "T64" in sys.argv else (10, 32, 47, 49)
+    fn = lambda a, b, c, d, e, n, q_, lm, kernel, s: fn0(a, b, c, d, e, n, q_, lm, Le, kernel, s)
     qtab = torch.randn(nq, 1536, device="cuda").to(torch.bfloat16)
     qkvm = torch.randn(Lm, 1536, device="cuda").to(torch.bfloat16)
     pre = torch.zeros(4 * nq * 130, device="cuda")
-    sets = [(torch.randn(batch, 49, 1024, device="cuda").to(torch.bfloat16), torch.empty(batch, nq, 512, device="cuda", dtype=torch.bfloat16))
+    sets = [(torch.randn(batch, Le, 1024, device="cuda").to(torch.bfloat16), torch.empty(batch, nq, 512, device="cuda", dtype=torch.bfloat16))
             for _ in range(nset)]
-    mb = batch * (49 * 2048 + nq * 1024) / 1e6
+    mb = batch * (Le * 2048 + nq * 1024) / 1e6
     for kernel, name in ((0, "pipelined"), (1, "direct"), (2, "pipe:loads"), (3, "pipe:math")):
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         ts = []
@@ -82,4 +84,4 @@ def dec(batch):
 
 if __name__ == "__main__":
     main()
-    dec(int(sys.argv[1]) if len(sys.argv) > 1 else 512)
+    dec(int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 512)
