@@ -29,5 +29,8 @@ echo "alone done"
 # BASELINE config 5: 8192 zero-shot windows per call
 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_trace_c5 -o kt --output-format csv -- python3 bench.py --config c5 --steps 10 --warmup 2 --no-extras > gpurun_out/${TAG}_trace_c5.log 2>&1
 echo "c5 done"
+# a 2048-candidate shard of BASELINE config 4 (T = 64: the 97-row attentions), serial order
+rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_trace_c4 -o kt --output-format csv -- $B --depth 0 --env halfcheetah --candidates 2048 --horizon 32 --traj-length 64 > gpurun_out/${TAG}_trace_c4.log 2>&1
+echo "c4 shard done"
 python3 bench.py --steps 50 --warmup 10 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 tail -c 400 gpurun_out/${TAG}_bench.json
