@@ -665,6 +665,8 @@ def plan_leg(local_rank, env, guidance, N, H, T, steps=20, warm=4, settle=12, de
     s_, a_, r_, h, rtg = p.assemble_window(hist, rtg=3.0)
     mode = capi.MODE_CRITIC if critic else capi.MODE_RTG
 
+    stamps = []  # host time at which each step's result was in hand (a leg that comes out slow: every step, or one stall?)
+
     def run(k):
         if depth == 0:
             for _ in range(k):
@@ -675,20 +677,24 @@ def plan_leg(local_rank, env, guidance, N, H, T, steps=20, warm=4, settle=12, de
             flight.append(p._issue(mode, s_, a_, r_, rtg, h, 0.6, pipelined=True, inputs_ready=True))
             if len(flight) > depth:
                 flight.popleft().pair()
+                stamps.append(time.perf_counter())
         while flight:
             flight.popleft().pair()
+            stamps.append(time.perf_counter())
 
     run(max(settle, p._cal_windows + capi.SLOTS))  # (every calibration pass of the weight load behind us before anything is timed)
     run(warm)
     if world > 1:
         torch.distributed.barrier(group)
     torch.cuda.synchronize()
+    del stamps[:]
     t0 = time.perf_counter()
     run(steps)
     if world > 1:
         torch.distributed.barrier(group)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gaps = sorted(1e3 * (b - a) for a, b in zip(stamps, stamps[1:]))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
@@ -700,6 +706,8 @@ def plan_leg(local_rank, env, guidance, N, H, T, steps=20, warm=4, settle=12, de
            "ms_per_step": round(ms, 4), "plan_steps_per_s": round(1e3 / ms, 2), "steps": steps, "steps_in_flight": depth,
            "alg_tflop_per_step_per_gpu": round(f_rank / 1e12, 4), "mfma_frac": round(f_rank / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["bf16"], 4),
            "argmax": int(p.last["argmax"].item()), "n_rescored": p.last.get("n_rescored")}
+    if gaps:  # (between consecutive results on the host: the median is the step, the maximum shows a stall)
+        out["step_gap_ms"] = {"median": round(gaps[len(gaps) // 2], 4), "max": round(gaps[-1], 4)}
     if world > 1:
         out["candidates_per_gpu"] = n_local
         out["replicated_ms"] = round(_replicated_ms(p, mode, s_, a_, r_, rtg, h), 4)
