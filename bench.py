@@ -54,6 +54,15 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # /opt/skills/guides/MI355X_
 HBM_PEAK_GBS = 8000.0
 
 
+
+def _quiesce():
+    """A full garbage collection BEFORE a timed region (never inside one): Python's cyclic collector runs a generation-2 pass every
+    ~70 k container allocations, and on this process's heap that pass takes 30-40 ms -- measured (tools/stall_probe.py) as the one
+    20-step leg in four that came out a quarter slower than its neighbours.  Collecting first puts the next such pass far behind
+    the end of the region; the collector stays enabled."""
+    import gc
+    gc.collect()
+
 def alg_flops(N, T, H, S, A, d=512, n_enc=2, mode="rtg"):
     """Algorithmic (exactly pruned) FLOPs of one plan step, SURVEY.md section 8(d)."""
     idx = T - H
@@ -117,6 +126,7 @@ def goal_leg(local_rank, E, T=8, H=4, S=11, A=3, steps=20, warm=3, precisions=("
         n = steps if prec == "bf16" else (fp32_steps or max(3, steps // 4))
         for _ in range(warm):
             p.handle.goal_step_batch(st, ac, T - H, capi.GOAL_PIID, pc, out=out_buf)
+        _quiesce()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -390,6 +400,7 @@ def main():
 
     run(max(args.settle, planner._cal_windows + capi.SLOTS))  # per-weight-load setup (calibration passes included): lets the re-score's error bound settle (a raise repeats that step's merge + select)
     run(args.warmup)
+    _quiesce()
     barrier()
     t0 = time.perf_counter()
     run(args.steps, record=True)
@@ -684,6 +695,7 @@ def plan_leg(local_rank, env, guidance, N, H, T, steps=20, warm=4, settle=12, de
 
     run(max(settle, p._cal_windows + capi.SLOTS))  # (every calibration pass of the weight load behind us before anything is timed)
     run(warm)
+    _quiesce()
     if world > 1:
         torch.distributed.barrier(group)
     torch.cuda.synchronize()

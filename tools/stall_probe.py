@@ -20,8 +20,20 @@ critic = guidance == "critic_lambda_guiding"
 dims = synth.Dims(S, A, T)
 cfg = types.SimpleNamespace(traj_length=T, action_samples=N, horizon=H, discount=0.99, temperature=1.0 if critic else 0.01, lmbda=0.6, plan_guidance=guidance)
 qsd, om, os_ = synth.make_critic(dims, 0) if critic else (None, None, None)
-gcs = []
-gc.callbacks.append(lambda phase, info: gcs.append((time.perf_counter(), phase, info.get("generation"))) if phase == "stop" else None)
+gcs = []     # (start time, duration ms, generation) of every collection
+_gc_t0 = [0.0]
+
+
+def _gc_cb(phase, info):
+    if phase == "start":
+        _gc_t0[0] = time.perf_counter()
+    else:
+        gcs.append((_gc_t0[0], 1e3 * (time.perf_counter() - _gc_t0[0]), info.get("generation")))
+
+
+gc.callbacks.append(_gc_cb)
+if "nogc" in sys.argv:
+    gc.disable()
 for rep in range(4):
     p = HipPlanner(cfg, synth.make_state_dict(dims, 0), synth.make_tokenizer_stats(dims, 0), qsd, om, os_, precision="bf16", device=0,
                    generator=torch.Generator(device="cuda").manual_seed(1), pipeline_depth=3)
@@ -53,6 +65,7 @@ for rep in range(4):
     gaps = [(r[0], round(r[1] + r[2], 2)) for r in rows]
     big = [r for r in rows[20:] if r[1] + r[2] > 1.6 * sorted(x[1] + x[2] for x in rows[20:])[len(rows[20:]) // 2]]
     print(f"rep {rep}: median step {sorted(x[1] + x[2] for x in rows[20:])[len(rows[20:]) // 2]:.2f} ms; slow steps (index, issue ms, wait ms, new segments, n_rescored, n_race, second pass):",
-          [(r[0], round(r[1], 2), round(r[2], 2), r[3], r[4], r[5], r[6]) for r in big], "gc:", len(gcs), flush=True)
+          [(r[0], round(r[1], 2), round(r[2], 2), r[3], r[4], r[5], r[6]) for r in big],
+          "gc: %d collections, longest %s" % (len(gcs), sorted(((round(d, 2), g) for _, d, g in gcs), reverse=True)[:3]), flush=True)
     del gcs[:]
     p.handle.close()
