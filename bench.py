@@ -55,13 +55,26 @@ HBM_PEAK_GBS = 8000.0
 
 
 
-def _quiesce():
-    """A full garbage collection BEFORE a timed region (never inside one): Python's cyclic collector runs a generation-2 pass every
-    ~70 k container allocations, and on this process's heap that pass takes 30-40 ms -- measured (tools/stall_probe.py) as the one
-    20-step leg in four that came out a quarter slower than its neighbours.  Collecting first puts the next such pass far behind
-    the end of the region; the collector stays enabled."""
-    import gc
-    gc.collect()
+class _NoGcPause:
+    """No pass of Python's cyclic collector inside a timed region: on this process's heap (170 k tracked objects) a generation-2
+    pass takes 30-40 ms -- measured (tools/stall_probe.py) as the one 20-step leg in four that came out a quarter slower than its
+    neighbours.  The collector is switched off from the settle / warm-up steps to the end of the timed steps (what `timeit` does),
+    after one full collection IN FRONT of the warm-up: a collection between warm-up and timed steps leaves the GPU idle for those
+    30-40 ms, its clocks drop, and the first timed steps pay for the ramp (measured: 20 timed steps 845-862 -> 783-791 plan-steps/s)."""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+        return False
+
 
 def alg_flops(N, T, H, S, A, d=512, n_enc=2, mode="rtg"):
     """Algorithmic (exactly pruned) FLOPs of one plan step, SURVEY.md section 8(d)."""
@@ -126,7 +139,6 @@ def goal_leg(local_rank, E, T=8, H=4, S=11, A=3, steps=20, warm=3, precisions=("
         n = steps if prec == "bf16" else (fp32_steps or max(3, steps // 4))
         for _ in range(warm):
             p.handle.goal_step_batch(st, ac, T - H, capi.GOAL_PIID, pc, out=out_buf)
-        _quiesce()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -398,14 +410,14 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    run(max(args.settle, planner._cal_windows + capi.SLOTS))  # per-weight-load setup (calibration passes included): lets the re-score's error bound settle (a raise repeats that step's merge + select)
-    run(args.warmup)
-    _quiesce()
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps, record=True)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    with _NoGcPause():
+        run(max(args.settle, planner._cal_windows + capi.SLOTS))  # per-weight-load setup (calibration passes included): lets the re-score's error bound settle (a raise repeats that step's merge + select)
+        run(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps, record=True)
+        barrier()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -693,19 +705,19 @@ def plan_leg(local_rank, env, guidance, N, H, T, steps=20, warm=4, settle=12, de
             flight.popleft().pair()
             stamps.append(time.perf_counter())
 
-    run(max(settle, p._cal_windows + capi.SLOTS))  # (every calibration pass of the weight load behind us before anything is timed)
-    run(warm)
-    _quiesce()
-    if world > 1:
-        torch.distributed.barrier(group)
-    torch.cuda.synchronize()
-    del stamps[:]
-    t0 = time.perf_counter()
-    run(steps)
-    if world > 1:
-        torch.distributed.barrier(group)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    with _NoGcPause():
+        run(max(settle, p._cal_windows + capi.SLOTS))  # (every calibration pass of the weight load behind us before anything is timed)
+        run(warm)
+        if world > 1:
+            torch.distributed.barrier(group)
+        torch.cuda.synchronize()
+        del stamps[:]
+        t0 = time.perf_counter()
+        run(steps)
+        if world > 1:
+            torch.distributed.barrier(group)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     gaps = sorted(1e3 * (b - a) for a, b in zip(stamps, stamps[1:]))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
