@@ -55,6 +55,31 @@ HBM_PEAK_GBS = 8000.0
 
 
 
+def usable_cpus():
+    """CPUs this process can really run on at once: the affinity mask cut to the cgroup's CFS quota.  A GPU box of this pool shows 256
+    CPUs and gives a job `cpu.max = 1600000 100000` = 16 of them; torch sizes its intra-op pool by the former (128 threads), and a
+    pool that wakes -- its workers spin for a while behind every parallel CPU op -- burns the 100-ms quota of the whole process in
+    ~12 ms: every thread, the one that feeds the GPU included, is then frozen until the period ends.  Seen as single 10-30 ms gaps
+    inside 20-step legs (`step_gap_ms.max`)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2: "max 100000" | "1600000 100000"
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:                                                                           # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 class _NoGcPause:
     """No pass of Python's cyclic collector inside a timed region: on this process's heap (170 k tracked objects) a generation-2
     pass takes 30-40 ms -- measured (tools/stall_probe.py) as the one 20-step leg in four that came out a quarter slower than its
@@ -174,11 +199,7 @@ def cpu_baseline(dims, cfg_kw, hist, rtg):
     Also returns the oracle's result for eps = synth.make_eps(N, dims, 1): the parity reference of the `parity` block."""
     from m3pc_amd import synth
     from oracle import mtm_oracle as O
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = min(avail, 64)  # MKL stops scaling on these GEMM shapes well before 64 threads
+    cores = min(usable_cpus(), 64)  # (what the cgroup lets run at once; MKL stops scaling on these GEMM shapes well before 64 threads)
     torch.set_num_threads(cores)
     sd = synth.make_state_dict(dims, 0)
     stats = O.make_stats(synth.make_tokenizer_stats(dims, 0))
@@ -305,6 +326,9 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn(args)
+    # the host threads of the GPU legs must never be frozen by this process's own CPU pool (usable_cpus): two CPUs stay free for the
+    # thread that enqueues and the runtime's; cpu_baseline sizes the pool for itself
+    torch.set_num_threads(max(1, min(usable_cpus(), 64) - 2))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
